@@ -1,0 +1,182 @@
+/* livecc_amd.h -- C-ABI of the MI355X-native LiveCC / Qwen2-VL streaming forward+generate hot path.
+ *
+ * Drop-in boundary.  The reference (showlab/livecc) is Python: demo/infer.py drives HuggingFace
+ * `Qwen2VLForConditionalGeneration.generate` and patches operators into it through three plugin points.
+ * Each entry point below names the reference interface it replaces (ref: = /root/reference, HF: = the
+ * `transformers` package the reference depends on, Q2VL: = HF models/qwen2_vl/modeling_qwen2_vl.py).
+ *
+ * Conventions
+ *   - plain C, no torch types.  All `dev` pointers are device (HBM) pointers on the current HIP device, borrowed:
+ *     the library never frees or retains them except the buffers bound to an engine with lcc_engine_bind_*.
+ *   - `stream` is a hipStream_t passed as void*; every launch goes to that stream; nothing synchronises the
+ *     host except the functions documented as blocking.
+ *   - bf16 tensors are raw uint16 storage; row-major; K (inner) dimension contiguous; pointers 16-byte aligned.
+ *   - return value: 0 on success, a negative lcc_status on error (shape/dtype/alignment are validated up
+ *     front, never UB on a bad shape); lcc_last_error() returns the message of the calling thread.
+ */
+#ifndef LIVECC_AMD_H
+#define LIVECC_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  LCC_OK = 0, LCC_ERR_ARG = -1, LCC_ERR_SHAPE = -2, LCC_ERR_ALIGN = -3, LCC_ERR_HIP = -4, LCC_ERR_STATE = -5
+} lcc_status;
+
+typedef enum {        /* GEMM epilogues, rounding points as HF's bf16 modules */
+  LCC_EPI_NONE = 0,        /* nn.Linear                                      */
+  LCC_EPI_QUICK_GELU = 1,  /* VisionMlp.fc1 + quick_gelu      Q2VL:293-301   */
+  LCC_EPI_GELU_ERF = 2,    /* PatchMerger.mlp[0] + nn.GELU    Q2VL:283-287   */
+  LCC_EPI_RESIDUAL = 3,    /* Linear + residual add           Q2VL:441-448   */
+  LCC_EPI_SWIGLU = 4       /* gate/up (rows interleaved 16|16) + silu*mul  Q2VL:453-466 */
+} lcc_epilogue;
+
+const char* lcc_last_error(void);
+const char* lcc_version(void);
+int lcc_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator level -- the slots of the reference's own operator plugins
+ *   (1) liger `apply_liger_kernel_to_qwen2_vl()`       ref:demo/infer.py:2-3   (RMSNorm/LayerNorm/SwiGLU/M-RoPE)
+ *   (2) HF AttentionInterface (`attn_implementation=`) ref:demo/infer.py:46    HF:modeling_utils.py:5093-5131
+ *   (3) HF Cache.update                                HF:cache_utils.py:127-146
+ *   (4) HF LogitsProcessor / sampler                   ref:demo/infer.py:10-23 HF:generation/utils.py:2894-2925
+ * ------------------------------------------------------------------------------------------------ */
+
+/* nn.Linear / Conv3d-as-GEMM:  C[M,N] = A[M,K] * W[N,K]^T (+bias)(+epilogue).  K%8==0, N%16==0.
+ * M<=16 takes the HBM-bound skinny path; `partial` (fp32 [nsplit][M][N], skinny path only) returns raw split-K slabs. */
+int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                  void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream);
+int lcc_gemv_num_splits(int N, int K);
+/* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
+int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream);
+
+/* HF video processor rescale+normalise+patchify (HF:models/qwen2_vl/video_processing_qwen2_vl.py:236-274,
+ * HF:image_processing_backends.py:307-333).  frames: uint8, layout 0=[T,H,W,3], 1=[T,3,H,W]; out bf16 [P,ld]. */
+int lcc_patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W, const float mean255[3],
+                         const float std255[3], void* out, int ld, void* stream);
+int lcc_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);  /* pixel_values.type(bf16) Q2VL:1044 */
+
+int lcc_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, void* stream); /* Q2VL:428-429,281 */
+int lcc_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int dim, float eps, void* stream);                 /* Q2VL:96-110 */
+/* h += delta (bf16 [rows,dim] or fp32 split-K slabs), then y = rmsnorm(h)*w (w==NULL: add only)   Q2VL:594-612 */
+int lcc_add_rmsnorm_bf16(void* h, const void* delta_bf16, const float* delta_partial, int nsplit, const void* w,
+                         void* y, int rows, int dim, float eps, void* stream);
+int lcc_swiglu_bf16(const void* gate, const void* up, void* out, int64_t n, void* stream);                                /* Q2VL:465 */
+
+/* ViT 2-D RoPE on q,k in place in qkv [P,3E] + V written blocked-transposed (Q2VL:225-248) */
+int lcc_vit_rope_vt_bf16(void* qkv, const float* cos, const float* sin, const int32_t* seg_of_patch,
+                         const int32_t* seg_start, const int32_t* seg_blk_start, void* vt, int P, int heads,
+                         int total_blocks, void* stream);
+/* VisionAttention core (Q2VL:375-417): non-causal attention inside each temporal slice */
+int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, const int32_t* tile_seg, const int32_t* tile_q0,
+                      const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
+                      int heads, int total_blocks, void* stream);
+
+/* M-RoPE tables (Q2VL:156-169) and apply + in-place KV append (Q2VL:180-222 + HF:cache_utils.py:127-146) */
+int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream);
+typedef struct { int n_layers, n_kv_heads, lmax, head_dim; } lcc_kv_layout;
+/* tok_stream[s] = stream slot of row s; tok_pos[s] = its cache index, or NULL -> kv_len[slot] (decode) */
+int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_partial, int nsplit, const void* bias,
+                            const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* tok_pos,
+                            const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer, void* q_out, int S,
+                            int n_q_heads, void* stream);
+/* Qwen2VLAttention core (Q2VL:537-556): causal GQA over the in-place cache */
+int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0,
+                          const int32_t* tile_nq, const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay,
+                          int layer, int n_tiles, int n_q_heads, void* stream);
+/* decode: row b belongs to slot slots[b]; attends to kv_len[slot]+1 keys (its own K/V already appended) */
+int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
+                         lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream);
+
+int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
+                          const void* vit_rows, void* out, int S, int dim, void* stream);             /* Q2VL:1159-1176 */
+int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, void* stream);
+/* RepetitionPenalty -> ThresholdLogitsProcessor -> argmax  (HF:generation/logits_process.py, ref:demo/infer.py:10-23) */
+int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
+                      const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
+                      int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
+                      int32_t* hist_col, float* scores_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model level -- what `model.generate(**inputs, past_key_values=...)` (ref:demo/infer.py:165-172) executes:
+ * ViT (Q2VL:700-729) -> embed+scatter -> 28x decoder layer -> lm_head -> processors -> sample, with the
+ * per-stream state (KV, length, rope_delta position, seen-id bitmap, generated ids) resident on the device.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct lcc_engine lcc_engine;
+
+typedef struct {
+  int vocab_size, hidden_size, intermediate_size, n_layers, n_q_heads, n_kv_heads, head_dim;
+  float rms_eps;
+  int mrope_sec_t, mrope_sec_h, mrope_sec_w;
+  int vit_depth, vit_embed, vit_heads, vit_mlp, patch_dim, merge;
+} lcc_model_config;
+
+typedef struct {
+  int max_slots;        /* concurrent video streams resident on this GPU                      */
+  int max_kv_len;       /* KV capacity per stream (multiple of 32), e.g. 32768                 */
+  int max_new_rows;     /* largest number of new LLM tokens in one prefill call (all streams)  */
+  int max_patches;      /* largest number of ViT patches in one encode call                    */
+  int max_history;      /* generated tokens kept on device per generate call                   */
+} lcc_engine_limits;
+
+lcc_engine* lcc_engine_create(const lcc_model_config* cfg, const lcc_engine_limits* lim);
+void lcc_engine_destroy(lcc_engine* e);
+/* bytes the caller must provide (allocated by PyTorch so that torch.distributed can broadcast into them) */
+size_t lcc_engine_workspace_bytes(const lcc_engine* e);
+size_t lcc_engine_state_bytes(const lcc_engine* e);
+size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e);
+size_t lcc_engine_meta_bytes(const lcc_engine* e);
+int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* state_dev, size_t state_bytes,
+                            void* meta_dev, void* meta_host_pinned, size_t meta_bytes);
+int lcc_engine_bind_kv(lcc_engine* e, int slot, void* kv_dev, size_t bytes);   /* zero-initialised arena */
+/* weights by name, borrowed device pointers (bf16 unless stated):  see INTEGRATION.md for the name table */
+int lcc_engine_set_weight(lcc_engine* e, const char* name, const void* dev, int64_t numel);
+int lcc_engine_weights_ready(const lcc_engine* e, char* missing, int missing_len);
+
+/* stream (slot) state */
+int lcc_slot_reset(lcc_engine* e, int slot, void* stream);                 /* new video stream: empty KV, empty history */
+int lcc_slot_set_length(lcc_engine* e, int slot, int kv_len, int next_pos, void* stream);  /* truncate after EOS */
+int lcc_slot_get_length(const lcc_engine* e, int slot, int* kv_len, int* next_pos);
+
+typedef struct {
+  const uint8_t* frames;     /* device uint8 frames, or NULL when pixel_values is given          */
+  const float* pixel_values; /* device fp32 [P,1176] (the HF processor output) or NULL           */
+  int layout, T, H, W;       /* frames: layout 0 THWC / 1 TCHW; pixel_values: T=grid_t*2, H, W in pixels */
+} lcc_clip;
+/* ViT + merger over n clips -> out bf16 [sum_i P_i/4, hidden].  cos/sin: fp32 [P_total, 40] vision RoPE tables. */
+int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips, const float mean255[3], const float std255[3],
+                   const float* rope_cos, const float* rope_sin, void* out_embeds, void* stream);
+
+typedef struct {
+  float repetition_penalty;  /* 1.0 = off */
+  int thr_token;             /* ThresholdLogitsProcessor token id (" ...") or -1 */
+  int use_thr; float thr_base, thr_step;
+  int eos_token;             /* <|im_end|>: a slot that samples it is frozen for the rest of the call (HF stopping criteria) */
+  int suppress_eos;          /* 1 = MinNewTokensLength active for the whole call (min_new_tokens == max_new_tokens) */
+  float* scores_out;         /* optional device fp32 [n_streams, V] of processed scores of the LAST step */
+  void* logits_out;          /* optional device bf16 [steps, n_streams, V] raw logits of every step (parity tests) */
+} lcc_sampling;
+
+/* Prefill of n_streams streams: host arrays are copied through the engine's pinned meta ring.
+ *   slots[n]; n_new[n]; ids[S] (S = sum n_new); vit_index[S] (-1 text, else row of vit_embeds);
+ *   pos3[3*S] M-RoPE positions (host computes them: Q2VL:914-1016 / 1349-1351).
+ * Appends K/V, runs the layers, samples the first new token of every stream (history column 0). */
+int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slots, const int32_t* n_new, const int32_t* ids,
+                    const int32_t* vit_index, const void* vit_embeds, const int32_t* pos3, const lcc_sampling* sp,
+                    void* stream);
+/* n_steps further decode steps for the same streams without any host round trip. */
+int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots, int n_steps, int first_step_index,
+                   const lcc_sampling* sp, void* stream);
+/* blocking: copy the ids generated by the last generate call of a slot to the host (at most max_n), report how many
+ * were generated (EOS included) and refresh the host mirror of the slot's KV length / next position. */
+int lcc_slot_read_tokens(lcc_engine* e, int slot, int32_t* out, int max_n, int* n_generated, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIVECC_AMD_H */

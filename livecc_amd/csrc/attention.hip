@@ -1,0 +1,373 @@
+// Attention kernels of the LiveCC hot path on gfx950 (flash-style, fp32 online softmax, bf16 MFMA).
+//
+// Replaces (HF modeling_qwen2_vl.py): VisionAttention 342-422 (non-causal, one segment per temporal slice,
+// cu_seqlens from vision_utils.py:42-65), Qwen2VLAttention 537-556 (causal, bottom-right aligned, GQA) for
+// prefill and for single-token decode, and the DynamicCache concat (cache_utils.py:127-146) which here is an
+// in-place append done by rope_kv_append (elementwise.hip).
+//
+// Formulation ("swapped QK^T"): one wave owns NQ*16 query columns.  For each 32-key tile
+//     S^T[key][q] = K[key][:] . Q[q][:]        A operand = K rows (16-byte loads, K is d-contiguous)
+//     O^T[d][q]  += V^T[d][key] . P^T[key][q]   A operand = V^T rows (V is stored blocked-transposed,
+//                                               [32-key block][d][32], so these are 16-byte loads too)
+// In the C/D layout a lane owns ONE query column (l&15) and 4 keys per MFMA, so the softmax row statistics
+// (max / sum / rescale factor) are lane-local plus two cross-lane steps (xor 16, 32), P feeds the second
+// MFMA directly from registers (the MFMA row->key map is permuted so a lane ends with 8 consecutive keys),
+// and no LDS is used at all: every operand goes HBM/L2 -> VGPR -> MFMA once.
+#include "common.h"
+#include "kernels.h"
+
+namespace lcc {
+
+template <int D, int NQ>
+struct AttnAcc {
+  f32x4 o[D / 16][NQ];
+  float m[NQ], l[NQ];
+  LCC_DEVICE void init() {
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      m[n] = -INFINITY;
+      l[n] = 0.f;
+#pragma unroll
+      for (int d = 0; d < D / 16; ++d) o[d][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+};
+
+template <int D>
+struct KFrag {
+  static constexpr int KS = (D + 31) / 32;
+  u32x4 v[2][KS];
+};
+
+// K rows of the tile starting at key kb.  krow(key) returns the row pointer (already clamped by the caller's
+// lambda to a readable row); lanes whose d-chunk lies beyond D load zeros (D = 80: chunks 10, 11).
+template <int D, class RowPtr>
+LCC_DEVICE void load_k(KFrag<D>& f, RowPtr krow, int kb, int li, int g) {
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = kb + (li >> 2) * 8 + kt * 4 + (li & 3);
+    const bf16_t* p = krow(key);
+#pragma unroll
+    for (int ks = 0; ks < KFrag<D>::KS; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      f.v[kt][ks] = (d0 < D) ? ld16(p + d0) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+}
+
+template <int D>
+LCC_DEVICE void load_v(u32x4 (&vf)[D / 16], const bf16_t* vt_block, int li, int g) {
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) vf[dt] = ld16(vt_block + (dt * 16 + li) * 32 + g * 8);
+}
+
+// one 32-key tile: scores, masking, online softmax, PV accumulation
+// key_limit[n] : keys with index >= key_limit[n] are masked for query tile n's column of this lane
+template <int D, int NQ>
+LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (&vf)[D / 16],
+                          const u32x4 (&qf)[NQ][(D + 31) / 32], int kb, int g, const int (&key_limit)[NQ],
+                          float scale_log2e) {
+  constexpr int KS = (D + 31) / 32;
+  f32x4 s[2][NQ];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a = mfma16(as_bf16x8(kf.v[kt][ks]), as_bf16x8(qf[n][ks]), a);
+      s[kt][n] = a;
+    }
+  bf16x8 pf[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + g * 8 + kt * 4 + r;
+        float v = (key < key_limit[n]) ? s[kt][n][r] * scale_log2e : -INFINITY;
+        s[kt][n][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(acc.m[n], mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(acc.m[n] - m_use);  // acc.m = -inf -> 0
+    acc.m[n] = m_new;
+    float p[8], psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = exp2f(s[kt][n][r] - m_use);
+        p[kt * 4 + r] = e;
+        psum += e;
+      }
+    acc.l[n] = acc.l[n] * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) acc.o[dt][n] *= alpha;
+    u32x4 pk = (u32x4){pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])};
+    pf[n] = as_bf16x8(pk);
+  }
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) acc.o[dt][n] = mfma16(as_bf16x8(vf[dt]), pf[n], acc.o[dt][n]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT attention: non-causal inside each temporal slice (segment).  grid = (ceil(n_tiles/4), heads),
+// 4 waves per block, one 32-query tile per wave.  qkv is the [P, 3*E] output of the qkv GEMM with q,k
+// already rotated in place; vt is the blocked-transposed V written by vit_rope_vt.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NQ>
+__global__ __launch_bounds__(256) void attn_vit_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+    const int32_t* __restrict__ tile_seg, const int32_t* __restrict__ tile_q0,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+    const int32_t* __restrict__ seg_blk_start, int n_tiles, int heads, int total_blocks, float scale_log2e) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= n_tiles) return;
+  const int h = blockIdx.y;
+  const int E = heads * D, ld = 3 * E;
+  const int sg = tile_seg[tile], q0 = tile_q0[tile];
+  const int s0 = seg_start[sg], sl = seg_len[sg];
+  constexpr int KS = (D + 31) / 32;
+
+  u32x4 qf[NQ][KS];
+  int key_limit[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int ql = min(q0 + n * 16 + li, sl - 1);  // clamp: columns beyond the segment are computed but not stored
+    const bf16_t* qp = qkv + (size_t)(s0 + ql) * ld + h * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      qf[n][ks] = (d0 < D) ? ld16(qp + d0) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    key_limit[n] = sl;
+  }
+  const bf16_t* kbase = qkv + (size_t)s0 * ld + E + h * D;
+  auto krow = [&](int key) { return kbase + (size_t)min(key, sl - 1) * ld; };
+  const bf16_t* vbase = vt + ((size_t)h * total_blocks + seg_blk_start[sg]) * (D * 32);
+
+  AttnAcc<D, NQ> acc;
+  acc.init();
+  KFrag<D> kf;
+  load_k<D>(kf, krow, 0, li, g);
+  const int ntile = (sl + 31) / 32;
+  for (int t = 0; t < ntile; ++t) {
+    u32x4 vf[D / 16];
+    load_v<D>(vf, vbase + (size_t)t * (D * 32), li, g);
+    KFrag<D> kcur = kf;
+    if (t + 1 < ntile) load_k<D>(kf, krow, (t + 1) * 32, li, g);
+    attn_tile<D, NQ>(acc, kcur, vf, qf, t * 32, g, key_limit, scale_log2e);
+  }
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float l = acc.l[n];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const int ql = q0 + n * 16 + li;
+    if (ql < sl) {
+      bf16_t* op = out + (size_t)(s0 + ql) * E + h * D;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        f32x4 o = acc.o[dt][n];
+        st8(op + dt * 16 + g * 4, (u32x2){pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv)});
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLM prefill attention: causal (bottom-right aligned), GQA, K/V read from the per-stream cache that
+// already contains this call's new keys.  grid = (ceil(n_tiles/4), n_q_heads).  A tile = NQ*16 consecutive
+// new tokens of one stream: tile_stream/tile_q0 (row in the packed q buffer)/tile_nq (valid rows)/
+// tile_pos0 (cache index of the first row = past_len + offset).
+// ------------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(
+    const bf16_t* __restrict__ q, bf16_t* __restrict__ out, const int32_t* __restrict__ tile_stream,
+    const int32_t* __restrict__ tile_q0, const int32_t* __restrict__ tile_nq,
+    const int32_t* __restrict__ tile_pos0, bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer,
+    int n_tiles, int n_q_heads, float scale_log2e) {
+  constexpr int D = 128, KS = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= n_tiles) return;
+  const int h = blockIdx.y, hk = h / (n_q_heads / lay.n_kv_heads);
+  const int strm = tile_stream[tile], q0 = tile_q0[tile], nq = tile_nq[tile], pos0 = tile_pos0[tile];
+  const int ldq = n_q_heads * D;
+
+  u32x4 qf[NQ][KS];
+  int key_limit[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int r = min(n * 16 + li, nq - 1);
+    const bf16_t* qp = q + (size_t)(q0 + r) * ldq + h * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[n][ks] = ld16(qp + ks * 32 + g * 8);
+    key_limit[n] = pos0 + r + 1;  // causal: keys 0..pos (inclusive)
+  }
+  const bf16_t* base = kv_base[strm] + (size_t)layer * lay.layer_stride();
+  const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
+  const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
+  const int kv_n = pos0 + nq;  // keys visible to the last row of this tile
+  auto krow = [&](int key) { return kbase + (size_t)min(key, kv_n - 1) * D; };
+
+  AttnAcc<D, NQ> acc;
+  acc.init();
+  KFrag<D> kf;
+  load_k<D>(kf, krow, 0, li, g);
+  const int ntile = (kv_n + 31) / 32;
+  for (int t = 0; t < ntile; ++t) {
+    u32x4 vf[D / 16];
+    load_v<D>(vf, vbase + (size_t)t * (D * 32), li, g);
+    KFrag<D> kcur = kf;
+    if (t + 1 < ntile) load_k<D>(kf, krow, (t + 1) * 32, li, g);
+    attn_tile<D, NQ>(acc, kcur, vf, qf, t * 32, g, key_limit, scale_log2e);
+  }
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float l = acc.l[n];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const int r = n * 16 + li;
+    if (r < nq) {
+      bf16_t* op = out + (size_t)(q0 + r) * ldq + h * D;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        f32x4 o = acc.o[dt][n];
+        st8(op + dt * 16 + g * 4, (u32x2){pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv)});
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLM decode attention: one new token per stream.  The G = Hq/Hkv query heads that share a KV head are the
+// query columns of one wave (G <= 16), so every K/V byte is read once per KV head.  grid = (nsplit, Hkv, B),
+// one wave per block; split s handles key tiles [s*per, (s+1)*per).  HBM-bound: L*512 bytes per KV head.
+// Partial (o, m, l) go to a workspace, attn_decode_combine merges the splits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_decode_kernel(
+    const bf16_t* __restrict__ q, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
+    bf16_t* const* __restrict__ kv_base,
+    KvLayout lay, int layer, int n_q_heads, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml,
+    float scale_log2e) {
+  constexpr int D = 128, KS = 4, NQ = 1;
+  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+  const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int G = n_q_heads / lay.n_kv_heads;
+  const int slot_id = slots[b];
+  const int n = kv_len[slot_id] + 1;  // the new token's K/V were appended at index kv_len[slot] by rope_kv_append
+  const int ntile = (n + 31) / 32;
+  const int per = (ntile + nsplit - 1) / nsplit;
+  const int t0 = split * per, t1 = min(ntile, t0 + per);
+
+  u32x4 qf[NQ][KS];
+  int key_limit[NQ] = {n};
+  {
+    const int hq = hk * G + min(li, G - 1);
+    const bf16_t* qp = q + ((size_t)b * n_q_heads + hq) * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[0][ks] = ld16(qp + ks * 32 + g * 8);
+  }
+  const bf16_t* base = kv_base[slot_id] + (size_t)layer * lay.layer_stride();
+  const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
+  const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
+  auto krow = [&](int key) { return kbase + (size_t)min(key, n - 1) * D; };
+
+  AttnAcc<D, NQ> acc;
+  acc.init();
+  if (t0 < t1) {
+    KFrag<D> kf;
+    load_k<D>(kf, krow, t0 * 32, li, g);
+    for (int t = t0; t < t1; ++t) {
+      u32x4 vf[D / 16];
+      load_v<D>(vf, vbase + (size_t)t * (D * 32), li, g);
+      KFrag<D> kcur = kf;
+      if (t + 1 < t1) load_k<D>(kf, krow, (t + 1) * 32, li, g);
+      attn_tile<D, NQ>(acc, kcur, vf, qf, t * 32, g, key_limit, scale_log2e);
+    }
+  }
+  float l = acc.l[0];
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (li < G) {
+    const size_t slot = (((size_t)b * lay.n_kv_heads + hk) * nsplit + split) * 16 + li;
+    float* op = ws_o + slot * D;
+#pragma unroll
+    for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + g * 4) = acc.o[dt][0];
+    if (g == 0) {
+      ws_ml[slot * 2 + 0] = acc.m[0];
+      ws_ml[slot * 2 + 1] = l;
+    }
+  }
+}
+
+// grid = (Hq, B), 128 threads: thread d merges the splits of one head.
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(
+    const float* __restrict__ ws_o, const float* __restrict__ ws_ml, bf16_t* __restrict__ out, int n_q_heads,
+    int n_kv_heads, int nsplit) {
+  constexpr int D = 128;
+  const int hq = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int G = n_q_heads / n_kv_heads, hk = hq / G, j = hq % G;
+  const size_t slot0 = (((size_t)b * n_kv_heads + hk) * nsplit) * 16 + j;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(slot0 + (size_t)s * 16) * 2]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const size_t slot = slot0 + (size_t)s * 16;
+    const float m = ws_ml[slot * 2], l = ws_ml[slot * 2 + 1];
+    const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
+    num += w * ws_o[slot * D + d];
+    den += w * l;
+  }
+  out[((size_t)b * n_q_heads + hq) * D + d] = f2bf(num / den);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
+
+int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* tile_seg, const int32_t* tile_q0,
+                  const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
+                  int heads, int total_blocks, hipStream_t st) {
+  if (n_tiles <= 0) return 0;
+  attn_vit_kernel<80, 2><<<dim3((n_tiles + 3) / 4, heads), dim3(256), 0, st>>>(
+      qkv, vt, out, tile_seg, tile_q0, seg_start, seg_len, seg_blk_start, n_tiles, heads, total_blocks,
+      scale_l2e(80));
+  return 0;
+}
+
+int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0,
+                      const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
+                      int layer, int n_tiles, int n_q_heads, hipStream_t st) {
+  if (n_tiles <= 0) return 0;
+  if (lay.head_dim != 128 || (lay.lmax & 31)) return LCC_ERR_SHAPE;
+  attn_prefill_kernel<2><<<dim3((n_tiles + 3) / 4, n_q_heads), dim3(256), 0, st>>>(
+      q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128));
+  return 0;
+}
+
+int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
+                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
+  attn_decode_kernel<<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
+      q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128));
+  attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
+                                                                       lay.n_kv_heads, nsplit);
+  return 0;
+}
+
+}  // namespace lcc

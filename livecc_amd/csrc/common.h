@@ -1,0 +1,95 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the LiveCC hot path.
+// wave = 64 lanes; MFMA fragments follow the gfx950 16x16x32 bf16 layout:
+//   A operand: lane l holds A[i = l&15][k = (l>>4)*8 + e], e = 0..7   (8 bf16 = 16 bytes)
+//   B operand: lane l holds B[k = (l>>4)*8 + e][j = l&15]
+//   C/D      : lane l holds D[row = (l>>4)*4 + r][col = l&15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcc {
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LCC_DEVICE __device__ __forceinline__
+
+LCC_DEVICE float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (same rounding as torch's c10::BFloat16)
+LCC_DEVICE bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// value of x after rounding to bf16 (used to reproduce HF's per-op bf16 rounding points)
+LCC_DEVICE float rbf(float x) { return bf2f(f2bf(x)); }
+
+LCC_DEVICE unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+LCC_DEVICE float lo2f(unsigned v) { return __uint_as_float(v << 16); }
+LCC_DEVICE float hi2f(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+
+LCC_DEVICE bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+LCC_DEVICE u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+
+LCC_DEVICE u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+LCC_DEVICE void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+LCC_DEVICE u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
+LCC_DEVICE void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+
+LCC_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// wave-wide reductions (64 lanes)
+LCC_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+LCC_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blocks of NW waves; `red` is a shared float[NW] scratch
+template <int NW>
+LCC_DEVICE float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if (NW == 1) return v;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+// activations, with HF's bf16 rounding points (inputs are already-rounded bf16 values held in fp32)
+// quick_gelu: HF activations.py QuickGELUActivation: input * sigmoid(1.702 * input) on bf16 tensors
+LCC_DEVICE float quick_gelu_bf16(float x) {
+  float t = rbf(1.702f * x);
+  float s = rbf(1.0f / (1.0f + expf(-t)));
+  return rbf(x * s);
+}
+// exact (erf) GELU: torch gelu on bf16 computes in fp32 and rounds once
+LCC_DEVICE float gelu_erf_bf16(float x) { return rbf(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f))); }
+// silu on bf16: x / (1 + exp(-x)) in fp32, rounded once
+LCC_DEVICE float silu_bf16(float x) { return rbf(x / (1.0f + expf(-x))); }
+
+enum Epilogue : int {
+  EPI_NONE = 0,        // C = bf16(acc + bias)
+  EPI_QUICK_GELU = 1,  // C = quick_gelu(bf16(acc + bias))
+  EPI_GELU_ERF = 2,    // C = gelu(bf16(acc + bias))
+  EPI_RESIDUAL = 3,    // C = bf16(residual + bf16(acc + bias))
+  EPI_SWIGLU = 4,      // W rows interleaved [16 gate | 16 up]; C[:, n/2] = bf16(silu(bf16 g) * bf16 u)
+};
+
+}  // namespace lcc

@@ -1,0 +1,488 @@
+// HBM-bound elementwise / normalisation / layout kernels of the LiveCC hot path (gfx950).
+// All bf16 traffic is 16 bytes per lane; reductions are wave shuffles (64 lanes) + a tiny LDS step.
+// Every kernel reproduces the rounding points of the HF op it replaces (cited per kernel).
+#include "common.h"
+#include "kernels.h"
+
+namespace lcc {
+
+static inline int64_t host_min(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------------------
+// K1: rescale + normalise + patchify, uint8 frames -> bf16 patch rows [P, 1176]
+//   HF video_processing_qwen2_vl.py:236-274 (patch order t, h/2, w/2, 2, 2; feature c*392+tt*196+py*14+px)
+//   HF image_processing_backends.py:307-333: (float(x) - mean*255) / (std*255) in fp32, then the model casts
+//   pixel_values to bf16 (modeling_qwen2_vl.py:1044).  The reference ships 4704 B/patch of fp32 over PCIe;
+//   here 1176 B/patch of uint8 are read from HBM.
+// layout 0: [T,H,W,3] (decoder-native), 1: [T,3,H,W] (what get_smart_resized_clip returns)
+// ------------------------------------------------------------------------------------------------
+struct NormConst { float mean[3], stdv[3]; };
+
+__global__ __launch_bounds__(256) void patchify_norm_kernel(const uint8_t* __restrict__ f, int layout, int T, int H,
+                                                            int W, bf16_t* __restrict__ out, int ld, NormConst nc,
+                                                            int P, int chunks_per_row) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P * chunks_per_row) return;
+  const int p = idx / chunks_per_row, c8 = (idx - p * chunks_per_row) * 8;
+  const int gh = H / 14, gw = W / 14, hb_n = gh / 2, wb_n = gw / 2;
+  int r = p;
+  const int mw = r & 1; r >>= 1;
+  const int mh = r & 1; r >>= 1;
+  const int wb = r % wb_n; r /= wb_n;
+  const int hb = r % hb_n; r /= hb_n;
+  const int tg = r;
+  const int py0 = (hb * 2 + mh) * 14, px0 = (wb * 2 + mw) * 14;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int col = c8 + e;
+    const int c = col / 392; col -= c * 392;
+    const int tt = col / 196; col -= tt * 196;
+    const int py = col / 14, px = col - py * 14;
+    const int t = min(tg * 2 + tt, T - 1);  // odd T: last frame repeated (video_processing_qwen2_vl.py:246-250)
+    const int y = py0 + py, x = px0 + px;
+    const size_t a = layout == 0 ? (((size_t)t * H + y) * W + x) * 3 + c : (((size_t)t * 3 + c) * H + y) * W + x;
+    v[e] = ((float)f[a] - nc.mean[c]) / nc.stdv[c];
+  }
+  st16(out + (size_t)p * ld + c8, (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])});
+}
+
+int patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W, const float* mean255,
+                     const float* std255, bf16_t* out, int ld, hipStream_t st) {
+  if (H % 28 || W % 28 || T <= 0 || (ld & 7) || ld < 1176) return LCC_ERR_SHAPE;
+  const int P = ((T + 1) / 2) * (H / 14) * (W / 14);
+  NormConst nc;
+  for (int i = 0; i < 3; ++i) { nc.mean[i] = mean255[i]; nc.stdv[i] = std255[i]; }
+  const int cpr = 1176 / 8;
+  patchify_norm_kernel<<<dim3((P * cpr + 255) / 256), dim3(256), 0, st>>>(frames, layout, T, H, W, out, ld, nc, P, cpr);
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                            int64_t n8) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + i * 8), b = *reinterpret_cast<const f32x4*>(in + i * 8 + 4);
+    st16(out + i * 8, (u32x4){pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])});
+  }
+}
+int cast_f32_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st) {
+  if (n & 7) return LCC_ERR_SHAPE;
+  const int64_t n8 = n / 8;
+  if (n8 == 0) return 0;
+  cast_f32_bf16_kernel<<<dim3((unsigned)host_min((n8 + 255) / 256, 4096)), dim3(256), 0, st>>>(in, out, n8);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row kernels: NW waves cooperate on one row of `dim` elements, MAXC 8-element chunks per thread in registers
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (ViT): torch native_layer_norm on bf16 = fp32 statistics, y = (x-mean)*rstd*w + b, one rounding.
+// HF modeling_qwen2_vl.py:428-429 (norm1/norm2), 281 (merger ln_q); eps 1e-6.
+template <int NW, int MAXC>
+__global__ __launch_bounds__(NW * 64) void layernorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                            int dim, float eps) {
+  __shared__ float red[NW];
+  const int row = blockIdx.x, tid = threadIdx.x, nchunk = dim / 8;
+  const bf16_t* xr = x + (size_t)row * dim;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = tid + c * NW * 64;
+    if (ch < nchunk) {
+      const u32x4 q = ld16(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo2f(q[e]); v[c][2 * e + 1] = hi2f(q[e]); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e];
+    }
+  }
+  const float mean = block_sum<NW>(s, red) / (float)dim;
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = tid + c * NW * 64;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; s2 += d * d; }
+    }
+  }
+  const float var = block_sum<NW>(s2, red) / (float)dim;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = tid + c * NW * 64;
+    if (ch < nchunk) {
+      const u32x4 wq = ld16(w + ch * 8), bq = ld16(b + ch * 8);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = (v[c][2 * e] - mean) * rstd * lo2f(wq[e]) + lo2f(bq[e]);
+        o[2 * e + 1] = (v[c][2 * e + 1] - mean) * rstd * hi2f(wq[e]) + hi2f(bq[e]);
+      }
+      st16(y + (size_t)row * dim + ch * 8,
+           (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])});
+    }
+  }
+}
+
+int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int dim, float eps,
+                   hipStream_t st) {
+  if (rows <= 0) return 0;
+  if ((dim & 7) || dim > 4 * 64 * 8 * 4) return LCC_ERR_SHAPE;
+  if (dim <= 64 * 8 * 4) layernorm_kernel<1, 4><<<dim3(rows), dim3(64), 0, st>>>(x, w, b, y, dim, eps);
+  else layernorm_kernel<4, 4><<<dim3(rows), dim3(256), 0, st>>>(x, w, b, y, dim, eps);
+  return 0;
+}
+
+// (residual add +) RMSNorm (LLM).  HF modeling_qwen2_vl.py:96-110: fp32 x, var = mean(x^2),
+// xhat = x*rsqrt(var+eps) -> cast to bf16 -> weight * xhat (bf16 product, rounded).  Residual add =
+// `residual + hidden_states` on bf16 tensors (decoder layer 604, 610): fp32 add, one rounding.
+// DELTA 0: none; 1: bf16 delta [rows,dim]; 2: fp32 split-K slabs [nsplit][rows][dim] (summed in slab order,
+// rounded to bf16 like the Linear output they stand for).
+template <int NW, int MAXC, int DELTA>
+__global__ __launch_bounds__(NW * 64) void add_rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ dbf,
+                                                              const float* __restrict__ dpart, int nsplit, int rows,
+                                                              const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                              int dim, float eps) {
+  __shared__ float red[NW];
+  const int row = blockIdx.x, tid = threadIdx.x, nchunk = dim / 8;
+  bf16_t* hr = h + (size_t)row * dim;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = tid + c * NW * 64;
+    if (ch < nchunk) {
+      const u32x4 q = ld16(hr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo2f(q[e]); v[c][2 * e + 1] = hi2f(q[e]); }
+      if (DELTA == 1) {
+        const u32x4 d = ld16(dbf + (size_t)row * dim + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[c][2 * e] = rbf(v[c][2 * e] + lo2f(d[e])); v[c][2 * e + 1] = rbf(v[c][2 * e + 1] + hi2f(d[e])); }
+      } else if (DELTA == 2) {
+        float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; ++sp) {
+          const float* pp = dpart + ((size_t)sp * rows + row) * dim + ch * 8;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { d[e] += a[e]; d[4 + e] += b[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = rbf(v[c][e] + rbf(d[e]));
+      }
+      if (DELTA != 0)
+        st16(hr + ch * 8, (u32x4){pack2(v[c][0], v[c][1]), pack2(v[c][2], v[c][3]), pack2(v[c][4], v[c][5]),
+                                  pack2(v[c][6], v[c][7])});
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e] * v[c][e];
+    }
+  }
+  if (w == nullptr) return;
+  const float var = block_sum<NW>(s, red) / (float)dim;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = tid + c * NW * 64;
+    if (ch < nchunk) {
+      const u32x4 wq = ld16(w + ch * 8);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = lo2f(wq[e]) * rbf(v[c][2 * e] * rstd);
+        o[2 * e + 1] = hi2f(wq[e]) * rbf(v[c][2 * e + 1] * rstd);
+      }
+      st16(y + (size_t)row * dim + ch * 8,
+           (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])});
+    }
+  }
+}
+
+int add_rmsnorm_bf16(bf16_t* h, const bf16_t* delta_bf16, const float* delta_partial, int nsplit, const bf16_t* w,
+                     bf16_t* y, int rows, int dim, float eps, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if ((dim & 7) || dim > 4 * 64 * 8 * 4) return LCC_ERR_SHAPE;
+  if (delta_bf16 != nullptr && delta_partial != nullptr) return LCC_ERR_ARG;
+  if (delta_partial != nullptr)
+    add_rmsnorm_kernel<4, 4, 2><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, delta_partial, nsplit, rows, w, y, dim, eps);
+  else if (delta_bf16 != nullptr)
+    add_rmsnorm_kernel<4, 4, 1><<<dim3(rows), dim3(256), 0, st>>>(h, delta_bf16, nullptr, 0, rows, w, y, dim, eps);
+  else
+    add_rmsnorm_kernel<4, 4, 0><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, nullptr, 0, rows, w, y, dim, eps);
+  return 0;
+}
+
+int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int dim, float eps, hipStream_t st) {
+  if (w == nullptr) return LCC_ERR_ARG;
+  return add_rmsnorm_bf16(const_cast<bf16_t*>(x), nullptr, nullptr, 0, w, y, rows, dim, eps, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT 2-D RoPE on q,k (in place in the qkv GEMM output) + V written blocked-transposed for the attention
+// kernel.  HF modeling_qwen2_vl.py:225-248: fp32 q*cos + rotate_half(q)*sin, one rounding to bf16; head_dim
+// 80 = cat(freqs, freqs) with freqs = [20 h-freqs | 20 w-freqs] (700-713, vision_utils.py:81-127).
+// cos/sin: fp32 [P, 40].  One thread = 8 channels (c..c+7, c < 40) and their partners (c+40..): 5 threads per
+// (patch, head, q|k), plus 10 threads per (patch, head) moving V.
+// vt layout: [head][block][80][32], block = seg_blk_start[seg] + local_index/32.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_rope_vt_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cs,
+                                                          const float* __restrict__ sn,
+                                                          const int32_t* __restrict__ seg_of_patch,
+                                                          const int32_t* __restrict__ seg_start,
+                                                          const int32_t* __restrict__ seg_blk_start,
+                                                          bf16_t* __restrict__ vt, int P, int heads, int total_blocks) {
+  constexpr int D = 80, HALF = 40;
+  const int items_per_ph = 5 * 2 + 10;  // 5 chunks x (q,k) + 10 V chunks
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)P * heads * items_per_ph) return;
+  const int it = (int)(idx % items_per_ph);
+  const int64_t ph = idx / items_per_ph;
+  const int h = (int)(ph % heads), p = (int)(ph / heads);
+  const int E = heads * D;
+  bf16_t* row = qkv + (size_t)p * 3 * E;
+  if (it < 10) {
+    const int which = it / 5, c0 = (it % 5) * 8;
+    bf16_t* base = row + which * E + h * D;
+    const u32x4 a = ld16(base + c0), b = ld16(base + c0 + HALF);
+    float x1[8], x2[8], o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x1[2 * e] = lo2f(a[e]); x1[2 * e + 1] = hi2f(a[e]); x2[2 * e] = lo2f(b[e]); x2[2 * e + 1] = hi2f(b[e]); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float c = cs[(size_t)p * HALF + c0 + e], s = sn[(size_t)p * HALF + c0 + e];
+      o1[e] = x1[e] * c - x2[e] * s;  // q*cos + (-x2)*sin
+      o2[e] = x2[e] * c + x1[e] * s;
+    }
+    st16(base + c0, (u32x4){pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])});
+    st16(base + c0 + HALF, (u32x4){pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])});
+  } else {
+    const int c0 = (it - 10) * 8;
+    const u32x4 a = ld16(row + 2 * E + h * D + c0);
+    const int sg = seg_of_patch[p];
+    const int kl = p - seg_start[sg];
+    bf16_t* dst = vt + (((size_t)h * total_blocks + seg_blk_start[sg] + (kl >> 5)) * D + c0) * 32 + (kl & 31);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[(2 * e) * 32] = (bf16_t)(a[e] & 0xffffu);
+      dst[(2 * e + 1) * 32] = (bf16_t)(a[e] >> 16);
+    }
+  }
+}
+
+int vit_rope_vt_bf16(bf16_t* qkv, const float* cos, const float* sin, const int32_t* seg_of_patch,
+                     const int32_t* seg_start, const int32_t* seg_blk_start, bf16_t* vt, int P, int heads,
+                     int total_blocks, hipStream_t st) {
+  if (P <= 0) return 0;
+  const int64_t n = (int64_t)P * heads * 20;
+  vit_rope_vt_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(qkv, cos, sin, seg_of_patch, seg_start,
+                                                                             seg_blk_start, vt, P, heads, total_blocks);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M-RoPE cos/sin tables: HF modeling_qwen2_vl.py:156-169: freqs = inv_freq * pos (fp32), cos/sin in fp32,
+// cast to the model dtype (bf16).  Only the 64 unique channels are stored ([S,64]); channel c takes the
+// position axis mrope_section assigns to it (180-222: [16,24,24] -> t,h,w).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mrope_table_kernel(const int32_t* __restrict__ pos3, const float* __restrict__ inv_freq,
+                                                          int S, int sec_t, int sec_h, bf16_t* __restrict__ cs,
+                                                          bf16_t* __restrict__ sn) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * 64) return;
+  const int s = idx >> 6, c = idx & 63;
+  const int axis = c < sec_t ? 0 : (c < sec_t + sec_h ? 1 : 2);
+  const float ang = inv_freq[c] * (float)pos3[(size_t)axis * S + s];
+  cs[idx] = f2bf(cosf(ang));
+  sn[idx] = f2bf(sinf(ang));
+}
+
+int mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, bf16_t* cos, bf16_t* sin,
+                hipStream_t st) {
+  if (S <= 0) return 0;
+  mrope_table_kernel<<<dim3((S * 64 + 255) / 256), dim3(256), 0, st>>>(pos3, inv_freq, S, sec_t, sec_h, cos, sin);
+  return 0;
+}
+
+// decode variant: one position per stream taken from a device counter (all three axes equal:
+// HF modeling_qwen2_vl.py:1349-1351), so that consecutive decode steps need no host round trip.
+__global__ __launch_bounds__(64) void mrope_table_decode_kernel(const int32_t* __restrict__ slots, const int32_t* __restrict__ pos,
+                                                                const float* __restrict__ inv_freq,
+                                                                bf16_t* __restrict__ cs, bf16_t* __restrict__ sn) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float ang = inv_freq[c] * (float)pos[slots[b]];
+  cs[b * 64 + c] = f2bf(cosf(ang));
+  sn[b * 64 + c] = f2bf(sinf(ang));
+}
+int mrope_table_decode(const int32_t* slots, const int32_t* pos, const float* inv_freq, int B, bf16_t* cos, bf16_t* sin,
+                       hipStream_t st) {
+  if (B <= 0) return 0;
+  mrope_table_decode_kernel<<<dim3(B), dim3(64), 0, st>>>(slots, pos, inv_freq, cos, sin);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M-RoPE apply + in-place KV append (replaces apply_multimodal_rotary_pos_emb 180-222 and
+// DynamicLayer.update's torch.cat, cache_utils.py:127-146: 57,344 B/token written instead of 2*L*57,344 moved).
+// bf16 op-by-op rounding as HF: out = bf16(bf16(x*cos) + bf16(rot(x)*sin)).
+// K -> cache [Hkv][Lmax][128]; V -> cache blocked-transposed [Hkv][Lmax/32][128][32]; q -> q_out [S, Hq*128].
+// One thread = 8 channels c..c+7 (c < 64) and partners c+64: 8 threads per rope head; 16 threads per V head.
+// QSRC 0: qkv bf16 [S, ld]; 1: fp32 split-K slabs [nsplit][S][ld] + bias (decode path).
+// ------------------------------------------------------------------------------------------------
+template <int QSRC>
+LCC_DEVICE void load8(const bf16_t* qkv, const float* part, int nsplit, int S, const bf16_t* bias, int s, int ld,
+                      int col, float (&v)[8]) {
+  if (QSRC == 0) {
+    const u32x4 a = ld16(qkv + (size_t)s * ld + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = lo2f(a[e]); v[2 * e + 1] = hi2f(a[e]); }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float* pp = part + ((size_t)sp * S + s) * ld + col;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    }
+    const u32x4 bq = ld16(bias + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = rbf(v[2 * e] + lo2f(bq[e])); v[2 * e + 1] = rbf(v[2 * e + 1] + hi2f(bq[e])); }
+  }
+}
+
+template <int QSRC>
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ part, int nsplit, const bf16_t* __restrict__ bias,
+    const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn, const int32_t* __restrict__ tok_stream,
+    const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ kv_len, bf16_t* const* __restrict__ kv_base,
+    KvLayout lay, int layer, bf16_t* __restrict__ q_out, int S, int n_q_heads) {
+  constexpr int D = 128;
+  const int hkv = lay.n_kv_heads;
+  const int per_tok = (n_q_heads + hkv) * 8 + hkv * 16;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)S * per_tok) return;
+  const int s = (int)(idx / per_tok);
+  int it = (int)(idx - (int64_t)s * per_tok);
+  const int ld = (n_q_heads + 2 * hkv) * D;
+  const int strm = tok_stream[s];
+  const int slot = tok_pos != nullptr ? tok_pos[s] : kv_len[strm];  // cache index of this token
+  bf16_t* base = kv_base[strm] + (size_t)layer * lay.layer_stride();
+  if (it < (n_q_heads + hkv) * 8) {
+    const int head = it >> 3, c0 = (it & 7) * 8;
+    float x1[8], x2[8], o1[8], o2[8];
+    load8<QSRC>(qkv, part, nsplit, S, bias, s, ld, head * D + c0, x1);
+    load8<QSRC>(qkv, part, nsplit, S, bias, s, ld, head * D + c0 + 64, x2);
+    const u32x4 cq = ld16(cs + (size_t)s * 64 + c0), sq = ld16(sn + (size_t)s * 64 + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float c = (e & 1) ? hi2f(cq[e >> 1]) : lo2f(cq[e >> 1]);
+      const float sv = (e & 1) ? hi2f(sq[e >> 1]) : lo2f(sq[e >> 1]);
+      o1[e] = rbf(x1[e] * c) + rbf(-x2[e] * sv);
+      o2[e] = rbf(x2[e] * c) + rbf(x1[e] * sv);
+    }
+    const u32x4 r1 = (u32x4){pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])};
+    const u32x4 r2 = (u32x4){pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
+    bf16_t* dst;
+    if (head < n_q_heads) dst = q_out + (size_t)s * n_q_heads * D + head * D;
+    else dst = base + (size_t)(head - n_q_heads) * lay.head_stride() + (size_t)slot * D;
+    st16(dst + c0, r1);
+    st16(dst + c0 + 64, r2);
+  } else {
+    it -= (n_q_heads + hkv) * 8;
+    const int hv = it >> 4, c0 = (it & 15) * 8;
+    float x[8];
+    load8<QSRC>(qkv, part, nsplit, S, bias, s, ld, (n_q_heads + hkv + hv) * D + c0, x);
+    bf16_t* dst = base + lay.kv_stride() + (size_t)hv * lay.head_stride() + ((size_t)(slot >> 5) * D + c0) * 32 + (slot & 31);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e * 32] = f2bf(x[e]);
+  }
+}
+
+int rope_kv_append_bf16(const bf16_t* qkv_bf16, const float* qkv_partial, int nsplit, const bf16_t* bias,
+                        const bf16_t* cos, const bf16_t* sin, const int32_t* tok_stream, const int32_t* tok_pos,
+                        const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay, int layer, bf16_t* q_out, int S,
+                        int n_q_heads, hipStream_t st) {
+  if (S <= 0) return 0;
+  if (lay.head_dim != 128 || (lay.lmax & 31)) return LCC_ERR_SHAPE;
+  if (tok_pos == nullptr && kv_len == nullptr) return LCC_ERR_ARG;
+  const int per_tok = (n_q_heads + lay.n_kv_heads) * 8 + lay.n_kv_heads * 16;
+  const int64_t n = (int64_t)S * per_tok;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (qkv_partial != nullptr) {
+    if (bias == nullptr) return LCC_ERR_ARG;
+    rope_kv_append_kernel<1><<<grid, dim3(256), 0, st>>>(nullptr, qkv_partial, nsplit, bias, cos, sin, tok_stream,
+                                                         tok_pos, kv_len, kv_base, lay, layer, q_out, S, n_q_heads);
+  } else {
+    rope_kv_append_kernel<0><<<grid, dim3(256), 0, st>>>(qkv_bf16, nullptr, 0, nullptr, cos, sin, tok_stream, tok_pos,
+                                                         kv_len, kv_base, lay, layer, q_out, S, n_q_heads);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// token embedding gather + ViT row scatter (HF modeling_qwen2_vl.py:1159-1176: embed_tokens then
+// masked_scatter of the video rows in order).  vit_index[s] < 0 -> embedding row ids[s]; else ViT row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ indirect,
+                                                           const int32_t* __restrict__ vit_index,
+                                                           const bf16_t* __restrict__ table, const bf16_t* __restrict__ vit_rows,
+                                                           bf16_t* __restrict__ out, int S, int dim) {
+  const int cpr = dim / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)S * cpr; i += (int64_t)gridDim.x * 256) {
+    const int s = (int)(i / cpr), c = (int)(i - (int64_t)s * cpr);
+    const int vi = vit_index != nullptr ? vit_index[s] : -1;
+    const int id = indirect != nullptr ? ids[indirect[s]] : ids[s];
+    const bf16_t* src = vi >= 0 ? vit_rows + (size_t)vi * dim : table + (size_t)id * dim;
+    st16(out + (size_t)s * dim + c * 8, ld16(src + c * 8));
+  }
+}
+int embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const bf16_t* table,
+                      const bf16_t* vit_rows, bf16_t* out, int S, int dim, hipStream_t st) {
+  if (S <= 0) return 0;
+  if (dim & 7) return LCC_ERR_SHAPE;
+  const int64_t n = (int64_t)S * (dim / 8);
+  embed_gather_kernel<<<dim3((unsigned)host_min((n + 255) / 256, 8192)), dim3(256), 0, st>>>(ids, indirect, vit_index, table, vit_rows, out, S, dim);
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ in, const int32_t* __restrict__ rows,
+                                                          bf16_t* __restrict__ out, int n, int dim) {
+  const int cpr = dim / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)n * cpr; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / cpr), c = (int)(i - (int64_t)r * cpr);
+    st16(out + (size_t)r * dim + c * 8, ld16(in + (size_t)rows[r] * dim + c * 8));
+  }
+}
+int gather_rows_bf16(const bf16_t* in, const int32_t* rows, bf16_t* out, int n, int dim, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (dim & 7) return LCC_ERR_SHAPE;
+  const int64_t t = (int64_t)n * (dim / 8);
+  gather_rows_kernel<<<dim3((unsigned)host_min((t + 255) / 256, 4096)), dim3(256), 0, st>>>(in, rows, out, n, dim);
+  return 0;
+}
+
+// standalone SwiGLU for the HF plugin path (liger's LigerSwiGLUMLP slot): out = bf16(silu(g) * u)
+__global__ __launch_bounds__(256) void swiglu_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u,
+                                                     bf16_t* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u32x4 a = ld16(g + i * 8), b = ld16(u + i * 8);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = silu_bf16(lo2f(a[e])) * lo2f(b[e]);
+      o[2 * e + 1] = silu_bf16(hi2f(a[e])) * hi2f(b[e]);
+    }
+    st16(out + i * 8, (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])});
+  }
+}
+int swiglu_bf16(const bf16_t* g, const bf16_t* u, bf16_t* out, int64_t n, hipStream_t st) {
+  if (n & 7) return LCC_ERR_SHAPE;
+  const int64_t n8 = n / 8;
+  if (n8 == 0) return 0;
+  swiglu_kernel<<<dim3((unsigned)host_min((n8 + 255) / 256, 8192)), dim3(256), 0, st>>>(g, u, out, n8);
+  return 0;
+}
+
+}  // namespace lcc

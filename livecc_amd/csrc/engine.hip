@@ -1,0 +1,798 @@
+// Model-level engine: the forward/generate arithmetic of `Qwen2VLForConditionalGeneration` (HF
+// modeling_qwen2_vl.py: visual.forward 700-729, Qwen2VLModel.forward 1144-1204, Qwen2VLTextModel.forward 762-844,
+// lm_head 1320-1323, GenerationMixin._sample utils.py:2783-2960) as one C++ launch sequence per call over
+// the HIP kernels, with every per-stream state (KV, lengths, rope position, seen-id bitmap, generated ids)
+// resident in HBM.  Host code only enqueues; the decode loop runs n steps without a host round trip.
+//
+// Memory comes from the caller (PyTorch allocations): weights, one KV arena per stream slot, an activation
+// workspace, a small device state block, and a pinned-host + device "meta" ring through which the per-call
+// integer tables (ids, positions, tile tables) travel in ONE async copy per call.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/livecc_amd.h"
+#include "kernels.h"
+
+using namespace lcc;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(x)                                                                          \
+  do {                                                                                      \
+    hipError_t e__ = (x);                                                                   \
+    if (e__ != hipSuccess) return fail(LCC_ERR_HIP, "%s: %s", #x, hipGetErrorString(e__)); \
+  } while (0)
+#define LCC_TRY(x)                                                            \
+  do {                                                                        \
+    int r__ = (x);                                                            \
+    if (r__ != 0) {                                                           \
+      if (g_err[0] == 0 || r__ != LCC_ERR_HIP) fail(r__, "%s failed (%d)", #x, r__); \
+      return r__;                                                             \
+    }                                                                         \
+  } while (0)
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LCC_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" const char* lcc_last_error(void) { return g_err; }
+extern "C" const char* lcc_version(void) { return "livecc_amd 0.1.0 (gfx950)"; }
+extern "C" int lcc_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, dev));
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct VitLayerW { const bf16_t *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
+struct LlmLayerW { const bf16_t *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gate_up_w, *down_w; };
+
+struct Carver {  // bump allocator over a caller-provided region
+  char* base = nullptr;
+  size_t off = 0;
+  template <class T>
+  T* take(size_t n) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off = align_up(off + n * sizeof(T));
+    return p;
+  }
+};
+
+constexpr int META_RING = 4;
+constexpr int MAX_SPLIT = 8;
+
+}  // namespace
+
+struct lcc_engine {
+  lcc_model_config c;
+  lcc_engine_limits lim;
+  int qd, kvd, qkvd, words, E, vit_hd;
+  KvLayout lay;
+
+  // weights
+  std::map<std::string, const void*> w;
+  std::vector<VitLayerW> vit;
+  std::vector<LlmLayerW> llm;
+  const bf16_t *patch_embed = nullptr, *mg_ln_w = nullptr, *mg_ln_b = nullptr, *mg_fc1_w = nullptr, *mg_fc1_b = nullptr,
+               *mg_fc2_w = nullptr, *mg_fc2_b = nullptr, *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
+  const float* inv_freq = nullptr;
+  bool weights_resolved = false;
+
+  // buffers
+  char* ws = nullptr; size_t ws_bytes = 0;
+  char* state = nullptr; size_t state_bytes = 0;
+  char *meta_dev = nullptr, *meta_host = nullptr; size_t meta_bytes = 0, meta_slot_bytes = 0;
+  int meta_next = 0;
+  hipEvent_t meta_ev[META_RING] = {};
+  bool meta_ev_used[META_RING] = {};
+
+  // device state (inside `state`)
+  int32_t *d_kv_len = nullptr, *d_pos = nullptr, *d_hist_col = nullptr, *d_cur_tok = nullptr, *d_done = nullptr, *d_history = nullptr;
+  uint32_t* d_seen = nullptr;
+  bf16_t** d_kv_base = nullptr;
+  // host mirrors
+  std::vector<int> h_kv_len, h_pos;
+  std::vector<void*> h_kv_base;
+
+  size_t llm_ws_bytes() const;
+  size_t vit_ws_bytes() const;
+};
+
+size_t lcc_engine::llm_ws_bytes() const {
+  const size_t S = lim.max_new_rows, B = lim.max_slots;
+  const size_t H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  size_t t = 0;
+  t += align_up(S * H * 2) * 2;              // h, xn
+  t += align_up(S * qkvd * 2);               // qkv
+  t += align_up(S * qd * 2) * 2;             // q, attn
+  t += align_up(S * I * 2);                  // act
+  t += align_up(S * 64 * 2) * 2;             // cos, sin
+  t += align_up((size_t)MAX_SPLIT * 16 * std::max<size_t>(qkvd, H) * 4);  // split-K slabs
+  t += align_up(B * H * 2) * 2;              // last_h, last_xn
+  t += align_up(B * V * 2);                  // logits
+  t += align_up(B * c.n_kv_heads * 64 * 16 * 128 * 4) + align_up(B * c.n_kv_heads * 64 * 16 * 2 * 4);  // decode attn ws
+  return t + 4096;
+}
+size_t lcc_engine::vit_ws_bytes() const {
+  const size_t P = lim.max_patches, Ev = c.vit_embed;
+  const size_t blocks = P / 32 + 2 * (P / 64 + 1) + 64;  // generous: every segment rounds up to a 32-key block
+  size_t t = 0;
+  t += align_up(P * (size_t)c.patch_dim * 2);  // patches
+  t += align_up(P * Ev * 2) * 3;               // x, xn, attn
+  t += align_up(P * 3 * Ev * 2);               // qkv
+  t += align_up(P * (size_t)c.vit_mlp * 2);    // mlp
+  t += align_up((size_t)c.vit_heads * blocks * 80 * 32 * 2);  // vt
+  t += align_up(P / 4 * 4 * Ev * 2 + 256);     // merger hidden
+  return t + 4096;
+}
+
+extern "C" lcc_engine* lcc_engine_create(const lcc_model_config* cfg, const lcc_engine_limits* lim) {
+  if (!cfg || !lim) { fail(LCC_ERR_ARG, "null config"); return nullptr; }
+  if (cfg->head_dim != 128 || cfg->vit_embed / cfg->vit_heads != 80 || cfg->vit_embed % cfg->vit_heads) {
+    fail(LCC_ERR_SHAPE, "head_dim must be 128 (LLM) and 80 (ViT)"); return nullptr;
+  }
+  if (cfg->n_q_heads % cfg->n_kv_heads || cfg->n_q_heads / cfg->n_kv_heads > 16) { fail(LCC_ERR_SHAPE, "GQA group must be <= 16"); return nullptr; }
+  if ((lim->max_kv_len & 31) || lim->max_slots <= 0 || lim->max_slots > 16 * 1024) { fail(LCC_ERR_SHAPE, "max_kv_len %% 32, max_slots"); return nullptr; }
+  if ((cfg->vocab_size & 31) || (cfg->hidden_size & 15) || (cfg->intermediate_size & 15) || cfg->patch_dim != 1176 || cfg->merge != 2) {
+    fail(LCC_ERR_SHAPE, "vocab %% 32, hidden/intermediate %% 16, patch_dim 1176, merge 2"); return nullptr;
+  }
+  if (cfg->mrope_sec_t + cfg->mrope_sec_h + cfg->mrope_sec_w != 64) { fail(LCC_ERR_SHAPE, "mrope sections must sum to 64"); return nullptr; }
+  lcc_engine* e = new lcc_engine();
+  e->c = *cfg; e->lim = *lim;
+  e->qd = cfg->n_q_heads * 128; e->kvd = cfg->n_kv_heads * 128; e->qkvd = e->qd + 2 * e->kvd;
+  e->words = cfg->vocab_size / 32; e->E = cfg->vit_embed; e->vit_hd = 80;
+  e->lay = KvLayout{cfg->n_layers, cfg->n_kv_heads, lim->max_kv_len, 128};
+  e->vit.resize(cfg->vit_depth); e->llm.resize(cfg->n_layers);
+  e->h_kv_len.assign(lim->max_slots, 0); e->h_pos.assign(lim->max_slots, 0); e->h_kv_base.assign(lim->max_slots, nullptr);
+  return e;
+}
+extern "C" void lcc_engine_destroy(lcc_engine* e) {
+  if (!e) return;
+  for (int i = 0; i < META_RING; ++i) if (e->meta_ev[i]) (void)hipEventDestroy(e->meta_ev[i]);
+  delete e;
+}
+extern "C" size_t lcc_engine_workspace_bytes(const lcc_engine* e) { return std::max(e->llm_ws_bytes(), e->vit_ws_bytes()); }
+extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
+  const size_t B = e->lim.max_slots;
+  return align_up(B * 4) * 5 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096;
+}
+extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->lay.total() * 2; }
+extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
+  const size_t S = e->lim.max_new_rows, P = e->lim.max_patches, B = e->lim.max_slots;
+  const size_t llm = (7 * S + 4 * (S / 32 + B + 1) + 4 * B + 64) * 4;
+  const size_t vit = (P + 5 * (P / 16 + 64) + 64) * 4;
+  return align_up(std::max(llm, vit) + 4096, 4096) * META_RING;
+}
+
+extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* state_dev, size_t state_bytes,
+                                       void* meta_dev, void* meta_host_pinned, size_t meta_bytes) {
+  if (!e || !workspace_dev || !state_dev || !meta_dev || !meta_host_pinned) return fail(LCC_ERR_ARG, "null buffer");
+  if (ws_bytes < lcc_engine_workspace_bytes(e) || state_bytes < lcc_engine_state_bytes(e) || meta_bytes < lcc_engine_meta_bytes(e))
+    return fail(LCC_ERR_STATE, "buffer too small: ws %zu/%zu state %zu/%zu meta %zu/%zu", ws_bytes, lcc_engine_workspace_bytes(e),
+                state_bytes, lcc_engine_state_bytes(e), meta_bytes, lcc_engine_meta_bytes(e));
+  if (((uintptr_t)workspace_dev | (uintptr_t)state_dev | (uintptr_t)meta_dev) & 255) return fail(LCC_ERR_ALIGN, "buffers must be 256-byte aligned");
+  e->ws = (char*)workspace_dev; e->ws_bytes = ws_bytes;
+  e->state = (char*)state_dev; e->state_bytes = state_bytes;
+  e->meta_dev = (char*)meta_dev; e->meta_host = (char*)meta_host_pinned; e->meta_bytes = meta_bytes;
+  e->meta_slot_bytes = lcc_engine_meta_bytes(e) / META_RING;
+  const size_t B = e->lim.max_slots;
+  Carver cv; cv.base = e->state;
+  e->d_kv_len = cv.take<int32_t>(B); e->d_pos = cv.take<int32_t>(B); e->d_hist_col = cv.take<int32_t>(B);
+  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_kv_base = cv.take<bf16_t*>(B);
+  e->d_history = cv.take<int32_t>(B * (size_t)e->lim.max_history);
+  e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
+  HIP_TRY(hipMemset(e->state, 0, state_bytes));
+  for (int i = 0; i < META_RING; ++i) if (!e->meta_ev[i]) HIP_TRY(hipEventCreateWithFlags(&e->meta_ev[i], hipEventDisableTiming));
+  return 0;
+}
+
+extern "C" int lcc_engine_bind_kv(lcc_engine* e, int slot, void* kv_dev, size_t bytes) {
+  if (!e || slot < 0 || slot >= e->lim.max_slots || !kv_dev) return fail(LCC_ERR_ARG, "bad slot/pointer");
+  if (!e->state) return fail(LCC_ERR_STATE, "bind_buffers first");
+  if (bytes < lcc_engine_kv_bytes_per_slot(e)) return fail(LCC_ERR_STATE, "kv arena too small: %zu < %zu", bytes, lcc_engine_kv_bytes_per_slot(e));
+  if ((uintptr_t)kv_dev & 255) return fail(LCC_ERR_ALIGN, "kv arena must be 256-byte aligned");
+  e->h_kv_base[slot] = kv_dev;
+  HIP_TRY(hipMemcpy(e->d_kv_base + slot, &kv_dev, sizeof(void*), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int lcc_engine_set_weight(lcc_engine* e, const char* name, const void* dev, int64_t numel) {
+  if (!e || !name || !dev) return fail(LCC_ERR_ARG, "null");
+  if ((uintptr_t)dev & 15) return fail(LCC_ERR_ALIGN, "weight %s not 16-byte aligned", name);
+  (void)numel;
+  e->w[name] = dev;
+  e->weights_resolved = false;
+  return 0;
+}
+
+static int resolve_weights(lcc_engine* e, std::string* missing) {
+  auto get = [&](const std::string& n) -> const bf16_t* {
+    auto it = e->w.find(n);
+    if (it == e->w.end()) { if (missing) { *missing += n; *missing += ' '; } return nullptr; }
+    return (const bf16_t*)it->second;
+  };
+  e->patch_embed = get("vit.patch_embed");
+  for (int i = 0; i < e->c.vit_depth; ++i) {
+    const std::string p = "vit." + std::to_string(i) + ".";
+    VitLayerW& L = e->vit[i];
+    L.ln1_w = get(p + "ln1_w"); L.ln1_b = get(p + "ln1_b"); L.qkv_w = get(p + "qkv_w"); L.qkv_b = get(p + "qkv_b");
+    L.proj_w = get(p + "proj_w"); L.proj_b = get(p + "proj_b"); L.ln2_w = get(p + "ln2_w"); L.ln2_b = get(p + "ln2_b");
+    L.fc1_w = get(p + "fc1_w"); L.fc1_b = get(p + "fc1_b"); L.fc2_w = get(p + "fc2_w"); L.fc2_b = get(p + "fc2_b");
+  }
+  e->mg_ln_w = get("merger.ln_w"); e->mg_ln_b = get("merger.ln_b"); e->mg_fc1_w = get("merger.fc1_w");
+  e->mg_fc1_b = get("merger.fc1_b"); e->mg_fc2_w = get("merger.fc2_w"); e->mg_fc2_b = get("merger.fc2_b");
+  e->embed = get("embed");
+  for (int i = 0; i < e->c.n_layers; ++i) {
+    const std::string p = "llm." + std::to_string(i) + ".";
+    LlmLayerW& L = e->llm[i];
+    L.in_norm = get(p + "in_norm"); L.qkv_w = get(p + "qkv_w"); L.qkv_b = get(p + "qkv_b"); L.o_w = get(p + "o_w");
+    L.post_norm = get(p + "post_norm"); L.gate_up_w = get(p + "gate_up_w"); L.down_w = get(p + "down_w");
+  }
+  e->final_norm = get("final_norm"); e->lm_head = get("lm_head");
+  e->inv_freq = (const float*)get("inv_freq");
+  if (missing && !missing->empty()) return LCC_ERR_STATE;
+  e->weights_resolved = true;
+  return 0;
+}
+extern "C" int lcc_engine_weights_ready(const lcc_engine* e, char* missing, int missing_len) {
+  std::string m;
+  int r = resolve_weights(const_cast<lcc_engine*>(e), &m);
+  if (missing && missing_len > 0) snprintf(missing, missing_len, "%s", m.c_str());
+  return r == 0 ? 1 : 0;
+}
+static int ensure_ready(lcc_engine* e) {
+  if (!e) return fail(LCC_ERR_ARG, "null engine");
+  if (!e->ws) return fail(LCC_ERR_STATE, "buffers not bound");
+  if (!e->weights_resolved) {
+    std::string m;
+    if (resolve_weights(e, &m) != 0) return fail(LCC_ERR_STATE, "missing weights: %.400s", m.c_str());
+  }
+  return 0;
+}
+
+// meta ring: fill host slot, one async H2D copy, return device pointers with the same offsets
+struct MetaWriter {
+  lcc_engine* e; int slot; char* host; char* dev; size_t off = 0, cap;
+  template <class T>
+  T* put(const T* src, size_t n, T** dev_out) {
+    T* h = reinterpret_cast<T*>(host + off);
+    if (off + n * sizeof(T) > cap) return nullptr;
+    if (src) memcpy(h, src, n * sizeof(T));
+    *dev_out = reinterpret_cast<T*>(dev + off);
+    off = align_up(off + n * sizeof(T), 16);
+    return h;
+  }
+};
+static int meta_begin(lcc_engine* e, MetaWriter* mw) {
+  const int s = e->meta_next;
+  e->meta_next = (s + 1) % META_RING;
+  if (e->meta_ev_used[s]) HIP_TRY(hipEventSynchronize(e->meta_ev[s]));
+  mw->e = e; mw->slot = s; mw->host = e->meta_host + (size_t)s * e->meta_slot_bytes; mw->dev = e->meta_dev + (size_t)s * e->meta_slot_bytes;
+  mw->off = 0; mw->cap = e->meta_slot_bytes;
+  return 0;
+}
+static int meta_commit(MetaWriter* mw, hipStream_t st) {
+  if (mw->off == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(mw->dev, mw->host, mw->off, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(mw->e->meta_ev[mw->slot], st));
+  mw->e->meta_ev_used[mw->slot] = true;
+  return 0;
+}
+
+extern "C" int lcc_slot_reset(lcc_engine* e, int slot, void* stream) {
+  if (!e || slot < 0 || slot >= e->lim.max_slots) return fail(LCC_ERR_ARG, "bad slot");
+  if (!e->state) return fail(LCC_ERR_STATE, "buffers not bound");
+  hipStream_t st = (hipStream_t)stream;
+  e->h_kv_len[slot] = 0; e->h_pos[slot] = 0;
+  HIP_TRY(hipMemsetAsync(e->d_kv_len + slot, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_pos + slot, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_hist_col + slot, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_done + slot, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_seen + (size_t)slot * e->words, 0, (size_t)e->words * 4, st));
+  return 0;
+}
+extern "C" int lcc_slot_set_length(lcc_engine* e, int slot, int kv_len, int next_pos, void* stream) {
+  if (!e || slot < 0 || slot >= e->lim.max_slots) return fail(LCC_ERR_ARG, "bad slot");
+  if (kv_len < 0 || kv_len > e->lim.max_kv_len) return fail(LCC_ERR_STATE, "kv_len %d out of range", kv_len);
+  hipStream_t st = (hipStream_t)stream;
+  MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
+  int32_t v[2] = {kv_len, next_pos}; int32_t* d = nullptr;
+  mw.put<int32_t>(v, 2, &d);
+  LCC_TRY(meta_commit(&mw, st));
+  HIP_TRY(hipMemcpyAsync(e->d_kv_len + slot, d, 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_pos + slot, d + 1, 4, hipMemcpyDeviceToDevice, st));
+  e->h_kv_len[slot] = kv_len; e->h_pos[slot] = next_pos;
+  return 0;
+}
+extern "C" int lcc_slot_get_length(const lcc_engine* e, int slot, int* kv_len, int* next_pos) {
+  if (!e || slot < 0 || slot >= e->lim.max_slots) return fail(LCC_ERR_ARG, "bad slot");
+  if (kv_len) *kv_len = e->h_kv_len[slot];
+  if (next_pos) *next_pos = e->h_pos[slot];
+  return 0;
+}
+extern "C" int lcc_slot_read_tokens(lcc_engine* e, int slot, int32_t* out, int max_n, int* n_generated, void* stream) {
+  if (!e || slot < 0 || slot >= e->lim.max_slots || !out || max_n < 0) return fail(LCC_ERR_ARG, "bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t v[3];
+  HIP_TRY(hipMemcpyAsync(&v[0], e->d_kv_len + slot, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&v[1], e->d_pos + slot, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&v[2], e->d_hist_col + slot, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  e->h_kv_len[slot] = v[0]; e->h_pos[slot] = v[1];   // device counters are authoritative (EOS freezes them)
+  const int n = std::min(std::min(v[2], max_n), e->lim.max_history);
+  if (n > 0) HIP_TRY(hipMemcpy(out, e->d_history + (size_t)slot * e->lim.max_history, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (n_generated) *n_generated = v[2];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT
+// ------------------------------------------------------------------------------------------------
+extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips, const float mean255[3], const float std255[3],
+                              const float* rope_cos, const float* rope_sin, void* out_embeds, void* stream) {
+  LCC_TRY(ensure_ready(e));
+  if (n_clips <= 0 || !clips || !rope_cos || !rope_sin || !out_embeds) return fail(LCC_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int E = e->E, heads = e->c.vit_heads, MLP = e->c.vit_mlp, H = e->c.hidden_size, PD = e->c.patch_dim;
+  // segment tables
+  std::vector<int32_t> seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0;
+  int P = 0, blocks = 0;
+  for (int ci = 0; ci < n_clips; ++ci) {
+    const lcc_clip& c = clips[ci];
+    if (c.T <= 0 || c.H % 28 || c.W % 28 || c.H <= 0 || c.W <= 0) return fail(LCC_ERR_SHAPE, "clip %d: T=%d H=%d W=%d (H,W must be multiples of 28)", ci, c.T, c.H, c.W);
+    if (!c.frames && !c.pixel_values) return fail(LCC_ERR_ARG, "clip %d has neither frames nor pixel_values", ci);
+    const int gt = (c.T + 1) / 2, n = (c.H / 14) * (c.W / 14);
+    for (int t = 0; t < gt; ++t) {
+      const int sg = (int)seg_start.size();
+      seg_start.push_back(P); seg_len.push_back(n); seg_blk.push_back(blocks);
+      for (int q = 0; q < n; q += 32) { tile_seg.push_back(sg); tile_q0.push_back(q); }
+      seg_of_patch.insert(seg_of_patch.end(), n, sg);
+      P += n; blocks += (n + 31) / 32;
+    }
+  }
+  if (P > e->lim.max_patches) return fail(LCC_ERR_STATE, "%d patches > max_patches %d", P, e->lim.max_patches);
+  const int n_tiles = (int)tile_seg.size(), n_seg = (int)seg_start.size();
+
+  Carver cv; cv.base = e->ws;
+  bf16_t* patches = cv.take<bf16_t>((size_t)P * PD);
+  bf16_t* x = cv.take<bf16_t>((size_t)P * E);
+  bf16_t* xn = cv.take<bf16_t>((size_t)P * E);
+  bf16_t* attn = cv.take<bf16_t>((size_t)P * E);
+  bf16_t* qkv = cv.take<bf16_t>((size_t)P * 3 * E);
+  bf16_t* mlp = cv.take<bf16_t>((size_t)P * MLP);
+  bf16_t* vt = cv.take<bf16_t>((size_t)heads * blocks * 80 * 32);
+  bf16_t* mg = cv.take<bf16_t>((size_t)(P / 4) * 4 * E);
+  if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small for %d patches", P);
+
+  MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
+  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0;
+  if (!mw.put(seg_start.data(), n_seg, &d_seg_start) || !mw.put(seg_len.data(), n_seg, &d_seg_len) ||
+      !mw.put(seg_blk.data(), n_seg, &d_seg_blk) || !mw.put(seg_of_patch.data(), P, &d_seg_of_patch) ||
+      !mw.put(tile_seg.data(), n_tiles, &d_tile_seg) || !mw.put(tile_q0.data(), n_tiles, &d_tile_q0))
+    return fail(LCC_ERR_STATE, "meta ring slot too small");
+  LCC_TRY(meta_commit(&mw, st));
+
+  // K1: patches
+  {
+    size_t row = 0;
+    for (int ci = 0; ci < n_clips; ++ci) {
+      const lcc_clip& c = clips[ci];
+      const size_t np = (size_t)((c.T + 1) / 2) * (c.H / 14) * (c.W / 14);
+      if (c.frames) LCC_TRY(patchify_norm_u8(c.frames, c.layout, c.T, c.H, c.W, mean255, std255, patches + row * PD, PD, st));
+      else LCC_TRY(cast_f32_bf16(c.pixel_values, patches + row * PD, (int64_t)np * PD, st));
+      row += np;
+    }
+  }
+  HIP_TRY(hipMemsetAsync(vt, 0, (size_t)heads * blocks * 80 * 32 * 2, st));
+  GemmArgs g;
+  // K2: patch embed (Conv3d k=s=(2,14,14) == GEMM, no bias)
+  g = GemmArgs(); g.A = patches; g.lda = PD; g.W = e->patch_embed; g.ldw = PD; g.C = x; g.ldc = E; g.M = P; g.N = E; g.K = PD;
+  LCC_TRY(gemm_bf16(g, st));
+  for (int l = 0; l < e->c.vit_depth; ++l) {
+    const VitLayerW& L = e->vit[l];
+    LCC_TRY(layernorm_bf16(x, L.ln1_w, L.ln1_b, xn, P, E, 1e-6f, st));
+    g = GemmArgs(); g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
+    LCC_TRY(gemm_bf16(g, st));
+    LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));
+    LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, st));
+    g = GemmArgs(); g.A = attn; g.lda = E; g.W = L.proj_w; g.ldw = E; g.bias = L.proj_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
+    g.M = P; g.N = E; g.K = E; g.epilogue = LCC_EPI_RESIDUAL;
+    LCC_TRY(gemm_bf16(g, st));
+    LCC_TRY(layernorm_bf16(x, L.ln2_w, L.ln2_b, xn, P, E, 1e-6f, st));
+    g = GemmArgs(); g.A = xn; g.lda = E; g.W = L.fc1_w; g.ldw = E; g.bias = L.fc1_b; g.C = mlp; g.ldc = MLP; g.M = P; g.N = MLP; g.K = E;
+    g.epilogue = LCC_EPI_QUICK_GELU;
+    LCC_TRY(gemm_bf16(g, st));
+    g = GemmArgs(); g.A = mlp; g.lda = MLP; g.W = L.fc2_w; g.ldw = MLP; g.bias = L.fc2_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
+    g.M = P; g.N = E; g.K = MLP; g.epilogue = LCC_EPI_RESIDUAL;
+    LCC_TRY(gemm_bf16(g, st));
+  }
+  // merger: LN -> view [P/4, 4E] -> Linear + GELU -> Linear
+  LCC_TRY(layernorm_bf16(x, e->mg_ln_w, e->mg_ln_b, xn, P, E, 1e-6f, st));
+  g = GemmArgs(); g.A = xn; g.lda = 4 * E; g.W = e->mg_fc1_w; g.ldw = 4 * E; g.bias = e->mg_fc1_b; g.C = mg; g.ldc = 4 * E;
+  g.M = P / 4; g.N = 4 * E; g.K = 4 * E; g.epilogue = LCC_EPI_GELU_ERF;
+  LCC_TRY(gemm_bf16(g, st));
+  g = GemmArgs(); g.A = mg; g.lda = 4 * E; g.W = e->mg_fc2_w; g.ldw = 4 * E; g.bias = e->mg_fc2_b; g.C = (bf16_t*)out_embeds; g.ldc = H;
+  g.M = P / 4; g.N = H; g.K = 4 * E;
+  LCC_TRY(gemm_bf16(g, st));
+  return check_launch("lcc_vit_encode");
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLM
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct LlmBuffers {
+  bf16_t *h, *xn, *qkv, *q, *attn, *act, *cos, *sin, *last_h, *last_xn, *logits;
+  float *partial, *ws_o, *ws_ml;
+};
+int carve_llm(lcc_engine* e, LlmBuffers* b) {
+  const size_t S = e->lim.max_new_rows, B = e->lim.max_slots, H = e->c.hidden_size, I = e->c.intermediate_size, V = e->c.vocab_size;
+  Carver cv; cv.base = e->ws;
+  b->h = cv.take<bf16_t>(S * H); b->xn = cv.take<bf16_t>(S * H); b->qkv = cv.take<bf16_t>(S * e->qkvd);
+  b->q = cv.take<bf16_t>(S * e->qd); b->attn = cv.take<bf16_t>(S * e->qd); b->act = cv.take<bf16_t>(S * I);
+  b->cos = cv.take<bf16_t>(S * 64); b->sin = cv.take<bf16_t>(S * 64);
+  b->partial = cv.take<float>((size_t)MAX_SPLIT * 16 * std::max<size_t>(e->qkvd, H));
+  b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H); b->logits = cv.take<bf16_t>(B * V);
+  b->ws_o = cv.take<float>(B * e->c.n_kv_heads * 64 * 16 * 128); b->ws_ml = cv.take<float>(B * e->c.n_kv_heads * 64 * 16 * 2);
+  if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small");
+  return 0;
+}
+
+// the 28 decoder layers over S packed rows; on exit b.h holds the residual stream after the last layer and,
+// on the skinny path (S <= 16), b.xn already holds final_norm(h).
+struct LayerCtx {
+  int S; bool skinny;
+  const int32_t *tok_stream, *tok_pos;          // prefill: explicit positions; decode: tok_pos == nullptr
+  const int32_t *tile_stream, *tile_q0, *tile_nq, *tile_pos0; int n_tiles;  // prefill attention tiles
+  const int32_t* slots; int B; int nsplit_attn;  // decode attention
+};
+int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream_t st) {
+  const int H = e->c.hidden_size, I = e->c.intermediate_size, S = cx.S;
+  const float eps = e->c.rms_eps;
+  const int sp_qkv = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(e->qkvd, H)) : 0;
+  const int sp_o = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(H, e->qd)) : 0;
+  const int sp_dn = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(H, I)) : 0;
+  LCC_TRY(rmsnorm_bf16(b.h, e->llm[0].in_norm, b.xn, S, H, eps, st));
+  for (int l = 0; l < e->c.n_layers; ++l) {
+    const LlmLayerW& L = e->llm[l];
+    const bf16_t* next_norm = (l + 1 < e->c.n_layers) ? e->llm[l + 1].in_norm : e->final_norm;
+    GemmArgs g;
+    // q/k/v projection (+bias) -> M-RoPE -> in-place KV append
+    g = GemmArgs(); g.A = b.xn; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
+    if (cx.skinny) {
+      g.partial = b.partial; g.nsplit = sp_qkv;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(rope_kv_append_bf16(nullptr, b.partial, sp_qkv, L.qkv_b, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
+                                  e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
+    } else {
+      g.bias = L.qkv_b; g.C = b.qkv; g.ldc = e->qkvd;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(rope_kv_append_bf16(b.qkv, nullptr, 0, nullptr, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
+                                  e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
+    }
+    // attention
+    if (cx.tok_pos == nullptr)
+      LCC_TRY(attn_decode_bf16(b.q, b.attn, cx.slots, e->d_kv_len, e->d_kv_base, e->lay, l, cx.B, e->c.n_q_heads, cx.nsplit_attn,
+                               b.ws_o, b.ws_ml, st));
+    else
+      LCC_TRY(attn_prefill_bf16(b.q, b.attn, cx.tile_stream, cx.tile_q0, cx.tile_nq, cx.tile_pos0, e->d_kv_base, e->lay, l,
+                                cx.n_tiles, e->c.n_q_heads, st));
+    // o_proj + residual + post-attention RMSNorm
+    g = GemmArgs(); g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
+    if (cx.skinny) {
+      g.partial = b.partial; g.nsplit = sp_o;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, sp_o, L.post_norm, b.xn, S, H, eps, st));
+    } else {
+      g.residual = b.h; g.ldr = H; g.C = b.h; g.ldc = H; g.epilogue = LCC_EPI_RESIDUAL;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(rmsnorm_bf16(b.h, L.post_norm, b.xn, S, H, eps, st));
+    }
+    // SwiGLU MLP
+    g = GemmArgs(); g.A = b.xn; g.lda = H; g.W = L.gate_up_w; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
+    g.epilogue = LCC_EPI_SWIGLU;
+    LCC_TRY(gemm_bf16(g, st));
+    g = GemmArgs(); g.A = b.act; g.lda = I; g.W = L.down_w; g.ldw = I; g.M = S; g.N = H; g.K = I;
+    if (cx.skinny) {
+      g.partial = b.partial; g.nsplit = sp_dn;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, sp_dn, next_norm, b.xn, S, H, eps, st));
+    } else {
+      g.residual = b.h; g.ldr = H; g.C = b.h; g.ldc = H; g.epilogue = LCC_EPI_RESIDUAL;
+      LCC_TRY(gemm_bf16(g, st));
+      if (l + 1 < e->c.n_layers) LCC_TRY(rmsnorm_bf16(b.h, next_norm, b.xn, S, H, eps, st));
+    }
+  }
+  return 0;
+}
+
+int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, int B, const int32_t* d_slots, const lcc_sampling* sp,
+                    int step_index, hipStream_t st) {
+  const int H = e->c.hidden_size, V = e->c.vocab_size;
+  bf16_t* logits = b.logits;
+  if (sp && sp->logits_out) logits = (bf16_t*)sp->logits_out + (size_t)step_index * B * V;
+  GemmArgs g; g.A = xn_rows; g.lda = H; g.W = e->lm_head; g.ldw = H; g.C = logits; g.ldc = V; g.M = B; g.N = V; g.K = H;
+  LCC_TRY(gemm_bf16(g, st));
+  const float pen = sp ? sp->repetition_penalty : 1.0f;
+  const int thr_tok = sp ? sp->thr_token : -1;
+  const int use_thr = sp ? sp->use_thr : 0;
+  const float thr = sp ? sp->thr_base + sp->thr_step * (float)step_index : 0.f;
+  LCC_TRY(sample_greedy(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr,
+                        sp ? sp->eos_token : -1, sp ? sp->suppress_eos : 0, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
+                        e->d_hist_col, sp ? sp->scores_out : nullptr, st));
+  return 0;
+}
+}  // namespace
+
+extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slots, const int32_t* n_new, const int32_t* ids,
+                               const int32_t* vit_index, const void* vit_embeds, const int32_t* pos3, const lcc_sampling* sp,
+                               void* stream) {
+  LCC_TRY(ensure_ready(e));
+  if (n_streams <= 0 || !slots || !n_new || !ids || !pos3) return fail(LCC_ERR_ARG, "null argument");
+  if (n_streams > e->lim.max_slots) return fail(LCC_ERR_STATE, "too many streams");
+  hipStream_t st = (hipStream_t)stream;
+  int S = 0;
+  for (int b = 0; b < n_streams; ++b) {
+    if (slots[b] < 0 || slots[b] >= e->lim.max_slots || !e->h_kv_base[slots[b]]) return fail(LCC_ERR_STATE, "slot %d not bound", slots[b]);
+    if (n_new[b] <= 0) return fail(LCC_ERR_ARG, "stream %d has no new tokens", b);
+    if (e->h_kv_len[slots[b]] + n_new[b] + e->lim.max_history > e->lim.max_kv_len)
+      return fail(LCC_ERR_STATE, "slot %d: KV capacity %d exceeded (%d cached + %d new + %d generation headroom)", slots[b], e->lim.max_kv_len,
+                  e->h_kv_len[slots[b]], n_new[b], e->lim.max_history);
+    S += n_new[b];
+  }
+  if (S > e->lim.max_new_rows) return fail(LCC_ERR_STATE, "%d new rows > max_new_rows %d", S, e->lim.max_new_rows);
+  for (int i = 0; i < S; ++i) {
+    if (ids[i] < 0 || ids[i] >= e->c.vocab_size) return fail(LCC_ERR_ARG, "token id %d out of range at %d", ids[i], i);
+    if (vit_index && vit_index[i] >= 0 && !vit_embeds) return fail(LCC_ERR_ARG, "vit_index set but vit_embeds is null");
+  }
+  LlmBuffers bf; LCC_TRY(carve_llm(e, &bf));
+
+  // host tables
+  std::vector<int32_t> tok_stream(S), tok_pos(S), last_row(n_streams), tile_stream, tile_q0, tile_nq, tile_pos0;
+  int row = 0;
+  for (int b = 0; b < n_streams; ++b) {
+    const int past = e->h_kv_len[slots[b]];
+    for (int i = 0; i < n_new[b]; ++i) { tok_stream[row + i] = slots[b]; tok_pos[row + i] = past + i; }
+    for (int q = 0; q < n_new[b]; q += 32) {
+      tile_stream.push_back(slots[b]); tile_q0.push_back(row + q); tile_nq.push_back(std::min(32, n_new[b] - q)); tile_pos0.push_back(past + q);
+    }
+    row += n_new[b];
+    last_row[b] = row - 1;
+  }
+  const int n_tiles = (int)tile_stream.size();
+  MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
+  int32_t *d_ids, *d_vit = nullptr, *d_pos3, *d_tok_stream, *d_tok_pos, *d_last_row, *d_slots, *d_ts, *d_tq, *d_tn, *d_tp;
+  bool ok = mw.put(ids, S, &d_ids) && mw.put(pos3, (size_t)3 * S, &d_pos3) && mw.put(tok_stream.data(), S, &d_tok_stream) &&
+            mw.put(tok_pos.data(), S, &d_tok_pos) && mw.put(last_row.data(), n_streams, &d_last_row) && mw.put(slots, n_streams, &d_slots) &&
+            mw.put(tile_stream.data(), n_tiles, &d_ts) && mw.put(tile_q0.data(), n_tiles, &d_tq) && mw.put(tile_nq.data(), n_tiles, &d_tn) &&
+            mw.put(tile_pos0.data(), n_tiles, &d_tp);
+  if (ok && vit_index) ok = mw.put(vit_index, S, &d_vit) != nullptr;
+  if (!ok) return fail(LCC_ERR_STATE, "meta ring slot too small");
+  LCC_TRY(meta_commit(&mw, st));
+
+  // history column restarts at 0 for this generate call; repetition penalty sees every id of the history
+  for (int b = 0; b < n_streams; ++b) {
+    HIP_TRY(hipMemsetAsync(e->d_hist_col + slots[b], 0, 4, st));
+    HIP_TRY(hipMemsetAsync(e->d_done + slots[b], 0, 4, st));
+  }
+  LCC_TRY(seen_set(e->d_seen, e->words, d_ids, d_tok_stream, S, 0, nullptr, st));
+  LCC_TRY(embed_gather_bf16(d_ids, nullptr, d_vit, e->embed, (const bf16_t*)vit_embeds, bf.h, S, e->c.hidden_size, st));
+  LCC_TRY(mrope_table(d_pos3, e->inv_freq, S, e->c.mrope_sec_t, e->c.mrope_sec_h, bf.cos, bf.sin, st));
+
+  LayerCtx cx{};
+  cx.S = S; cx.skinny = S <= 16; cx.tok_stream = d_tok_stream; cx.tok_pos = d_tok_pos;
+  cx.tile_stream = d_ts; cx.tile_q0 = d_tq; cx.tile_nq = d_tn; cx.tile_pos0 = d_tp; cx.n_tiles = n_tiles;
+  cx.slots = d_slots; cx.B = n_streams; cx.nsplit_attn = 1;
+  LCC_TRY(run_layers(e, bf, cx, st));
+
+  const bf16_t* xn_rows;
+  if (cx.skinny) {
+    LCC_TRY(gather_rows_bf16(bf.xn, d_last_row, bf.last_xn, n_streams, e->c.hidden_size, st));
+    xn_rows = bf.last_xn;
+  } else {
+    LCC_TRY(gather_rows_bf16(bf.h, d_last_row, bf.last_h, n_streams, e->c.hidden_size, st));
+    LCC_TRY(rmsnorm_bf16(bf.last_h, e->final_norm, bf.last_xn, n_streams, e->c.hidden_size, e->c.rms_eps, st));
+    xn_rows = bf.last_xn;
+  }
+  // lengths: the new rows are now in the cache; the position of the next token continues the last row's (all 3 axes equal
+  // for the last text token): next_pos = max over axes of the last position + 1  (== kv_len + rope_delta)
+  row = 0;
+  for (int b = 0; b < n_streams; ++b) {
+    const int s = slots[b];
+    int last = row + n_new[b] - 1;
+    int mx = std::max(pos3[last], std::max(pos3[S + last], pos3[2 * S + last]));
+    e->h_kv_len[s] += n_new[b];
+    e->h_pos[s] = mx + 1;
+    row += n_new[b];
+  }
+  {
+    MetaWriter mw2; LCC_TRY(meta_begin(e, &mw2));
+    std::vector<int32_t> kv(n_streams), ps(n_streams); int32_t *d_kv, *d_ps;
+    for (int b = 0; b < n_streams; ++b) { kv[b] = e->h_kv_len[slots[b]]; ps[b] = e->h_pos[slots[b]]; }
+    mw2.put(kv.data(), n_streams, &d_kv); mw2.put(ps.data(), n_streams, &d_ps);
+    LCC_TRY(meta_commit(&mw2, st));
+    for (int b = 0; b < n_streams; ++b) {
+      HIP_TRY(hipMemcpyAsync(e->d_kv_len + slots[b], d_kv + b, 4, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(e->d_pos + slots[b], d_ps + b, 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  LCC_TRY(head_and_sample(e, bf, xn_rows, n_streams, d_slots, sp, 0, st));
+  return check_launch("lcc_llm_prefill");
+}
+
+extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots, int n_steps, int first_step_index,
+                              const lcc_sampling* sp, void* stream) {
+  LCC_TRY(ensure_ready(e));
+  if (n_streams <= 0 || !slots || n_steps < 0) return fail(LCC_ERR_ARG, "bad argument");
+  if (n_streams > 16) return fail(LCC_ERR_SHAPE, "decode batches of more than 16 streams are not supported yet");
+  if (n_steps == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int max_len = 0;
+  for (int b = 0; b < n_streams; ++b) {
+    const int s = slots[b];
+    if (s < 0 || s >= e->lim.max_slots || !e->h_kv_base[s]) return fail(LCC_ERR_STATE, "slot %d not bound", s);
+    if (e->h_kv_len[s] + n_steps > e->lim.max_kv_len) return fail(LCC_ERR_STATE, "slot %d: KV capacity exceeded", s);
+    max_len = std::max(max_len, e->h_kv_len[s] + n_steps);
+  }
+  if (first_step_index + n_steps > e->lim.max_history) return fail(LCC_ERR_STATE, "history capacity %d exceeded", e->lim.max_history);
+  LlmBuffers bf; LCC_TRY(carve_llm(e, &bf));
+  MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
+  int32_t* d_slots;
+  if (!mw.put(slots, n_streams, &d_slots)) return fail(LCC_ERR_STATE, "meta ring slot too small");
+  LCC_TRY(meta_commit(&mw, st));
+  const int ntile = (max_len + 31) / 32;
+  const int nsplit = std::max(1, std::min(64, (ntile + 3) / 4));
+
+  LayerCtx cx{};
+  cx.S = n_streams; cx.skinny = true; cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
+  cx.nsplit_attn = nsplit;
+  for (int step = 0; step < n_steps; ++step) {
+    // the token sampled by the previous step (d_cur_tok[slot]) is embedded, appended at kv_len[slot], position pos[slot]
+    LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
+    LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
+    LCC_TRY(mrope_table_decode(d_slots, e->d_pos, e->inv_freq, n_streams, bf.cos, bf.sin, st));
+    LCC_TRY(run_layers(e, bf, cx, st));
+    LCC_TRY(advance_lengths(d_slots, e->d_kv_len, e->d_pos, n_streams, e->d_done, st));
+    LCC_TRY(head_and_sample(e, bf, bf.xn, n_streams, d_slots, sp, first_step_index + step, st));
+  }
+  for (int b = 0; b < n_streams; ++b) { e->h_kv_len[slots[b]] += n_steps; e->h_pos[slots[b]] += n_steps; }
+  return check_launch("lcc_llm_decode");
+}
+
+// ------------------------------------------------------------------------------------------------
+// operator-level C-ABI wrappers
+// ------------------------------------------------------------------------------------------------
+static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_heads, l.lmax, l.head_dim}; }
+#define OP_RET(call, name)                                   \
+  do {                                                       \
+    int r__ = (call);                                        \
+    if (r__ != 0) return fail(r__, "%s: invalid arguments (%d)", name, r__); \
+    return check_launch(name);                               \
+  } while (0)
+
+extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                             void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {
+  if (!A || !W || (!C && !partial)) return fail(LCC_ERR_ARG, "lcc_gemm_bf16: null pointer");
+  GemmArgs g; g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = (const bf16_t*)bias;
+  g.residual = (const bf16_t*)residual; g.ldr = ldr; g.C = (bf16_t*)C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epilogue = epilogue;
+  g.partial = partial; g.nsplit = nsplit;
+  if (partial && C == nullptr) g.C = (bf16_t*)partial;  // alignment check only
+  OP_RET(gemm_bf16(g, (hipStream_t)stream), "lcc_gemm_bf16");
+}
+extern "C" int lcc_gemv_num_splits(int N, int K) { return gemv_num_splits(N, K); }
+extern "C" int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream) {
+  if (!A || !B || !D) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(mfma_probe((const bf16_t*)A, (const bf16_t*)B, D, (hipStream_t)stream), "lcc_debug_mfma_probe");
+}
+extern "C" int lcc_patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W, const float mean255[3],
+                                    const float std255[3], void* out, int ld, void* stream) {
+  if (!frames || !out || !mean255 || !std255) return fail(LCC_ERR_ARG, "lcc_patchify_norm_u8: null pointer");
+  OP_RET(patchify_norm_u8(frames, layout, T, H, W, mean255, std255, (bf16_t*)out, ld, (hipStream_t)stream), "lcc_patchify_norm_u8");
+}
+extern "C" int lcc_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (!in || !out) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(cast_f32_bf16(in, (bf16_t*)out, n, (hipStream_t)stream), "lcc_cast_f32_bf16");
+}
+extern "C" int lcc_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, void* stream) {
+  if (!x || !w || !b || !y) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(layernorm_bf16((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, dim, eps, (hipStream_t)stream), "lcc_layernorm_bf16");
+}
+extern "C" int lcc_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int dim, float eps, void* stream) {
+  if (!x || !w || !y) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(rmsnorm_bf16((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rows, dim, eps, (hipStream_t)stream), "lcc_rmsnorm_bf16");
+}
+extern "C" int lcc_add_rmsnorm_bf16(void* h, const void* delta_bf16, const float* delta_partial, int nsplit, const void* w, void* y,
+                                    int rows, int dim, float eps, void* stream) {
+  if (!h || (w && !y)) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(add_rmsnorm_bf16((bf16_t*)h, (const bf16_t*)delta_bf16, delta_partial, nsplit, (const bf16_t*)w, (bf16_t*)y, rows, dim, eps,
+                          (hipStream_t)stream), "lcc_add_rmsnorm_bf16");
+}
+extern "C" int lcc_swiglu_bf16(const void* gate, const void* up, void* out, int64_t n, void* stream) {
+  if (!gate || !up || !out) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(swiglu_bf16((const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)out, n, (hipStream_t)stream), "lcc_swiglu_bf16");
+}
+extern "C" int lcc_vit_rope_vt_bf16(void* qkv, const float* cos, const float* sin, const int32_t* seg_of_patch, const int32_t* seg_start,
+                                    const int32_t* seg_blk_start, void* vt, int P, int heads, int total_blocks, void* stream) {
+  if (!qkv || !cos || !sin || !seg_of_patch || !seg_start || !seg_blk_start || !vt) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(vit_rope_vt_bf16((bf16_t*)qkv, cos, sin, seg_of_patch, seg_start, seg_blk_start, (bf16_t*)vt, P, heads, total_blocks,
+                          (hipStream_t)stream), "lcc_vit_rope_vt_bf16");
+}
+extern "C" int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, const int32_t* tile_seg, const int32_t* tile_q0,
+                                 const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles, int heads,
+                                 int total_blocks, void* stream) {
+  if (!qkv || !vt || !out || !tile_seg || !tile_q0 || !seg_start || !seg_len || !seg_blk_start) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(attn_vit_bf16((const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, tile_seg, tile_q0, seg_start, seg_len, seg_blk_start, n_tiles,
+                       heads, total_blocks, (hipStream_t)stream), "lcc_attn_vit_bf16");
+}
+extern "C" int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream) {
+  if (!pos3 || !inv_freq || !cos || !sin) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(mrope_table(pos3, inv_freq, S, sec_t, sec_h, (bf16_t*)cos, (bf16_t*)sin, (hipStream_t)stream), "lcc_mrope_table");
+}
+extern "C" int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_partial, int nsplit, const void* bias, const void* cos,
+                                       const void* sin, const int32_t* tok_stream, const int32_t* tok_pos, const int32_t* kv_len,
+                                       void* const* kv_base, lcc_kv_layout lay, int layer, void* q_out, int S, int n_q_heads, void* stream) {
+  if ((!qkv_bf16 && !qkv_partial) || !cos || !sin || !tok_stream || !kv_base || !q_out) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(rope_kv_append_bf16((const bf16_t*)qkv_bf16, qkv_partial, nsplit, (const bf16_t*)bias, (const bf16_t*)cos, (const bf16_t*)sin,
+                             tok_stream, tok_pos, kv_len, (bf16_t* const*)kv_base, to_lay(lay), layer, (bf16_t*)q_out, S, n_q_heads,
+                             (hipStream_t)stream), "lcc_rope_kv_append_bf16");
+}
+extern "C" int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
+                                     const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay, int layer, int n_tiles,
+                                     int n_q_heads, void* stream) {
+  if (!q || !out || !tile_stream || !tile_q0 || !tile_nq || !tile_pos0 || !kv_base) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(attn_prefill_bf16((const bf16_t*)q, (bf16_t*)out, tile_stream, tile_q0, tile_nq, tile_pos0, (bf16_t* const*)kv_base, to_lay(lay),
+                           layer, n_tiles, n_q_heads, (hipStream_t)stream), "lcc_attn_prefill_bf16");
+}
+extern "C" int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
+                                    lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream) {
+  if (!q || !out || !slots || !kv_len || !kv_base || !ws_o || !ws_ml || nsplit < 1) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(attn_decode_bf16((const bf16_t*)q, (bf16_t*)out, slots, kv_len, (bf16_t* const*)kv_base, to_lay(lay), layer, B, n_q_heads, nsplit,
+                          ws_o, ws_ml, (hipStream_t)stream), "lcc_attn_decode_bf16");
+}
+extern "C" int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
+                                     const void* vit_rows, void* out, int S, int dim, void* stream) {
+  if (!ids || !table || !out) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(embed_gather_bf16(ids, indirect, vit_index, (const bf16_t*)table, (const bf16_t*)vit_rows, (bf16_t*)out, S, dim, (hipStream_t)stream),
+         "lcc_embed_gather_bf16");
+}
+extern "C" int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, void* stream) {
+  if (!seen || !ids || !slot_of_id) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(seen_set(seen, words_per_stream, ids, slot_of_id, n, 0, nullptr, (hipStream_t)stream), "lcc_seen_set");
+}
+extern "C" int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream, const int32_t* stream_slot,
+                                 float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token,
+                                 int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
+                                 int32_t* hist_col, float* scores_out, void* stream) {
+  if (!logits || !seen || !stream_slot || !out_tokens || (history && !hist_col)) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(sample_greedy((const bf16_t*)logits, ld, B, V, seen, words_per_stream, stream_slot, repetition_penalty, thr_token, use_thr,
+                       thr_value, eos_token, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out, (hipStream_t)stream),
+         "lcc_sample_greedy");
+}

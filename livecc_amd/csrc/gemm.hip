@@ -1,0 +1,349 @@
+// bf16 GEMMs of the LiveCC hot path on gfx950 (MI355X):  C[M,N] = A[M,K] * W[N,K]^T  (+bias, +epilogue)
+//
+// W keeps the nn.Linear layout [N,K] (K contiguous) so that both MFMA operands are read as 8 contiguous
+// bf16 (16 bytes) per lane.  fp32 accumulation, one rounding to bf16 at the points where HF rounds.
+//
+//  * gemm_tiled_kernel   : M >= 17 (ViT, merger, LLM prefill).  MFMA-bound.  BMx128x64 block tile,
+//                          4 waves (2x2), register-staged double-buffered LDS with an XOR swizzle,
+//                          v_mfma_f32_16x16x32_bf16, XCD-aware block remap so that the blocks that share a
+//                          W panel run on one XCD (one L2).
+//  * gemv_skinny_kernel  : M <= 16 (decode, lm_head).  HBM-bound weight streaming.  One wave per block,
+//                          16 (or 32) W rows x a K slice per wave, W fragments loaded straight from HBM into
+//                          the MFMA operand registers (no LDS round trip - the operand is used once), split-K
+//                          partial sums as fp32 slabs that the consumer kernel reduces.
+//
+// Replaces: every nn.Linear / Conv3d of HF modeling_qwen2_vl.py on the path
+//   (PatchEmbed 251-274, VisionAttention.qkv/proj 349-350, VisionMlp 293-301, PatchMerger 277-290,
+//    Qwen2VLAttention q/k/v/o_proj 501-504, Qwen2MLP 453-466, lm_head 1218/1323).
+#include "common.h"
+#include "kernels.h"
+
+namespace lcc {
+
+// ------------------------------------------------------------------------------------------------
+// tiled GEMM
+// ------------------------------------------------------------------------------------------------
+template <int BM, int EPI>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+  constexpr int BN = 128, BK = 64;
+  constexpr int WM = BM / 2;       // wave tile rows (of A)
+  constexpr int MT = WM / 16;      // 16-row MFMA tiles per wave in M
+  constexpr int NT = 4;            // 16-col MFMA tiles per wave in N (wave tile is WM x 64)
+  constexpr int AI = BM * 8 / 256; // 16-byte chunks of the A tile per thread
+  constexpr int BI = BN * 8 / 256;
+  constexpr int STAGE = (BM + BN) * 8;  // 16-byte units per stage
+  __shared__ u32x4 smem[2 * STAGE];
+
+  // XCD-aware remap: hardware places block b on XCD b%8; give every XCD a contiguous range of tile ids
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;  // consecutive ids share the W panel
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, g = lane >> 4;
+
+  // global -> register staging addresses
+  const bf16_t* aptr[AI];
+  const bf16_t* bptr[BI];
+  int aoff[AI], boff[BI];  // LDS offsets (16B units) within a stage
+  const int chunk = tid & 7;
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int row = (tid >> 3) + i * 32;
+    int gr = min(m0 + row, M - 1);
+    aptr[i] = A + (size_t)gr * lda + chunk * 8;
+    aoff[i] = row * 8 + (chunk ^ ((row >> 1) & 7));
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int row = (tid >> 3) + i * 32;
+    int gr = min(n0 + row, N - 1);
+    bptr[i] = W + (size_t)gr * ldw + chunk * 8;
+    boff[i] = BM * 8 + row * 8 + (chunk ^ ((row >> 1) & 7));
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[AI], rb[BI];
+  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
+  auto gload = [&](int kt) {
+    const int k = kt * BK + chunk * 8;
+    const bool ok = k < K;  // K % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ra[i] = ok ? ld16(aptr[i] + kt * BK) : zero4;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ok ? ld16(bptr[i] + kt * BK) : zero4;
+  };
+  auto sstore = [&](int buf) {
+    u32x4* s = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) s[aoff[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) s[boff[i]] = rb[i];
+  };
+
+  const int nkt = (K + BK - 1) / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = kt + 1 < nkt;
+    if (more) gload(kt + 1);
+    const u32x4* s = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        int row = wm * WM + i * 16 + li;
+        fa[i] = as_bf16x8(s[row * 8 + ((kk * 4 + g) ^ ((row >> 1) & 7))]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        int row = wn * 64 + j * 16 + li;
+        fb[j] = as_bf16x8(s[BM * 8 + row * 8 + ((kk * 4 + g) ^ ((row >> 1) & 7))]);
+      }
+      // swapped operands: D'[n][m] so that a lane owns 4 consecutive n of one row m (8-byte stores)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+    if (more) sstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane owns C[m][n..n+3], m = .. + li, n = .. + g*4
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * WM + i * 16 + li;
+    if (m >= M) continue;
+    if (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int n = n0 + wn * 64 + j * 16 + g * 4;  // column in the interleaved [gate16|up16] space
+        if (n >= N) continue;
+        const int oc = (n0 + wn * 64) / 2 + (j / 2) * 16 + g * 4;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gate = rbf(acc[i][j][r]), up = rbf(acc[i][j + 1][r]);
+          o[r] = silu_bf16(gate) * up;
+        }
+        st8(C + (size_t)m * ldc + oc, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + g * 4;
+        if (n >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (bias != nullptr) {
+          u32x2 b = ld8(bias + n);
+          v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        if (EPI == EPI_QUICK_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = quick_gelu_bf16(v[r]);
+        } else if (EPI == EPI_GELU_ERF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf_bf16(v[r]);
+        } else if (EPI == EPI_RESIDUAL) {
+          u32x2 q = ld8(residual + (size_t)m * ldr + n);
+          v[0] += lo2f(q.x); v[1] += hi2f(q.x); v[2] += lo2f(q.y); v[3] += hi2f(q.y);
+        }
+        st8(C + (size_t)m * ldc + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+      }
+    }
+  }
+}
+
+template <int BM, int EPI>
+static void launch_tiled(const GemmArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 127) / 128;
+  gemm_tiled_kernel<BM, EPI><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(
+      a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n);
+}
+
+template <int EPI>
+static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
+  // small problems: 64-row tiles waste less of a ragged M and give >= ~2 blocks per CU sooner
+  const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  if (blocks128 >= 512) launch_tiled<128, EPI>(a, st);
+  else launch_tiled<64, EPI>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny GEMV-like kernel (M <= 16)
+// ------------------------------------------------------------------------------------------------
+// One wave per block.  The wave owns NTILE*16 consecutive W rows and the K range [k_begin, k_end) of
+// split `blockIdx.y`.  Per 64-element step it issues, per tile, two 16-byte loads per lane that together
+// cover one full 128-byte line of each of the 16 rows, plus the matching x fragment (L2/L1 resident).
+// D'[n][m]: lane (m = l&15, g) ends with 4 consecutive n for activation row m.
+template <int NTILE, int MODE>  // MODE 0: fp32 partial slab out[split][M][N]; 1: bf16 out with bias/act; 2: swiglu bf16
+__global__ __launch_bounds__(64) void gemv_skinny_kernel(
+    const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
+    const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int ksplit_len) {
+  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * (NTILE * 16);
+  const int split = blockIdx.y;
+  const int kb = split * ksplit_len, ke = min(K, kb + ksplit_len);
+
+  const int xm = min(li, M - 1);
+  const bf16_t* xp = X + (size_t)xm * ldx + g * 8;
+  const bf16_t* wp[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) wp[t] = W + (size_t)min(n0 + t * 16 + li, N - 1) * ldw + g * 8;
+
+  f32x4 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int k = kb;
+  constexpr int UNR = (NTILE == 1) ? 4 : 2;  // 64-element steps in flight
+  for (; k + 64 * UNR <= ke; k += 64 * UNR) {
+    u32x4 wv[UNR][2][NTILE], xv[UNR][2];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + k + u * 64 + h * 32));
+        xv[u][h] = ld16(xp + k + u * 64 + h * 32);
+      }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h]), acc[t]);
+  }
+  for (; k < ke; k += 32) {  // K % 32 == 0
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      u32x4 wv = __builtin_nontemporal_load((const u32x4*)(wp[t] + k));
+      acc[t] = mfma16(as_bf16x8(wv), as_bf16x8(ld16(xp + k)), acc[t]);
+    }
+  }
+
+  if (li >= M) return;
+  if (MODE == 0) {
+    float* o = (float*)out + ((size_t)split * M + li) * ldo;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const int n = n0 + t * 16 + g * 4;
+      if (n < N) *reinterpret_cast<f32x4*>(o + n) = acc[t];
+    }
+  } else if (MODE == 1) {
+    bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const int n = n0 + t * 16 + g * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+      if (bias != nullptr) {
+        u32x2 b = ld8(bias + n);
+        v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+      }
+      st8(o + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+    }
+  } else {  // swiglu: tile 0 = 16 gate rows, tile 1 = the 16 matching up rows
+    static_assert(MODE != 2 || NTILE == 2, "swiglu needs the gate and up tile in one wave");
+    bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
+    const int oc = n0 / 2 + g * 4;
+    if (n0 < N) {
+      float r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = silu_bf16(rbf(acc[0][q])) * rbf(acc[NTILE - 1][q]);
+      st8(o + oc, (u32x2){pack2(r[0], r[1]), pack2(r[2], r[3])});
+    }
+  }
+}
+
+// layout probe (tests/test_gpu_ops.py::test_mfma_layout_probe): D[16x16] = A[16x32] * B[32x16] with the fragment maps of
+// common.h, one wave.  Verifies the operand/result lane maps every kernel in this library relies on.
+__global__ __launch_bounds__(64) void mfma_probe_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                        float* __restrict__ D) {
+  const int l = threadIdx.x, i = l & 15, g = l >> 4;
+  bf16_t av[8], bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    av[e] = A[i * 32 + g * 8 + e];        // A[i][k = g*8+e]
+    bv[e] = B[(g * 8 + e) * 16 + i];      // B[k = g*8+e][j = i]
+  }
+  u32x4 a = (u32x4){(unsigned)av[0] | ((unsigned)av[1] << 16), (unsigned)av[2] | ((unsigned)av[3] << 16),
+                    (unsigned)av[4] | ((unsigned)av[5] << 16), (unsigned)av[6] | ((unsigned)av[7] << 16)};
+  u32x4 b = (u32x4){(unsigned)bv[0] | ((unsigned)bv[1] << 16), (unsigned)bv[2] | ((unsigned)bv[3] << 16),
+                    (unsigned)bv[4] | ((unsigned)bv[5] << 16), (unsigned)bv[6] | ((unsigned)bv[7] << 16)};
+  f32x4 c = mfma16(as_bf16x8(a), as_bf16x8(b), (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[(g * 4 + r) * 16 + i] = c[r];  // D[row = g*4+r][col = i]
+}
+int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st) {
+  mfma_probe_kernel<<<dim3(1), dim3(64), 0, st>>>(A, B, D);
+  return 0;
+}
+
+// choose the number of K splits of a skinny GEMV so that ~>= 1536 waves are in flight, each wave keeps
+// >= 256 elements of K, and the fp32 slab traffic stays small (S <= 8)
+int gemv_num_splits(int N, int K) {
+  const int tiles = (N + 15) / 16;
+  int s = 1;
+  while (s < 8 && tiles * s < 1536 && K / (s * 2) >= 256 && (K % (s * 2 * 32) == 0)) s *= 2;
+  return s;
+}
+
+int gemm_bf16(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
+  if ((a.K & 7) || (a.N & 15) || (a.lda & 7) || (a.ldw & 7) || (a.ldc & 3)) return LCC_ERR_SHAPE;
+  if ((((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) != 0) return LCC_ERR_ALIGN;
+  if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
+  if (a.epilogue == EPI_RESIDUAL && a.residual == nullptr) return LCC_ERR_ARG;
+  const bool skinny = a.M <= 16 && (a.K % 32 == 0) && a.epilogue != EPI_QUICK_GELU &&
+                      a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
+  if (skinny) {
+    if (a.epilogue == EPI_SWIGLU) {
+      gemv_skinny_kernel<2, 2><<<dim3((a.N + 31) / 32, 1), dim3(64), 0, st>>>(
+          a.A, a.lda, a.W, a.ldw, nullptr, a.C, a.ldc, a.M, a.N, a.K, a.K);
+    } else if (a.partial != nullptr) {
+      const int S = a.nsplit > 0 ? a.nsplit : 1;
+      if (a.K % (S * 32) != 0) return LCC_ERR_SHAPE;
+      gemv_skinny_kernel<1, 0><<<dim3((a.N + 15) / 16, S), dim3(64), 0, st>>>(
+          a.A, a.lda, a.W, a.ldw, nullptr, a.partial, a.N, a.M, a.N, a.K, a.K / S);
+    } else {
+      gemv_skinny_kernel<1, 1><<<dim3((a.N + 15) / 16, 1), dim3(64), 0, st>>>(
+          a.A, a.lda, a.W, a.ldw, a.bias, a.C, a.ldc, a.M, a.N, a.K, a.K);
+    }
+    return 0;
+  }
+  if (a.partial != nullptr) return LCC_ERR_ARG;  // partial slabs only exist on the skinny path
+  switch (a.epilogue) {
+    case EPI_NONE: launch_tiled_bm<EPI_NONE>(a, st); break;
+    case EPI_QUICK_GELU: launch_tiled_bm<EPI_QUICK_GELU>(a, st); break;
+    case EPI_GELU_ERF: launch_tiled_bm<EPI_GELU_ERF>(a, st); break;
+    case EPI_RESIDUAL: launch_tiled_bm<EPI_RESIDUAL>(a, st); break;
+    case EPI_SWIGLU: launch_tiled_bm<EPI_SWIGLU>(a, st); break;
+    default: return LCC_ERR_ARG;
+  }
+  return 0;
+}
+
+}  // namespace lcc

@@ -1,0 +1,80 @@
+// Internal C++ launch API of the HIP kernels (the C-ABI in capi.hip and the engine call these).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/livecc_amd.h"  // lcc_status codes
+
+namespace lcc {
+
+typedef unsigned short bf16_t;
+
+
+// ---- GEMM (gemm.hip) ----
+struct GemmArgs {
+  const bf16_t* A = nullptr; int lda = 0;       // [M,K]
+  const bf16_t* W = nullptr; int ldw = 0;       // [N,K]
+  const bf16_t* bias = nullptr;                 // [N] or null
+  const bf16_t* residual = nullptr; int ldr = 0;
+  bf16_t* C = nullptr; int ldc = 0;             // [M,N] (swiglu: [M,N/2])
+  float* partial = nullptr; int nsplit = 0;     // skinny path only: fp32 slabs [nsplit][M][N]
+  int M = 0, N = 0, K = 0;
+  int epilogue = 0;
+};
+int gemm_bf16(const GemmArgs& a, hipStream_t st);
+int gemv_num_splits(int N, int K);
+int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
+
+// ---- elementwise / normalisation / layout (elementwise.hip) ----
+int patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W, const float* mean255,
+                     const float* std255, bf16_t* out, int ld, hipStream_t st);
+int cast_f32_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st);
+int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int dim, float eps,
+                   hipStream_t st);
+int rmsnorm_bf16(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int dim, float eps, hipStream_t st);
+int add_rmsnorm_bf16(bf16_t* h, const bf16_t* delta_bf16, const float* delta_partial, int nsplit, const bf16_t* w,
+                     bf16_t* y, int rows, int dim, float eps, hipStream_t st);
+int vit_rope_vt_bf16(bf16_t* qkv, const float* cos, const float* sin, const int32_t* seg_of_patch,
+                     const int32_t* seg_start, const int32_t* seg_blk_start, bf16_t* vt, int P, int heads,
+                     int total_blocks, hipStream_t st);
+int mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, bf16_t* cos, bf16_t* sin,
+                hipStream_t st);
+int mrope_table_decode(const int32_t* slots, const int32_t* pos, const float* inv_freq, int B, bf16_t* cos, bf16_t* sin,
+                       hipStream_t st);
+int swiglu_bf16(const bf16_t* g, const bf16_t* u, bf16_t* out, int64_t n, hipStream_t st);
+
+struct KvLayout {  // per-stream KV arena: [layer][K|V][Hkv][Lmax][128]; V blocked-transposed [Lmax/32][128][32]
+  int n_layers, n_kv_heads, lmax, head_dim;
+  __host__ __device__ size_t head_stride() const { return (size_t)lmax * head_dim; }
+  __host__ __device__ size_t kv_stride() const { return (size_t)n_kv_heads * lmax * head_dim; }
+  __host__ __device__ size_t layer_stride() const { return (size_t)2 * n_kv_heads * lmax * head_dim; }
+  __host__ __device__ size_t total() const { return (size_t)n_layers * layer_stride(); }
+};
+int rope_kv_append_bf16(const bf16_t* qkv_bf16, const float* qkv_partial, int nsplit, const bf16_t* bias,
+                        const bf16_t* cos, const bf16_t* sin, const int32_t* tok_stream, const int32_t* tok_pos,
+                        const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay, int layer, bf16_t* q_out, int S,
+                        int n_q_heads, hipStream_t st);
+int embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const bf16_t* table,
+                      const bf16_t* vit_rows, bf16_t* out, int S, int dim, hipStream_t st);
+int gather_rows_bf16(const bf16_t* in, const int32_t* rows, bf16_t* out, int n, int dim, hipStream_t st);
+
+// ---- attention (attention.hip) ----
+int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* tile_seg, const int32_t* tile_q0,
+                  const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
+                  int heads, int total_blocks, hipStream_t st);
+int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0,
+                      const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
+                      int layer, int n_tiles, int n_q_heads, hipStream_t st);
+int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
+                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
+
+// ---- sampler (sampler.hip) ----
+int seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, int indirect,
+             const int32_t* done, hipStream_t st);
+int sample_greedy(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
+                  const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
+                  int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
+                  int32_t* hist_col, float* scores_out, hipStream_t st);
+int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st);
+
+}  // namespace lcc

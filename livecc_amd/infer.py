@@ -1,0 +1,93 @@
+"""Stream orchestrator with the surface of the reference's `LiveCCDemoInfer` (ref demo/infer.py:25-310), driving the
+native model instead of HF.  Video decode / resize (decord, torchvision) are outside this round's scope:
+clips arrive as uint8 frame tensors already at the model resolution (what `get_smart_resized_clip`,
+ref livecc_utils/video_process_patch.py:126-156, returns), and text arrives either through a real HF processor /
+tokenizer (when a checkpoint directory with tokenizer files is given) or as synthetic turn ids (`TurnBuilder`).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import protocol
+from .modeling import LiveCCForConditionalGeneration
+
+
+class ThresholdLogitsProcessor:
+    """ref demo/infer.py:10-23.  Executed natively inside the fused sampler kernel; this object only carries the
+    parameters (and the `count` the reference keeps)."""
+
+    def __init__(self, token_id: int, base_threshold: float, step: float):
+        self.token_id, self.base_threshold, self.step, self.count = token_id, base_threshold, step, 0
+
+
+class LiveCCDemoInfer:
+    fps = protocol.FPS
+    initial_fps_frames = protocol.INITIAL_FPS_FRAMES
+    streaming_fps_frames = protocol.STREAMING_FPS_FRAMES
+    initial_time_interval = protocol.INITIAL_TIME_INTERVAL
+    streaming_time_interval = protocol.STREAMING_TIME_INTERVAL
+    frame_time_interval = protocol.FRAME_TIME_INTERVAL
+
+    def __init__(self, model: LiveCCForConditionalGeneration = None, model_path: str = None, device: str = None,
+                 turn_builder: Optional[protocol.TurnBuilder] = None, decode: Optional[Callable[[List[int]], str]] = None,
+                 streaming_eos_token_id: Optional[int] = None):
+        if model is None:
+            device = device or "cuda"
+            model = LiveCCForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map=device)
+        self.model = model
+        self.cfg = model.cfg
+        self.turn_builder = turn_builder or protocol.TurnBuilder(self.cfg)
+        self.decode = decode or (lambda ids: " ".join(str(i) for i in ids))
+        # ref infer.py:49: tokenizer(' ...').input_ids[-1]; without tokenizer files the caller supplies it
+        self.streaming_eos_token_id = streaming_eos_token_id
+
+    @torch.inference_mode()
+    def live_cc(self, clip: torch.Tensor, state: dict, frames_layout: str = "TCHW", do_sample: bool = False,
+                repetition_penalty: float = 1.05, streaming_eos_base_threshold: float = None,
+                streaming_eos_threshold_step: float = None, max_new_tokens: int = 16, force_length: bool = False):
+        """One call = the frames that became due since the last call (ref infer.py:61-180, steps 4-5).
+        `clip`: uint8 frames [T,3,H,W] (or THWC).  Yields ((start, stop), text, state) per chunk."""
+        if do_sample:
+            raise NotImplementedError("pass do_sample=False (greedy); see modeling.generate")
+        initialized = state.get("last_timestamp", -1.0) >= 0
+        t0 = state.get("last_timestamp", -self.frame_time_interval) + self.frame_time_interval
+        for a, b in protocol.split_clip(clip.shape[0], initialized):
+            frames = clip[a:b]
+            start = t0 + a * self.frame_time_interval
+            stop = t0 + b * self.frame_time_interval
+            turn = state.get("turn_index", 0)
+            grid = protocol.grid_of(frames.shape[0], *(frames.shape[2:] if frames_layout == "TCHW" else frames.shape[1:3]), self.cfg)
+            new_ids = self.turn_builder.turn_ids(turn, protocol.num_video_tokens(grid, self.cfg))
+            past_ids = state.get("past_ids")
+            ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
+            procs = None
+            if streaming_eos_base_threshold is not None and self.streaming_eos_token_id is not None:
+                procs = [ThresholdLogitsProcessor(self.streaming_eos_token_id, streaming_eos_base_threshold,
+                                                  streaming_eos_threshold_step or 0.0)]
+            out = self.model.generate(
+                input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, frames_layout=frames_layout,
+                past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=False,
+                repetition_penalty=repetition_penalty, logits_processor=procs, max_new_tokens=max_new_tokens,
+                min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id)
+            seq = out.sequences[0].cpu().numpy()
+            state["past_key_values"] = out.past_key_values
+            state["past_ids"] = seq[:-1]                      # ref infer.py:174
+            state["turn_index"] = turn + 1
+            state["last_timestamp"] = stop - self.frame_time_interval
+            new_tokens = seq[len(ids):].tolist()
+            yield (start, stop), self.decode([t for t in new_tokens if t != self.cfg.eos_token_id]), state
+
+    @torch.inference_mode()
+    def live_cc_once_for_evaluation(self, clip: torch.Tensor, frames_layout: str = "TCHW", max_new_tokens: int = 32,
+                                    repetition_penalty: float = 1.05, video_start: float = 0.0, force_length: bool = False):
+        """Offline replay of a whole clip (ref infer.py:244-310): chunks 6,2,2,...; returns [[t0, t1, text], ...]."""
+        state: dict = {}
+        responses = []
+        for (a, b), text, state in self.live_cc(clip, state, frames_layout=frames_layout, repetition_penalty=repetition_penalty,
+                                                max_new_tokens=max_new_tokens, force_length=force_length):
+            responses.append([video_start + a, video_start + b, text])
+        self.last_state = state
+        return responses

@@ -1,0 +1,247 @@
+"""Operator-level Python wrappers over the C-ABI (torch tensors in, pointers out).  Used by the HF plugin
+(`plugin.py`) and by the per-kernel parity tests.  Every wrapper validates dtype/device/contiguity and raises;
+nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU = range(5)
+
+
+def _st(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.LccError(f"{name}: expected a GPU tensor (livecc_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epilogue(x @ w.T + bias); x [M,K] bf16, w [N,K] bf16."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K,
+                                 _chk(bias, torch.bfloat16, "bias"), _chk(residual, torch.bfloat16, "residual"), N,
+                                 out.data_ptr(), out.shape[1], M, N, K, epilogue, None, 0, _st(x)), "lcc_gemm_bf16")
+    return out
+
+
+def linear_partial(x: torch.Tensor, w: torch.Tensor, nsplit: int) -> torch.Tensor:
+    """Skinny split-K path: fp32 slabs [nsplit, M, N] (M <= 16)."""
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(nsplit, M, N, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K, None, None, 0, None, N,
+                                 M, N, K, EPI_NONE, out.data_ptr(), nsplit, _st(x)), "lcc_gemm_bf16(partial)")
+    return out
+
+
+def gemv_num_splits(N: int, K: int) -> int:
+    return _lib.load().lcc_gemv_num_splits(N, K)
+
+
+def layernorm(x, w, b, eps=1e-6):
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    _lib.check(_lib.load().lcc_layernorm_bf16(_chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"),
+                                              _chk(b, torch.bfloat16, "b"), y.data_ptr(), rows, x.shape[-1], eps, _st(x)),
+               "lcc_layernorm_bf16")
+    return y
+
+
+def rmsnorm(x, w, eps=1e-6):
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    _lib.check(_lib.load().lcc_rmsnorm_bf16(_chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"), y.data_ptr(), rows,
+                                            x.shape[-1], eps, _st(x)), "lcc_rmsnorm_bf16")
+    return y
+
+
+def add_rmsnorm_(h, w, eps=1e-6, delta=None, partial=None):
+    """In place h += delta; returns rmsnorm(h)*w (or None when w is None)."""
+    y = torch.empty_like(h) if w is not None else None
+    rows = h.numel() // h.shape[-1]
+    nsplit = partial.shape[0] if partial is not None else 0
+    _lib.check(_lib.load().lcc_add_rmsnorm_bf16(_chk(h, torch.bfloat16, "h"), _chk(delta, torch.bfloat16, "delta"),
+                                                _chk(partial, torch.float32, "partial"), nsplit, _chk(w, torch.bfloat16, "w"),
+                                                y.data_ptr() if y is not None else None, rows, h.shape[-1], eps, _st(h)),
+               "lcc_add_rmsnorm_bf16")
+    return y
+
+
+def swiglu(gate, up):
+    out = torch.empty_like(gate)
+    _lib.check(_lib.load().lcc_swiglu_bf16(_chk(gate, torch.bfloat16, "gate"), _chk(up, torch.bfloat16, "up"), out.data_ptr(),
+                                           gate.numel(), _st(gate)), "lcc_swiglu_bf16")
+    return out
+
+
+def patchify_norm(frames: torch.Tensor, layout: str, mean255, std255) -> torch.Tensor:
+    lay = 0 if layout == "THWC" else 1
+    if lay == 0:
+        T, H, W, _ = frames.shape
+    else:
+        T, _, H, W = frames.shape
+    P = ((T + 1) // 2) * (H // 14) * (W // 14)
+    out = torch.empty(P, 1176, dtype=torch.bfloat16, device=frames.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean255])
+    s = (C.c_float * 3)(*[float(v) for v in std255])
+    _lib.check(_lib.load().lcc_patchify_norm_u8(_chk(frames, torch.uint8, "frames"), lay, T, H, W, m, s, out.data_ptr(), 1176,
+                                                _st(frames)), "lcc_patchify_norm_u8")
+    return out
+
+
+def cast_f32_bf16(x):
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().lcc_cast_f32_bf16(_chk(x, torch.float32, "x"), out.data_ptr(), x.numel(), _st(x)), "lcc_cast_f32_bf16")
+    return out
+
+
+def _i32(a, device) -> torch.Tensor:
+    return torch.as_tensor(np.asarray(a, dtype=np.int32), device=device)
+
+
+def vit_segments(grids: Sequence[Sequence[int]], device):
+    """Segment / tile tables of the ViT attention for clips with grids (t,h,w): one segment per temporal slice."""
+    seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0 = [], [], [], [], [], []
+    P = blocks = 0
+    for t, h, w in grids:
+        n = h * w
+        for _ in range(t):
+            sg = len(seg_start)
+            seg_start.append(P); seg_len.append(n); seg_blk.append(blocks)
+            for q in range(0, n, 32):
+                tile_seg.append(sg); tile_q0.append(q)
+            seg_of_patch += [sg] * n
+            P += n; blocks += (n + 31) // 32
+    d = dict(seg_start=_i32(seg_start, device), seg_len=_i32(seg_len, device), seg_blk=_i32(seg_blk, device),
+             seg_of_patch=_i32(seg_of_patch, device), tile_seg=_i32(tile_seg, device), tile_q0=_i32(tile_q0, device),
+             P=P, blocks=blocks, n_tiles=len(tile_seg))
+    return d
+
+
+def vit_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, grids, heads: int) -> torch.Tensor:
+    """qkv [P, 3E] bf16 (un-rotated; modified in place), cos/sin fp32 [P,40] -> attention output [P, E]."""
+    lib = _lib.load()
+    seg = vit_segments(grids, qkv.device)
+    P, E = qkv.shape[0], qkv.shape[1] // 3
+    vt = torch.zeros(heads * seg["blocks"] * 80 * 32, dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty(P, E, dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(lib.lcc_vit_rope_vt_bf16(_chk(qkv, torch.bfloat16, "qkv"), _chk(cos, torch.float32, "cos"),
+                                        _chk(sin, torch.float32, "sin"), seg["seg_of_patch"].data_ptr(),
+                                        seg["seg_start"].data_ptr(), seg["seg_blk"].data_ptr(), vt.data_ptr(), P, heads,
+                                        seg["blocks"], _st(qkv)), "lcc_vit_rope_vt_bf16")
+    _lib.check(lib.lcc_attn_vit_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg["tile_seg"].data_ptr(),
+                                     seg["tile_q0"].data_ptr(), seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(),
+                                     seg["seg_blk"].data_ptr(), seg["n_tiles"], heads, seg["blocks"], _st(qkv)),
+               "lcc_attn_vit_bf16")
+    return out
+
+
+def mrope_table(pos3: torch.Tensor, inv_freq: torch.Tensor, sections) -> Tuple[torch.Tensor, torch.Tensor]:
+    S = pos3.shape[1]
+    cos = torch.empty(S, 64, dtype=torch.bfloat16, device=pos3.device)
+    sin = torch.empty_like(cos)
+    _lib.check(_lib.load().lcc_mrope_table(_chk(pos3, torch.int32, "pos3"), _chk(inv_freq, torch.float32, "inv_freq"), S,
+                                           int(sections[0]), int(sections[1]), cos.data_ptr(), sin.data_ptr(), _st(pos3)),
+               "lcc_mrope_table")
+    return cos, sin
+
+
+class KvArena:
+    """Stand-alone KV arena(s) for the operator-level attention tests / plugin: [layer][K|V][Hkv][Lmax][128]."""
+
+    def __init__(self, n_slots, n_layers, n_kv_heads, lmax, device):
+        self.lay = _lib.KvLayout(n_layers, n_kv_heads, lmax, 128)
+        self.per_slot = n_layers * 2 * n_kv_heads * lmax * 128
+        self.buf = torch.zeros(n_slots, self.per_slot, dtype=torch.bfloat16, device=device)
+        ptrs = np.asarray([self.buf[i].data_ptr() for i in range(n_slots)], dtype=np.uint64)
+        self.ptrs = torch.as_tensor(ptrs.view(np.int64), device=device)
+        self.n_kv_heads, self.lmax, self.n_layers = n_kv_heads, lmax, n_layers
+
+    def k_view(self, slot, layer):  # [Hkv, Lmax, 128]
+        o = layer * 2 * self.n_kv_heads * self.lmax * 128
+        return self.buf[slot, o:o + self.n_kv_heads * self.lmax * 128].view(self.n_kv_heads, self.lmax, 128)
+
+    def v_view(self, slot, layer):  # logical [Hkv, Lmax, 128] gathered from the blocked-transposed storage
+        o = (layer * 2 + 1) * self.n_kv_heads * self.lmax * 128
+        raw = self.buf[slot, o:o + self.n_kv_heads * self.lmax * 128].view(self.n_kv_heads, self.lmax // 32, 128, 32)
+        return raw.permute(0, 1, 3, 2).reshape(self.n_kv_heads, self.lmax, 128)
+
+
+def rope_kv_append(qkv: Optional[torch.Tensor], cos, sin, tok_stream, tok_pos, kv: KvArena, layer: int, n_q_heads: int,
+                   partial: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                   kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+    S = cos.shape[0]
+    q = torch.empty(S, n_q_heads * 128, dtype=torch.bfloat16, device=cos.device)
+    _lib.check(_lib.load().lcc_rope_kv_append_bf16(
+        _chk(qkv, torch.bfloat16, "qkv"), _chk(partial, torch.float32, "partial"), partial.shape[0] if partial is not None else 0,
+        _chk(bias, torch.bfloat16, "bias"), _chk(cos, torch.bfloat16, "cos"), _chk(sin, torch.bfloat16, "sin"),
+        _chk(tok_stream, torch.int32, "tok_stream"), _chk(tok_pos, torch.int32, "tok_pos"), _chk(kv_len, torch.int32, "kv_len"),
+        kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr(), S, n_q_heads, _st(cos)), "lcc_rope_kv_append_bf16")
+    return q
+
+
+def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tuple[int, int, int]], n_q_heads: int):
+    """segments: (slot, n_new, past_len) per stream, rows packed in that order."""
+    ts, tq, tn, tp = [], [], [], []
+    row = 0
+    for slot, n_new, past in segments:
+        for o in range(0, n_new, 32):
+            ts.append(slot); tq.append(row + o); tn.append(min(32, n_new - o)); tp.append(past + o)
+        row += n_new
+    dev = q.device
+    out = torch.empty_like(q)
+    a, b, c, d = _i32(ts, dev), _i32(tq, dev), _i32(tn, dev), _i32(tp, dev)
+    _lib.check(_lib.load().lcc_attn_prefill_bf16(_chk(q, torch.bfloat16, "q"), out.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                                 c.data_ptr(), d.data_ptr(), kv.ptrs.data_ptr(), kv.lay, layer, len(ts),
+                                                 n_q_heads, _st(q)), "lcc_attn_prefill_bf16")
+    return out
+
+
+def attn_decode(q: torch.Tensor, kv: KvArena, layer: int, slots: torch.Tensor, kv_len: torch.Tensor, n_q_heads: int,
+                nsplit: int):
+    B = q.shape[0]
+    out = torch.empty_like(q)
+    ws_o = torch.empty(B * kv.n_kv_heads * nsplit * 16 * 128, dtype=torch.float32, device=q.device)
+    ws_ml = torch.empty(B * kv.n_kv_heads * nsplit * 16 * 2, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().lcc_attn_decode_bf16(_chk(q, torch.bfloat16, "q"), out.data_ptr(), _chk(slots, torch.int32, "slots"),
+                                                _chk(kv_len, torch.int32, "kv_len"), kv.ptrs.data_ptr(), kv.lay, layer, B,
+                                                n_q_heads, nsplit, ws_o.data_ptr(), ws_ml.data_ptr(), _st(q)),
+               "lcc_attn_decode_bf16")
+    return out
+
+
+def sample_greedy(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor, repetition_penalty: float = 1.0,
+                  thr_token: int = -1, thr_value: Optional[float] = None, eos_token: int = -1, suppress_eos: bool = False,
+                  want_scores: bool = False):
+    B, V = logits.shape
+    n_slots, words = seen.shape
+    out = torch.zeros(n_slots, dtype=torch.int32, device=logits.device)
+    scores = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_scores else None
+    _lib.check(_lib.load().lcc_sample_greedy(
+        _chk(logits, torch.bfloat16, "logits"), V, B, V, _chk(seen, torch.int32, "seen"), words, _chk(slots, torch.int32, "slots"),
+        repetition_penalty, thr_token, 1 if thr_value is not None else 0, float(thr_value or 0.0), eos_token,
+        1 if suppress_eos else 0, None, out.data_ptr(), None, 0, None, scores.data_ptr() if scores is not None else None,
+        _st(logits)), "lcc_sample_greedy")
+    return out, scores

@@ -1,0 +1,175 @@
+"""Weight arena of the native engine.
+
+All parameters live in ONE flat bf16 HBM arena (plus a tiny fp32 tail for `inv_freq`); every named weight
+is a view into it.  That is what makes the multi-GPU start-up a single RCCL broadcast over xGMI
+(`distributed.broadcast_weights`) instead of every data-parallel worker re-reading the checkpoint from disk
+as the reference does (ref evaluation/livesports3kcc/distributed_generate_livecc.py:46).
+
+Layout decisions (engine names -> shapes):
+  vit.patch_embed [E,1176]           Conv3d weight [E,3,2,14,14] flattened (c,t,y,x) = patch feature order
+  vit.{i}.qkv_w [3E,E] ...           as HF
+  llm.{i}.qkv_w [Hq*128+2*Hkv*128, H] q_proj|k_proj|v_proj rows concatenated (one GEMM)
+  llm.{i}.gate_up_w [2I, H]          rows interleaved in blocks of 16: [16 gate rows | 16 up rows] so that
+                                     the GEMM epilogue holds gate and up of the same column in one lane
+  lm_head [V,H]                      tied checkpoints (2B) alias `embed`
+HF parameter names follow HF models/qwen2_vl/modeling_qwen2_vl.py (5.x: `model.visual.*`,
+`model.language_model.*`; 4.5x checkpoints: `visual.*`, `model.layers.*`) -- both are accepted.
+"""
+from __future__ import annotations
+
+import re
+from typing import Callable, Dict, Iterable, List, Tuple
+
+import torch
+
+from .config import LiveCCConfig
+
+
+def weight_shapes(cfg: LiveCCConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    E, H, I = cfg.vit_embed_dim, cfg.hidden_size, cfg.intermediate_size
+    M = cfg.vit_mlp_dim
+    out: List[Tuple[str, Tuple[int, ...]]] = [("vit.patch_embed", (E, cfg.patch_dim))]
+    for i in range(cfg.vit_depth):
+        p = f"vit.{i}."
+        out += [(p + "ln1_w", (E,)), (p + "ln1_b", (E,)), (p + "qkv_w", (3 * E, E)), (p + "qkv_b", (3 * E,)),
+                (p + "proj_w", (E, E)), (p + "proj_b", (E,)), (p + "ln2_w", (E,)), (p + "ln2_b", (E,)),
+                (p + "fc1_w", (M, E)), (p + "fc1_b", (M,)), (p + "fc2_w", (E, M)), (p + "fc2_b", (E,))]
+    out += [("merger.ln_w", (E,)), ("merger.ln_b", (E,)), ("merger.fc1_w", (4 * E, 4 * E)), ("merger.fc1_b", (4 * E,)),
+            ("merger.fc2_w", (H, 4 * E)), ("merger.fc2_b", (H,)), ("embed", (cfg.vocab_size, H))]
+    for i in range(cfg.num_hidden_layers):
+        p = f"llm.{i}."
+        out += [(p + "in_norm", (H,)), (p + "qkv_w", (cfg.qkv_dim, H)), (p + "qkv_b", (cfg.qkv_dim,)),
+                (p + "o_w", (H, cfg.q_dim)), (p + "post_norm", (H,)), (p + "gate_up_w", (2 * I, H)),
+                (p + "down_w", (H, I))]
+    out += [("final_norm", (H,))]
+    if not cfg.tie_word_embeddings:
+        out += [("lm_head", (cfg.vocab_size, H))]
+    return out
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I,H],[I,H] -> [2I,H] with rows [16 gate | 16 up | 16 gate | ...]."""
+    I, H = gate.shape
+    assert I % 16 == 0
+    return torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], dim=1).reshape(2 * I, H)
+
+
+class WeightArena:
+    def __init__(self, cfg: LiveCCConfig, device):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.shapes = weight_shapes(cfg)
+        offs, total = {}, 0
+        for name, shp in self.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            offs[name] = (total, n, shp)
+            total += (n + 127) // 128 * 128          # keep every weight 256-byte aligned
+        self.offsets, self.numel = offs, total
+        self.flat = torch.empty(total, dtype=torch.bfloat16, device=self.device)
+        hd = cfg.head_dim
+        # HF Qwen2VLRotaryEmbedding.compute_default_rope_parameters (modeling_qwen2_vl.py:129-146), fp32 on CPU
+        self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(self.device)
+
+    def view(self, name: str) -> torch.Tensor:
+        if name == "lm_head" and self.cfg.tie_word_embeddings:
+            name = "embed"
+        o, n, shp = self.offsets[name]
+        return self.flat[o:o + n].view(*shp)
+
+    def names(self) -> List[str]:
+        n = [s[0] for s in self.shapes]
+        if self.cfg.tie_word_embeddings:
+            n.append("lm_head")
+        return n
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * 2
+
+    # ---- fillers ----
+    @torch.no_grad()
+    def fill_random(self, seed: int = 0, std: float = 0.02) -> "WeightArena":
+        """Random weights generated directly in HBM (no checkpoints offline): N(0, std) matrices, norm weights
+        1 + 0.1 N(0,1), biases 0.05 N(0,1).  Throughput is data-independent; used by bench.py at 7B shapes."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for name, shp in self.shapes:
+            v = self.view(name)
+            if len(shp) >= 2:
+                v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(std))
+            elif name.endswith("_b"):
+                v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(0.05))
+            else:
+                v.copy_(1.0 + 0.1 * torch.randn(shp, generator=g, device=self.device, dtype=torch.float32))
+        return self
+
+    @torch.no_grad()
+    def load_state_dict(self, sd_get: Callable[[str], torch.Tensor]) -> "WeightArena":
+        """Fill from an HF state dict accessor (tensor by HF name; any float dtype; CPU or GPU)."""
+        cfg = self.cfg
+
+        def put(name, t):
+            v = self.view(name)
+            assert tuple(t.shape) == tuple(v.shape), f"{name}: {tuple(t.shape)} vs {tuple(v.shape)}"
+            v.copy_(t.to(self.device, dtype=torch.bfloat16))
+
+        put("vit.patch_embed", sd_get("visual.patch_embed.proj.weight").reshape(cfg.vit_embed_dim, -1))
+        for i in range(cfg.vit_depth):
+            s, p = f"visual.blocks.{i}.", f"vit.{i}."
+            for a, b in (("norm1.weight", "ln1_w"), ("norm1.bias", "ln1_b"), ("attn.qkv.weight", "qkv_w"),
+                         ("attn.qkv.bias", "qkv_b"), ("attn.proj.weight", "proj_w"), ("attn.proj.bias", "proj_b"),
+                         ("norm2.weight", "ln2_w"), ("norm2.bias", "ln2_b"), ("mlp.fc1.weight", "fc1_w"),
+                         ("mlp.fc1.bias", "fc1_b"), ("mlp.fc2.weight", "fc2_w"), ("mlp.fc2.bias", "fc2_b")):
+                put(p + b, sd_get(s + a))
+        for a, b in (("ln_q.weight", "ln_w"), ("ln_q.bias", "ln_b"), ("mlp.0.weight", "fc1_w"), ("mlp.0.bias", "fc1_b"),
+                     ("mlp.2.weight", "fc2_w"), ("mlp.2.bias", "fc2_b")):
+            put("merger." + b, sd_get("visual.merger." + a))
+        put("embed", sd_get("language_model.embed_tokens.weight"))
+        for i in range(cfg.num_hidden_layers):
+            s, p = f"language_model.layers.{i}.", f"llm.{i}."
+            put(p + "in_norm", sd_get(s + "input_layernorm.weight"))
+            put(p + "qkv_w", torch.cat([sd_get(s + f"self_attn.{x}_proj.weight") for x in "qkv"], dim=0))
+            put(p + "qkv_b", torch.cat([sd_get(s + f"self_attn.{x}_proj.bias") for x in "qkv"], dim=0))
+            put(p + "o_w", sd_get(s + "self_attn.o_proj.weight"))
+            put(p + "post_norm", sd_get(s + "post_attention_layernorm.weight"))
+            put(p + "gate_up_w", interleave_gate_up(sd_get(s + "mlp.gate_proj.weight"), sd_get(s + "mlp.up_proj.weight")))
+            put(p + "down_w", sd_get(s + "mlp.down_proj.weight"))
+        put("final_norm", sd_get("language_model.norm.weight"))
+        if not cfg.tie_word_embeddings:
+            put("lm_head", sd_get("lm_head.weight"))
+        return self
+
+
+def _normalise_hf_key(k: str) -> str:
+    """Map 5.x and 4.5x parameter names onto one scheme: visual.* / language_model.* / lm_head.weight."""
+    k = re.sub(r"^model\.visual\.", "visual.", k)
+    k = re.sub(r"^model\.language_model\.", "language_model.", k)
+    k = re.sub(r"^model\.(layers|embed_tokens|norm)\.", r"language_model.\1.", k)
+    return k
+
+
+def from_hf_model(hf_model, cfg: LiveCCConfig, device) -> WeightArena:
+    sd = {_normalise_hf_key(k): v for k, v in hf_model.state_dict().items()}
+    return WeightArena(cfg, device).load_state_dict(lambda n: sd[n])
+
+
+def from_pretrained(path: str, cfg: LiveCCConfig, device) -> WeightArena:
+    """safetensors checkpoint directory -> arena (what `from_pretrained` does at ref demo/infer.py:43-47)."""
+    import glob
+    import os
+    from safetensors import safe_open
+    index: Dict[str, Tuple[str, str]] = {}
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    handles = {f: safe_open(f, framework="pt", device="cpu") for f in files}
+    for f, h in handles.items():
+        for k in h.keys():
+            index[_normalise_hf_key(k)] = (f, k)
+
+    def get(name):
+        if name not in index:
+            raise KeyError(f"{name} missing from checkpoint {path}")
+        f, k = index[name]
+        return handles[f].get_tensor(k)
+
+    return WeightArena(cfg, device).load_state_dict(get)

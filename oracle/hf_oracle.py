@@ -167,9 +167,11 @@ class OracleStream:
         if streaming_eos is not None:
             from transformers import LogitsProcessorList
             procs = LogitsProcessorList([ThresholdLogitsProcessor(*streaming_eos)])
+        force = None
         if teacher_tokens is not None:
             from transformers import LogitsProcessorList
-            procs = LogitsProcessorList([_ForceTokens(list(teacher_tokens), input_ids.shape[1])])
+            force = _ForceTokens(list(teacher_tokens), input_ids.shape[1])
+            procs = LogitsProcessorList(([procs[0]] if procs is not None else []) + [force])
         # restore this stream's rope_deltas (HF keeps it on the module: modeling_qwen2_vl.py:857)
         model.model.rope_deltas = self.rope_deltas
         t0 = time.perf_counter()
@@ -186,7 +188,7 @@ class OracleStream:
         n_in = input_ids.shape[1]
         return dict(sequences=out.sequences[0].clone(), new_tokens=out.sequences[0, n_in:].tolist(),
                     logits=[l[0].float().clone() for l in out.logits],
-                    scores=[s[0].float().clone() for s in out.scores], n_input=n_in)
+                    scores=(force.pre if force is not None else [s[0].float().clone() for s in out.scores]), n_input=n_in)
 
 
 class _ForceTokens:
@@ -195,8 +197,10 @@ class _ForceTokens:
 
     def __init__(self, tokens: List[int], n_prompt: int):
         self.tokens, self.n_prompt = tokens, n_prompt
+        self.pre: List[torch.Tensor] = []      # processed scores before forcing (the oracle's own preference)
 
     def __call__(self, input_ids, scores):
+        self.pre.append(scores[0].float().clone())
         i = input_ids.shape[1] - self.n_prompt
         if i < len(self.tokens):
             scores = scores.clone()

@@ -1,0 +1,368 @@
+"""Per-kernel parity tests (-m gpu): every HIP kernel, called through the C-ABI (livecc_amd.ops -> ctypes ->
+liblivecc_amd.so), against an fp32 torch restatement of the HF op it replaces with HF's bf16 rounding points.
+
+Tolerances (written per test): results that HF rounds once to bf16 must agree with the reference to <= 1 bf16 ulp
+with only rare (<0.2%) 1-ulp flips (different fp32 summation order); chains of rounded ops get 2 ulp; attention
+(P is rounded to bf16 before P.V, as in HF eager/flash kernels) is checked at 2% of the output scale.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_bf16_close, rb, record
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+def _ref_linear(x, w, bias=None, epi=0, residual=None):
+    acc = x.float() @ w.float().t()
+    if bias is not None:
+        acc = acc + bias.float()
+    if epi == 4:  # swiglu over interleaved [16 gate | 16 up] column blocks
+        M, N2 = acc.shape
+        a = acc.view(M, N2 // 32, 2, 16)
+        g, u = rb(a[:, :, 0]), rb(a[:, :, 1])
+        s = rb(g / (1.0 + torch.exp(-g)))
+        return rb(s * u).reshape(M, N2 // 2)
+    y = rb(acc)
+    if epi == 1:
+        t = rb(1.702 * y)
+        y = rb(y * rb(torch.sigmoid(t)))
+    elif epi == 2:
+        y = rb(torch.nn.functional.gelu(y))
+    elif epi == 3:
+        y = rb(y + residual.float())
+    return y
+
+
+def test_mfma_layout_probe(dev):
+    """The 16x16x32 bf16 MFMA operand / result lane maps assumed by every kernel (common.h)."""
+    from livecc_amd import _lib
+    a = (torch.arange(16 * 32).view(16, 32) % 13 - 6).to(torch.bfloat16).to(dev)
+    b = (torch.arange(32 * 16).view(32, 16) % 7 - 3).to(torch.bfloat16).to(dev)
+    d = torch.zeros(16, 16, device=dev)
+    _lib.check(_lib.load().lcc_debug_mfma_probe(a.data_ptr(), b.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(d, a.float() @ b.float()), "MFMA fragment layout assumption is wrong"
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 512, 256), (386, 1280, 1176), (130, 480, 160), (64, 1024, 640), (1456, 3840, 1280),
+                                   (17, 256, 512), (300, 4608, 3584)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_tiled(dev, M, N, K, epi):
+    from livecc_amd import ops
+    x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
+    res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
+    got = ops.linear(x, w, b, epi, res)
+    ref = _ref_linear(x, w, b, epi, res)
+    assert_bf16_close(got, ref, f"gemm_tiled[{M}x{N}x{K},epi{epi}]", max_ulp=1.0 if epi in (0, 3) else 2.0, max_frac=5e-3)
+
+
+@pytest.mark.parametrize("M,I,K", [(100, 512, 256), (386, 2432, 896)])
+def test_gemm_tiled_swiglu(dev, M, I, K):
+    from livecc_amd import ops
+    x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
+    got = ops.linear(x, w, None, ops.EPI_SWIGLU)
+    assert_bf16_close(got, _ref_linear(x, w, None, 4), f"gemm_tiled_swiglu[{M}x{I}x{K}]", max_ulp=2.0, max_frac=5e-3)
+
+
+def test_gemm_no_bias_identity_layout(dev):
+    """A = I with an asymmetric W catches a transposed C write (symmetric inputs would not)."""
+    from livecc_amd import ops
+    K = 256
+    x = torch.eye(K, dtype=torch.bfloat16, device=dev)[:200].contiguous()
+    w = (torch.arange(512 * K, device=dev).view(512, K) % 251 - 125).to(torch.bfloat16).contiguous()
+    got = ops.linear(x, w)
+    assert torch.equal(got.float(), w.float().t()[:200].contiguous())
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944)])
+def test_gemv_skinny(dev, M, N, K):
+    from livecc_amd import ops
+    x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.03, 2), _rand((N,), dev, 0.1, 3)
+    got = ops.linear(x, w, b)
+    assert_bf16_close(got, _ref_linear(x, w, b), f"gemv[{M}x{N}x{K}]", max_ulp=1.0, max_frac=5e-3)
+    S = ops.gemv_num_splits(N, K)
+    part = ops.linear_partial(x, w, S)
+    ref = x.float() @ w.float().t()
+    err = (part.sum(0) - ref).abs().max().item()
+    record(f"gemv_partial[{M}x{N}x{K},S{S}]", dict(max_abs=err, scale=float(ref.abs().max())))
+    assert err <= 2e-5 * float(ref.abs().max()) * math.sqrt(K / 256) + 1e-5, f"split-K slabs: {err}"
+
+
+@pytest.mark.parametrize("M", [1, 7, 16])
+def test_gemv_swiglu(dev, M):
+    from livecc_amd import ops
+    I, K = 2432, 896
+    x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
+    got = ops.linear(x, w, None, ops.EPI_SWIGLU)
+    assert_bf16_close(got, _ref_linear(x, w, None, 4), f"gemv_swiglu[{M}]", max_ulp=2.0, max_frac=5e-3)
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from livecc_amd import _lib, ops
+    x, w = _rand((4, 100), dev), _rand((32, 100), dev)   # K % 8 != 0
+    with pytest.raises(_lib.LccError):
+        ops.linear(x, w)
+    with pytest.raises((TypeError, _lib.LccError)):
+        ops.linear(x.float(), w)
+
+
+@pytest.mark.parametrize("rows,dim", [(37, 1280), (5, 160), (300, 320)])
+def test_layernorm(dev, rows, dim):
+    from livecc_amd import ops
+    x, w, b = _rand((rows, dim), dev, 2.0, 1), _rand((dim,), dev, 1.0, 2), _rand((dim,), dev, 0.5, 3)
+    got = ops.layernorm(x, w, b, 1e-6)
+    ref = rb(torch.nn.functional.layer_norm(x.float(), (dim,), w.float(), b.float(), 1e-6))
+    assert_bf16_close(got, ref, f"layernorm[{rows}x{dim}]", max_ulp=1.0, max_frac=5e-3)
+
+
+def _ref_rmsnorm(x, w, eps):
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    return rb(w.float() * rb(xf * torch.rsqrt(var + eps)))
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 3584), (9, 256), (386, 3584), (3, 8192)])
+def test_rmsnorm_and_add(dev, rows, dim):
+    from livecc_amd import ops
+    x, w = _rand((rows, dim), dev, 3.0, 1), _rand((dim,), dev, 1.0, 2)
+    assert_bf16_close(ops.rmsnorm(x, w, 1e-6), _ref_rmsnorm(x, w, 1e-6), f"rmsnorm[{rows}x{dim}]", 1.0, 5e-3)
+    # bf16 delta
+    d = _rand((rows, dim), dev, 1.0, 3)
+    h = x.clone()
+    y = ops.add_rmsnorm_(h, w, 1e-6, delta=d)
+    h_ref = rb(x.float() + d.float())
+    assert torch.equal(h.float(), h_ref), "residual add must be exact (one fp32 add, one rounding)"
+    assert_bf16_close(y, _ref_rmsnorm(h_ref, w, 1e-6), f"add_rmsnorm[{rows}x{dim}]", 1.0, 5e-3)
+    # fp32 split-K slabs
+    if rows <= 16:
+        part = torch.randn(4, rows, dim, device=dev) * 0.5
+        h = x.clone()
+        y = ops.add_rmsnorm_(h, w, 1e-6, partial=part)
+        h_ref = rb(x.float() + rb(part[0] + part[1] + part[2] + part[3]))
+        assert_bf16_close(h, h_ref, f"add_partial[{rows}x{dim}]", 1.0, 1e-3)
+        assert_bf16_close(y, _ref_rmsnorm(h, w, 1e-6), f"add_partial_rmsnorm[{rows}x{dim}]", 1.0, 5e-3)
+
+
+def test_swiglu(dev):
+    from livecc_amd import ops
+    g, u = _rand((33, 512), dev, 2.0, 1), _rand((33, 512), dev, 1.0, 2)
+    gf = g.float()
+    ref = rb(rb(gf / (1.0 + torch.exp(-gf))) * u.float())
+    assert_bf16_close(ops.swiglu(g, u), ref, "swiglu", 1.0, 5e-3)
+
+
+@pytest.mark.parametrize("layout", ["THWC", "TCHW"])
+@pytest.mark.parametrize("T,H,W", [(2, 56, 84), (6, 112, 56), (3, 28, 28)])
+def test_patchify_norm_matches_oracle(dev, layout, T, H, W):
+    """bit-exact vs the oracle restatement of the HF video processor (same fp32 ops, one rounding to bf16)."""
+    from livecc_amd import ops, protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.engine import fused_mean_std
+    from oracle import hf_oracle as O
+    f = protocol.synth_frames(T, H, W, seed=7, layout="TCHW")
+    ref, grid = O.patchify_normalize_ref(torch.from_numpy(f), tiny())
+    fin = torch.from_numpy(f if layout == "TCHW" else np.ascontiguousarray(f.transpose(0, 2, 3, 1))).to(dev)
+    m, s = fused_mean_std()
+    got = ops.patchify_norm(fin, layout, m, s)
+    assert got.shape == ref.shape
+    assert torch.equal(got.float().cpu(), rb(ref)), "patchify+normalise must be bit-exact"
+
+
+def test_cast(dev):
+    from livecc_amd import ops
+    x = torch.randn(1000, 8, device=dev) * 3
+    assert torch.equal(ops.cast_f32_bf16(x), x.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def _check_attn(got, ref, name, rel=0.02):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert torch.isfinite(got).all(), f"{name}: non-finite"
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    record(name, dict(max_abs=err, scale=scale, mean_abs=float((got - ref).abs().mean())))
+    assert err <= rel * scale, f"{name}: max err {err:.4g} > {rel} * scale {scale:.4g}"
+    assert (got - ref).abs().mean().item() <= 0.25 * rel * scale
+
+
+@pytest.mark.parametrize("grids", [[(1, 4, 6)], [(3, 4, 6)], [(1, 10, 14), (2, 6, 8)], [(1, 28, 52)]])
+def test_vit_rope_attention(dev, grids):
+    """VisionAttention core: fp32 2-D RoPE (one rounding) + per-temporal-slice non-causal attention, d = 80."""
+    from livecc_amd import ops
+    from livecc_amd.config import tiny
+    from livecc_amd.engine import vision_rope_tables
+    heads, D = 2, 80
+    E = heads * D
+    P = sum(t * h * w for t, h, w in grids)
+    qkv = _rand((P, 3 * E), dev, 1.5, 5)
+    cos, sin = vision_rope_tables(grids, tiny())
+    assert cos.shape == (P, 40)
+    q, k, v = [x.reshape(P, heads, D).float() for x in qkv.float().split(E, dim=1)]
+    c = torch.cat([cos, cos], -1).to(dev)[:, None, :]
+    s = torch.cat([sin, sin], -1).to(dev)[:, None, :]
+    rot = lambda x: torch.cat([-x[..., D // 2:], x[..., :D // 2]], -1)
+    qr, kr = rb(q * c + rot(q) * s), rb(k * c + rot(k) * s)
+    ref = torch.zeros(P, heads, D, device=dev)
+    off = 0
+    for t, h, w in grids:
+        n = h * w
+        for _ in range(t):
+            sl = slice(off, off + n)
+            att = torch.einsum("qhd,khd->hqk", qr[sl], kr[sl]) / math.sqrt(D)
+            ref[sl] = torch.einsum("hqk,khd->qhd", att.softmax(-1), v[sl])
+            off += n
+    got = ops.vit_attention(qkv.clone(), cos.to(dev), sin.to(dev), grids, heads)
+    _check_attn(got.view(P, heads, D), rb(ref), f"vit_attn{grids}")
+
+
+def _hf_mrope_ref(pos3, theta=1e6):
+    inv = 1.0 / (theta ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))
+    freqs = pos3.float()[:, :, None] * inv[None, None, :]          # [3,S,64]
+    emb = torch.cat([freqs, freqs], -1)
+    cos, sin = emb.cos().to(torch.bfloat16), emb.sin().to(torch.bfloat16)
+    sec = [16, 24, 24] * 2
+    cs = torch.cat([m[i % 3] for i, m in enumerate(cos.split(sec, dim=-1))], -1)   # [S,128]
+    sn = torch.cat([m[i % 3] for i, m in enumerate(sin.split(sec, dim=-1))], -1)
+    return cs, sn, inv
+
+
+def test_mrope_table(dev):
+    from livecc_amd import ops
+    S = 300
+    pos = torch.stack([torch.randint(0, 33000, (S,)), torch.randint(0, 33000, (S,)), torch.randint(0, 33000, (S,))]).int()
+    cs, sn, inv = _hf_mrope_ref(pos)
+    c, s = ops.mrope_table(pos.to(dev), inv.to(dev), [16, 24, 24])
+    # cos/sin of large fp32 angles: device and host libm may differ by an fp32 ulp, i.e. a rare bf16 flip
+    assert_bf16_close(c, cs[:, :64], "mrope_cos", 1.0, 2e-3, atol=1e-3)
+    assert_bf16_close(s, sn[:, :64], "mrope_sin", 1.0, 2e-3, atol=1e-3)
+
+
+def _ref_attn_causal(q, k, v, past):
+    """q [S,Hq,128]; k,v [L,Hkv,128] (L = past+S); bottom-right aligned causal GQA, fp32."""
+    S, Hq, D = q.shape
+    L, Hkv, _ = k.shape
+    G = Hq // Hkv
+    kk, vv = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
+    att = torch.einsum("qhd,khd->hqk", q, kk) / math.sqrt(D)
+    qpos = past + torch.arange(S, device=q.device)
+    mask = torch.arange(L, device=q.device)[None, :] > qpos[:, None]
+    att = att.masked_fill(mask[None], float("-inf"))
+    return torch.einsum("hqk,khd->qhd", att.softmax(-1), vv)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(2, 1), (7, 1), (28, 4)])
+def test_rope_append_prefill_decode_attention(dev, Hq, Hkv):
+    """M-RoPE apply + KV append (bit-level vs HF's bf16 op sequence), then prefill and decode attention over the cache."""
+    from livecc_amd import ops
+    D, L0, S1, S2 = 128, 0, 70, 45
+    qkv_dim = (Hq + 2 * Hkv) * D
+    kv = ops.KvArena(2, 2, Hkv, 256, dev)
+    layer, slot = 1, 1
+    k_all, v_all = [], []
+    past = 0
+    for turn, S in enumerate([S1, S2]):
+        qkv = _rand((S, qkv_dim), dev, 1.0, 10 + turn)
+        pos = torch.arange(past, past + S).int()
+        pos3 = torch.stack([pos, pos + (3 if turn == 0 else 0), pos + (5 if turn == 0 else 0)])
+        cs, sn, inv = _hf_mrope_ref(pos3)
+        c, s = ops.mrope_table(pos3.to(dev), inv.to(dev), [16, 24, 24])
+        q_got = ops.rope_kv_append(qkv, c, s, torch.full((S,), slot, dtype=torch.int32, device=dev),
+                                   pos.to(dev), kv, layer, Hq)
+        # HF apply_multimodal_rotary_pos_emb on bf16 tensors: every op rounds
+        x = qkv.float().view(S, Hq + 2 * Hkv, D)
+        cf, sf = c.float().repeat(1, 2)[:, None, :], s.float().repeat(1, 2)[:, None, :]   # device tables (tested above)
+        rot = torch.cat([-x[..., 64:], x[..., :64]], -1)
+        emb = rb(rb(x * cf) + rb(rot * sf))
+        q_ref, k_new, v_new = emb[:, :Hq], emb[:, Hq:Hq + Hkv], x[:, Hq + Hkv:]
+        assert torch.equal(q_got.float().view(S, Hq, D), q_ref), "rotated q must be bit-exact"
+        k_all.append(k_new); v_all.append(v_new)
+        K, V = torch.cat(k_all), torch.cat(v_all)
+        assert torch.equal(kv.k_view(slot, layer)[:, :past + S].float(), K.transpose(0, 1)), "K cache append"
+        assert torch.equal(kv.v_view(slot, layer)[:, :past + S].float(), V.transpose(0, 1)), "V cache append (blocked-transposed)"
+        got = ops.attn_prefill(q_got, kv, layer, [(slot, S, past)], Hq)
+        ref = _ref_attn_causal(q_ref, K, V, past)
+        _check_attn(got.view(S, Hq, D), rb(ref), f"attn_prefill[Hq{Hq},turn{turn}]")
+        past += S
+    # decode: one new token, appended at kv_len through the device counter path, several split counts
+    qkv = _rand((1, qkv_dim), dev, 1.0, 99)
+    bias = _rand((qkv_dim,), dev, 0.2, 98)
+    part = torch.stack([qkv[0].float() * 0.25, qkv[0].float() * 0.75]).view(2, 1, qkv_dim).contiguous()
+    x_lin = rb(part[0] + part[1] + bias.float())
+    pos3 = torch.full((3, 1), past, dtype=torch.int32)
+    cs, sn, inv = _hf_mrope_ref(pos3)
+    c, s = ops.mrope_table(pos3.to(dev), inv.to(dev), [16, 24, 24])
+    kv_len = torch.tensor([0, past], dtype=torch.int32, device=dev)
+    slots = torch.tensor([slot], dtype=torch.int32, device=dev)
+    q_got = ops.rope_kv_append(None, c, s, slots, None, kv, layer, Hq, partial=part, bias=bias, kv_len=kv_len)
+    x = x_lin.view(1, Hq + 2 * Hkv, D)
+    cf, sf = c.float().repeat(1, 2)[:, None, :], s.float().repeat(1, 2)[:, None, :]
+    rot = torch.cat([-x[..., 64:], x[..., :64]], -1)
+    emb = rb(rb(x * cf) + rb(rot * sf))
+    assert torch.equal(q_got.float().view(1, Hq, D), emb[:, :Hq]), "decode-path rope (fp32 slabs + bias)"
+    K = torch.cat(k_all + [emb[:, Hq:Hq + Hkv]]); V = torch.cat(v_all + [x[:, Hq + Hkv:]])
+    ref = rb(_ref_attn_causal(emb[:, :Hq], K, V, past))
+    for nsplit in (1, 2, 5):
+        got = ops.attn_decode(q_got, kv, layer, slots, kv_len, Hq, nsplit)
+        _check_attn(got.view(1, Hq, D), ref, f"attn_decode[Hq{Hq},nsplit{nsplit}]")
+
+
+def test_attention_masks_garbage_beyond_length(dev):
+    """Keys past the valid length (stale cache contents) must not leak into the result."""
+    from livecc_amd import ops
+    Hq, Hkv, D, S = 2, 1, 128, 40
+    kv = ops.KvArena(1, 1, Hkv, 128, dev)
+    kv.buf.fill_(1e4)   # finite garbage everywhere
+    qkv = _rand((S, (Hq + 2 * Hkv) * D), dev, 1.0, 3)
+    pos = torch.arange(S).int()
+    pos3 = torch.stack([pos, pos, pos])
+    _, _, inv = _hf_mrope_ref(pos3)
+    c, s = ops.mrope_table(pos3.to(dev), inv.to(dev), [16, 24, 24])
+    q = ops.rope_kv_append(qkv, c, s, torch.zeros(S, dtype=torch.int32, device=dev), pos.to(dev), kv, 0, Hq)
+    got = ops.attn_prefill(q, kv, 0, [(0, S, 0)], Hq)
+    K = kv.k_view(0, 0)[:, :S].float().transpose(0, 1); V = kv.v_view(0, 0)[:, :S].float().transpose(0, 1)
+    ref = _ref_attn_causal(q.float().view(S, Hq, D), K, V, 0)
+    _check_attn(got.view(S, Hq, D), rb(ref), "attn_garbage_tail")
+
+
+# ---------------------------------------------------------------------------------------------
+# sampler
+# ---------------------------------------------------------------------------------------------
+def test_sampler_matches_hf_processors(dev):
+    from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
+    from livecc_amd import ops
+    from oracle.hf_oracle import ThresholdLogitsProcessor
+    V, B = 2048, 3
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(B, V, generator=g) * 2).to(torch.bfloat16)
+    hist = [torch.randint(0, V, (50,), generator=g) for _ in range(B)]
+    seen_np = np.zeros((B, V // 32), dtype=np.uint32)
+    for b in range(B):
+        for t in hist[b].tolist():
+            seen_np[b, t >> 5] |= np.uint32(1 << (t & 31))
+    seen = torch.from_numpy(seen_np.view(np.int32))
+    slots = torch.arange(B, dtype=torch.int32)
+    for pen, thr, eos_sup in [(1.0, None, False), (1.15, None, False), (1.05, 0.002, False), (1.05, None, True)]:
+        thr_tok = int(logits[0].float().argmax())          # make the threshold token matter for stream 0
+        eos = int(logits[1].float().argmax())              # and EOS suppression for stream 1
+        tok, scores = ops.sample_greedy(logits.to(dev), seen.to(dev), slots.to(dev), pen, thr_tok if thr is not None else -1,
+                                        thr, eos if eos_sup else -1, eos_sup, want_scores=True)
+        for b in range(B):
+            sc = logits[b:b + 1].float().clone()
+            sc = RepetitionPenaltyLogitsProcessor(pen)(hist[b].view(1, -1), sc) if pen != 1.0 else sc
+            if eos_sup:
+                sc[:, eos] = -float("inf")
+            if thr is not None:
+                sc = ThresholdLogitsProcessor(thr_tok, thr, 0.0)(hist[b].view(1, -1), sc)
+            assert int(tok[b]) == int(sc.argmax()), f"token mismatch pen={pen} thr={thr} stream {b}"
+            assert torch.allclose(scores[b].cpu(), sc[0], rtol=1e-6, atol=1e-6), "processed scores"
