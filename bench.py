@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- streaming commentary throughput of the LiveCC hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): LiveCC-7B shapes, one video stream per GPU replayed back-to-back, 2 fps,
+60 frames at 392x728 (28x52 patch grid): one 6-frame turn + 27 two-frame turns, 16 greedy tokens per turn
+(min_new_tokens = max_new_tokens, repetition_penalty 1.05) -> 448 commentary tokens, KV grows to ~12k.
+Synthetic frames / prompt ids, random weights of the real architecture (no network: SURVEY 8d).
+
+A "step" = one complete replay of the stream(s) on every rank (frames already resident in HBM).  One JSON line on
+rank 0; `value` = commentary tokens/s summed over all streams of all GPUs.  `roofline` = the dominant kernel (decode
+gate/up weight-streaming GEMV, HBM-bound) timed live with HIP events on its launch stream inside the timed region;
+`cpu_baseline` = the HF CPU oracle (the reference's arithmetic) at the same 7B shapes on the host cores, one
+streaming turn (bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="livecc-7b")
+    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--height", type=int, default=392)
+    ap.add_argument("--width", type=int, default=728)
+    ap.add_argument("--streams-per-gpu", type=int, default=1)
+    ap.add_argument("--max-new-tokens", type=int, default=16)
+    ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
+    ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
+    return ap.parse_args()
+
+
+def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod):
+    """One back-to-back replay of all local streams, batched turn by turn.  Returns (tokens, frames)."""
+    n = len(frames_list)
+    builders = [protocol.TurnBuilder(cfg, seed=s) for s in builders_seed]
+    states = [None] * n
+    past = [None] * n
+    tokens = 0
+    nframes = frames_list[0].shape[0]
+    for ti, (a, b) in enumerate(protocol.split_clip(nframes)):
+        reqs = []
+        for i in range(n):
+            clip = frames_list[i][a:b]
+            grid = protocol.grid_of(clip.shape[0], clip.shape[1], clip.shape[2], cfg)
+            new = builders[i].turn_ids(ti, protocol.num_video_tokens(grid, cfg))
+            ids = new if past[i] is None else np.concatenate([past[i], new])
+            reqs.append(dict(input_ids=torch_mod.from_numpy(ids), frames=clip, frames_layout="THWC", state=states[i]))
+        outs = model.generate_batch(reqs, repetition_penalty=1.05, max_new_tokens=max_new, force_length=True)
+        for i, o in enumerate(outs):
+            states[i] = o.past_key_values
+            seq = o.sequences[0].cpu().numpy()
+            past[i] = seq[:-1]
+            tokens += max_new
+    for s in states:
+        s.release()
+    return tokens, n * nframes
+
+
+def cpu_baseline(cfg_name, args):
+    """The reference's CPU path (HF Qwen2VLForConditionalGeneration, bf16, SDPA) on the host cores: one streaming
+    turn = ViT over 2 frames + ~390-token prefill + 16 greedy tokens.  Weights are filled by tiling a small random
+    block (throughput is data independent; initialising 8.3 B parameters with a CPU RNG would take minutes)."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from oracle import hf_oracle as O
+    from transformers import Qwen2VLForConditionalGeneration
+    cfg = get_config(cfg_name)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    with torch.device("meta"):
+        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=torch.bfloat16)
+    m = m.to_empty(device="cpu")
+    blk = (torch.randn(1 << 22) * 0.02).to(torch.bfloat16)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            flat = p.data.view(-1)
+            if p.dim() == 1:
+                flat.fill_(1.0 if name.endswith("weight") else 0.0)
+                continue
+            for o in range(0, flat.numel(), blk.numel()):
+                k = min(blk.numel(), flat.numel() - o)
+                flat[o:o + k].copy_(blk[:k])
+        for name, buf in m.named_buffers():
+            if "inv_freq" in name:
+                dim = buf.numel() * 2
+                theta = 10000.0 if "visual" in name else cfg.rope_theta
+                buf.copy_(1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float) / dim)))
+    m.eval()
+    m.generation_config.do_sample = False
+    m.generation_config.top_k = m.generation_config.top_p = m.generation_config.temperature = None
+    build_s = time.perf_counter() - t0
+    frames = torch.from_numpy(protocol.synth_frames(2, args.height, args.width, seed=1234, layout="TCHW"))
+    pv, grid = O.patchify_normalize_ref(frames, cfg)
+    ids = protocol.TurnBuilder(cfg, seed=1234).turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    st = O.OracleStream(m, cfg)
+    t0 = time.perf_counter()
+    st.turn(ids, pv, grid, max_new_tokens=args.max_new_tokens, repetition_penalty=1.05)
+    dt = time.perf_counter() - t0
+    return dict(value=round(args.max_new_tokens / dt, 4), unit="tokens/s/stream", cores=cores, kind="reference",
+                frames_per_s=round(2 / dt, 4), seconds=round(dt, 2), build_seconds=round(build_s, 1),
+                sample=f"HF transformers CPU path (bf16, sdpa) at {cfg.name} shapes: one streaming turn = ViT on 2 frames "
+                       f"({pv.shape[0]} patches) + {len(ids)}-token prefill + {args.max_new_tokens} greedy tokens, "
+                       f"{torch.get_num_threads()} threads")
+
+
+def main():
+    args = parse()
+    from livecc_amd import distributed as D, protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.weights import WeightArena
+    rank, local, world = D.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    cfg = get_config(args.config)
+    spg = args.streams_per_gpu
+
+    # weights: generated on rank 0, broadcast once over RCCL/xGMI -- no collective afterwards
+    arena = WeightArena(cfg, dev)
+    if rank == 0:
+        arena.fill_random(seed=0)
+    bcast_s = D.broadcast_weights(arena.flat, src=0)
+    n_tok_turn = (args.height // 28) * (args.width // 28)
+    kv_need = 32 * ((args.frames // 2 + 2) * (n_tok_turn + 64) // 32 + 4)
+    model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
+                                           max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
+                                           max_history=max(16, args.max_new_tokens))
+    frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + rank * spg + i)).to(dev)
+              for i in range(spg)]
+    seeds = [1234 + rank * spg + i for i in range(spg)]
+
+    for _ in range(args.warmup):
+        replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
+    model.engine.profile(True, 8192)
+    D.barrier(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    toks = nfr = 0
+    for _ in range(args.steps):
+        a, b = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
+        toks += a
+        nfr += b
+    torch.cuda.synchronize(dev)
+    D.barrier(dev)
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    model.engine.profile(False)
+    total_tokens = D.sum_over_ranks(float(toks), dev)
+    total_frames = D.sum_over_ranks(float(nfr), dev)
+    if rank != 0:
+        return
+    ms = model.engine.profile_read(8192)
+    # dominant kernel: gemv_skinny_kernel<2,2> (gate/up + SwiGLU), algorithmic bytes per launch:
+    # weights 2I*H*2 + activations in M*H*2 + out M*I*2, M = streams per GPU
+    I, H = cfg.intermediate_size, cfg.hidden_size
+    alg_bytes = 2 * I * H * 2 + spg * H * 2 + spg * I * 2
+    roof = None
+    if len(ms):
+        avg_ms = float(np.mean(ms))
+        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("gemv_gate_up_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = dict(bound="hbm", kernel="gemv_skinny_kernel<2,2> (decode gate/up + SwiGLU)", achieved=round(ach, 1), peak=8000.0,
+                    unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic, avg_launch_us=round(avg_ms * 1e3, 2),
+                    launches_timed=int(len(ms)), algorithmic_bytes_per_launch=alg_bytes)
+    cpu = None
+    want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)
+    if want_cpu:
+        try:
+            cpu = cpu_baseline(args.cpu_config or args.config, args)
+        except Exception as e:  # the baseline must never take the bench line down
+            cpu = dict(value=None, unit="tokens/s/stream", cores=os.cpu_count(), kind="reference", sample=f"failed: {e!r}")
+    n_streams = world * spg
+    out = {
+        "metric": "commentary tokens/s (all streams) + frames/s ingested, LiveCC-7B streaming", "value": round(total_tokens / dt, 3),
+        "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic frames + synthetic prompt ids, random weights of the real architecture",
+        "config": {"workload": f"{cfg.name} single stream per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
+                               f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05 (BASELINE.json configs[1])",
+                   "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)"},
+        "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
+        "weight_broadcast_s": round(bcast_s, 3), "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

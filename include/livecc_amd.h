@@ -138,6 +138,11 @@ int lcc_engine_bind_kv(lcc_engine* e, int slot, void* kv_dev, size_t bytes);   /
 int lcc_engine_set_weight(lcc_engine* e, const char* name, const void* dev, int64_t numel);
 int lcc_engine_weights_ready(const lcc_engine* e, char* missing, int missing_len);
 
+/* live timing of the dominant kernel (the decode gate/up weight-streaming GEMV): hipEvent pairs recorded on the launch
+ * stream around up to max_samples launches; read back (blocking) as milliseconds per launch. */
+int lcc_engine_profile(lcc_engine* e, int enable, int max_samples);
+int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, int* n_out);
+
 /* stream (slot) state */
 int lcc_slot_reset(lcc_engine* e, int slot, void* stream);                 /* new video stream: empty KV, empty history */
 int lcc_slot_set_length(lcc_engine* e, int slot, int kv_len, int next_pos, void* stream);  /* truncate after EOS */

@@ -118,6 +118,9 @@ struct lcc_engine {
   int32_t *d_kv_len = nullptr, *d_pos = nullptr, *d_hist_col = nullptr, *d_cur_tok = nullptr, *d_done = nullptr, *d_history = nullptr;
   uint32_t* d_seen = nullptr;
   bf16_t** d_kv_base = nullptr;
+  // optional live timing of the dominant kernel (decode gate/up GEMV): hipEvent pairs on the launch stream
+  std::vector<hipEvent_t> prof_ev;   // 2 * capacity
+  int prof_n = 0; bool prof_on = false;
   // host mirrors
   std::vector<int> h_kv_len, h_pos;
   std::vector<void*> h_kv_base;
@@ -177,7 +180,31 @@ extern "C" lcc_engine* lcc_engine_create(const lcc_model_config* cfg, const lcc_
 extern "C" void lcc_engine_destroy(lcc_engine* e) {
   if (!e) return;
   for (int i = 0; i < META_RING; ++i) if (e->meta_ev[i]) (void)hipEventDestroy(e->meta_ev[i]);
+  for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   delete e;
+}
+extern "C" int lcc_engine_profile(lcc_engine* e, int enable, int max_samples) {
+  if (!e) return fail(LCC_ERR_ARG, "null engine");
+  if (enable) {
+    while ((int)e->prof_ev.size() < 2 * max_samples) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      e->prof_ev.push_back(ev);
+    }
+    e->prof_n = 0;
+  }
+  e->prof_on = enable != 0;
+  return 0;
+}
+extern "C" int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, int* n_out) {
+  if (!e || !ms_out || !n_out) return fail(LCC_ERR_ARG, "null argument");
+  const int n = std::min(e->prof_n, max_n);
+  for (int i = 0; i < n; ++i) {
+    HIP_TRY(hipEventSynchronize(e->prof_ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms_out[i], e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+  }
+  *n_out = n;
+  return 0;
 }
 extern "C" size_t lcc_engine_workspace_bytes(const lcc_engine* e) { return std::max(e->llm_ws_bytes(), e->vit_ws_bytes()); }
 extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
@@ -519,7 +546,10 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     // SwiGLU MLP
     g = GemmArgs(); g.A = b.xn; g.lda = H; g.W = L.gate_up_w; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
     g.epilogue = LCC_EPI_SWIGLU;
+    const bool prof = e->prof_on && cx.skinny && cx.tok_pos == nullptr && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
+    if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
     LCC_TRY(gemm_bf16(g, st));
+    if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
     g = GemmArgs(); g.A = b.act; g.lda = I; g.W = L.down_w; g.ldw = I; g.M = S; g.N = H; g.K = I;
     if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_dn;

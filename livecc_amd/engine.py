@@ -217,6 +217,15 @@ class Engine:
         _lib.check(self.lib.lcc_llm_decode(self.h, len(slots), slots_a.ctypes.data, n_steps, first_step_index, C.byref(sp),
                                            self._stream()), "lcc_llm_decode")
 
+    def profile(self, enable: bool, max_samples: int = 4096) -> None:
+        _lib.check(self.lib.lcc_engine_profile(self.h, 1 if enable else 0, max_samples), "lcc_engine_profile")
+
+    def profile_read(self, max_n: int = 4096) -> np.ndarray:
+        buf = np.zeros(max_n, dtype=np.float32)
+        n = C.c_int()
+        _lib.check(self.lib.lcc_engine_profile_read(self.h, buf.ctypes.data, max_n, C.byref(n)), "lcc_engine_profile_read")
+        return buf[:n.value]
+
     def read_tokens(self, slot: int, max_n: int) -> List[int]:
         buf = np.zeros(max(max_n, 1), dtype=np.int32)
         n = C.c_int()

@@ -21,10 +21,14 @@ def bf16_ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def assert_bf16_close(got: torch.Tensor, ref: torch.Tensor, name: str, max_ulp: float = 1.0, max_frac: float = 2e-3,
-                      atol: float = 0.0):
+                      atol=0.0):
     """Two bf16 tensors computed with fp32 accumulation in different orders agree except for rare 1-ulp rounding
-    flips: every element within `max_ulp` bf16 ulps (or atol), and at most `max_frac` of the elements differ at all."""
+    flips: every element within `max_ulp` bf16 ulps (or within `atol`, a float or a per-element tensor -- for dot
+    products the fp32 summation-order noise is ~eps32 * sum|a_k b_k|, which exceeds one bf16 ulp of the result when
+    the sum cancels to nearly zero), and at most `max_frac` of the elements differ at all."""
     got, ref = got.float().cpu(), ref.float().cpu()
+    if torch.is_tensor(atol):
+        atol = atol.float().cpu()
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(got).all(), f"{name}: non-finite values"
     d = bf16_ulp_diff(got, ref)
