@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
+    ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock budget of the CPU baseline leg, seconds")
     return ap.parse_args()
 
 
@@ -68,52 +69,64 @@ def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod)
     return tokens, n * nframes
 
 
-def cpu_baseline(cfg_name, args):
-    """The reference's CPU path (HF Qwen2VLForConditionalGeneration, bf16, SDPA) on the host cores: one streaming
-    turn = ViT over 2 frames + ~390-token prefill + 16 greedy tokens.  Weights are filled by tiling a small random
-    block (throughput is data independent; initialising 8.3 B parameters with a CPU RNG would take minutes)."""
-    from livecc_amd import protocol
-    from livecc_amd.config import get_config
-    from oracle import hf_oracle as O
-    from transformers import Qwen2VLForConditionalGeneration
-    cfg = get_config(cfg_name)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    with torch.device("meta"):
-        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=torch.bfloat16)
-    m = m.to_empty(device="cpu")
-    blk = (torch.randn(1 << 22) * 0.02).to(torch.bfloat16)
-    with torch.no_grad():
-        for name, p in m.named_parameters():
-            flat = p.data.view(-1)
-            if p.dim() == 1:
-                flat.fill_(1.0 if name.endswith("weight") else 0.0)
-                continue
-            for o in range(0, flat.numel(), blk.numel()):
-                k = min(blk.numel(), flat.numel() - o)
-                flat[o:o + k].copy_(blk[:k])
-        for name, buf in m.named_buffers():
-            if "inv_freq" in name:
-                dim = buf.numel() * 2
-                theta = 10000.0 if "visual" in name else cfg.rope_theta
-                buf.copy_(1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float) / dim)))
-    m.eval()
-    m.generation_config.do_sample = False
-    m.generation_config.top_k = m.generation_config.top_p = m.generation_config.temperature = None
-    build_s = time.perf_counter() - t0
-    frames = torch.from_numpy(protocol.synth_frames(2, args.height, args.width, seed=1234, layout="TCHW"))
-    pv, grid = O.patchify_normalize_ref(frames, cfg)
-    ids = protocol.TurnBuilder(cfg, seed=1234).turn_ids(0, protocol.num_video_tokens(grid, cfg))
-    st = O.OracleStream(m, cfg)
-    t0 = time.perf_counter()
-    st.turn(ids, pv, grid, max_new_tokens=args.max_new_tokens, repetition_penalty=1.05)
-    dt = time.perf_counter() - t0
-    return dict(value=round(args.max_new_tokens / dt, 4), unit="tokens/s/stream", cores=cores, kind="reference",
-                frames_per_s=round(2 / dt, 4), seconds=round(dt, 2), build_seconds=round(build_s, 1),
-                sample=f"HF transformers CPU path (bf16, sdpa) at {cfg.name} shapes: one streaming turn = ViT on 2 frames "
-                       f"({pv.shape[0]} patches) + {len(ids)}-token prefill + {args.max_new_tokens} greedy tokens, "
-                       f"{torch.get_num_threads()} threads")
+def cpu_baseline(cfg_name, args, budget_s=240.0):
+    """The reference's CPU path (HF generate, bf16, SDPA) on the host cores, one streaming turn at `cfg_name` shapes, run
+    by oracle/cpu_baseline.py in a subprocess under a wall-clock budget.  The child reports every generated token, so a
+    run cut by the budget still yields measured prefill time and decode rate (then the 16-token turn is extrapolated
+    and the `sample` string says so)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", cfg_name, "--height", str(args.height),
+           "--width", str(args.width), "--max-new-tokens", str(args.max_new_tokens)]
+    t_start = time.perf_counter()
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    ev = []
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(p.stdout, selectors.EVENT_READ)
+    cut = False
+    while True:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left <= 0:
+            cut = True
+            break
+        if not sel.select(timeout=min(left, 5.0)):
+            if p.poll() is not None:
+                break
+            continue
+        line = p.stdout.readline()
+        if not line:
+            break
+        try:
+            ev.append(json.loads(line))
+        except ValueError:
+            pass
+        if ev and ev[-1].get("event") == "done":
+            break
+    if p.poll() is None:
+        p.kill()          # exactly the child we started
+    p.wait()
+    info = next((e for e in ev if e["event"] == "start"), {})
+    inputs = next((e for e in ev if e["event"] == "inputs"), {})
+    built = next((e for e in ev if e["event"] == "built"), None)
+    toks = [e for e in ev if e["event"] == "token"]
+    done = next((e for e in ev if e["event"] == "done"), None)
+    n = args.max_new_tokens
+    base = dict(unit="tokens/s/stream", cores=info.get("cores", os.cpu_count()), kind="reference", cpu=info.get("cpu", ""),
+                build_seconds=built["seconds"] if built else None)
+    what = (f"HF transformers CPU path (bf16, sdpa, {info.get('threads', '?')} threads) at {cfg_name} shapes: one streaming turn = "
+            f"ViT on 2 frames ({inputs.get('patches', '?')} patches) + {inputs.get('prompt_tokens', '?')}-token prefill + {n} greedy tokens")
+    if done is not None:
+        dt = done["t"]
+        return dict(base, value=round(n / dt, 4), frames_per_s=round(2 / dt, 4), seconds=dt, sample=what)
+    if len(toks) >= 2:
+        prefill = toks[0]["t"]
+        per_tok = (toks[-1]["t"] - toks[0]["t"]) / (len(toks) - 1)
+        dt = prefill + per_tok * n
+        return dict(base, value=round(n / dt, 4), frames_per_s=round(2 / dt, 4), seconds=round(dt, 2),
+                    sample=what + f"; cut by the {budget_s:.0f}s budget after {len(toks)} tokens: prefill {prefill:.1f}s measured, "
+                                  f"decode {per_tok:.2f}s/token measured, turn time extrapolated")
+    return dict(base, value=None, sample=what + f"; nothing measurable inside the {budget_s:.0f}s budget "
+                                                f"(built={built is not None}, tokens={len(toks)}, cut={cut})")
 
 
 def main():
@@ -185,7 +198,11 @@ def main():
     want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)
     if want_cpu:
         try:
-            cpu = cpu_baseline(args.cpu_config or args.config, args)
+            torch.cuda.empty_cache()
+            cpu = cpu_baseline(args.cpu_config or args.config, args, args.cpu_budget)
+            if cpu.get("value") is None and (args.cpu_config or args.config) != "qwen2vl-2b":
+                # BASELINE.json configs[0]: the reference's own CPU-runnable case is Qwen2-VL-2B
+                cpu = cpu_baseline("qwen2vl-2b", args, args.cpu_budget / 2)
         except Exception as e:  # the baseline must never take the bench line down
             cpu = dict(value=None, unit="tokens/s/stream", cores=os.cpu_count(), kind="reference", sample=f"failed: {e!r}")
     n_streams = world * spg

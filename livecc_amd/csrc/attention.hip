@@ -322,8 +322,10 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(
   const int G = n_q_heads / n_kv_heads, hk = hq / G, j = hq % G;
   const size_t slot0 = (((size_t)b * n_kv_heads + hk) * nsplit) * 16 + j;
   float M = -INFINITY;
+#pragma unroll 8
   for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(slot0 + (size_t)s * 16) * 2]);
   float num = 0.f, den = 0.f;
+#pragma unroll 8
   for (int s = 0; s < nsplit; ++s) {
     const size_t slot = slot0 + (size_t)s * 16;
     const float m = ws_ml[slot * 2], l = ws_ml[slot * 2 + 1];

@@ -164,12 +164,20 @@ __global__ __launch_bounds__(NW * 64) void add_rmsnorm_kernel(bf16_t* __restrict
         for (int e = 0; e < 4; ++e) { v[c][2 * e] = rbf(v[c][2 * e] + lo2f(d[e])); v[c][2 * e + 1] = rbf(v[c][2 * e + 1] + hi2f(d[e])); }
       } else if (DELTA == 2) {
         float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < nsplit; ++sp) {
-          const float* pp = dpart + ((size_t)sp * rows + row) * dim + ch * 8;
-          const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+        f32x4 pa[8], pb[8];  // all slabs are loaded before the first add: one L2 round trip instead of nsplit
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { d[e] += a[e]; d[4 + e] += b[e]; }
+        for (int sp = 0; sp < 8; ++sp) {
+          if (sp < nsplit) {
+            const float* pp = dpart + ((size_t)sp * rows + row) * dim + ch * 8;
+            pa[sp] = *reinterpret_cast<const f32x4*>(pp); pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
+          } else {
+            pa[sp] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[sp] = pa[sp];
+          }
         }
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp)   // slab order (adding +0.0 for absent slabs is exact)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { d[e] += pa[sp][e]; d[4 + e] += pb[sp][e]; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[c][e] = rbf(v[c][e] + rbf(d[e]));
       }
@@ -205,6 +213,7 @@ int add_rmsnorm_bf16(bf16_t* h, const bf16_t* delta_bf16, const float* delta_par
   if (rows <= 0) return 0;
   if ((dim & 7) || dim > 4 * 64 * 8 * 4) return LCC_ERR_SHAPE;
   if (delta_bf16 != nullptr && delta_partial != nullptr) return LCC_ERR_ARG;
+  if (delta_partial != nullptr && (nsplit < 1 || nsplit > 8)) return LCC_ERR_SHAPE;
   if (delta_partial != nullptr)
     add_rmsnorm_kernel<4, 4, 2><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, delta_partial, nsplit, rows, w, y, dim, eps);
   else if (delta_bf16 != nullptr)
@@ -340,12 +349,20 @@ LCC_DEVICE void load8(const bf16_t* qkv, const float* part, int nsplit, int S, c
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float* pp = part + ((size_t)sp * S + s) * ld + col;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+    f32x4 pa[8], pb[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    for (int sp = 0; sp < 8; ++sp) {
+      if (sp < nsplit) {
+        const float* pp = part + ((size_t)sp * S + s) * ld + col;
+        pa[sp] = *reinterpret_cast<const f32x4*>(pp); pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
+      } else {
+        pa[sp] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[sp] = pa[sp];
+      }
     }
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += pa[sp][e]; v[4 + e] += pb[sp][e]; }
     const u32x4 bq = ld16(bias + col);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[2 * e] = rbf(v[2 * e] + lo2f(bq[e])); v[2 * e + 1] = rbf(v[2 * e + 1] + hi2f(bq[e])); }
@@ -412,6 +429,7 @@ int rope_kv_append_bf16(const bf16_t* qkv_bf16, const float* qkv_partial, int ns
   const dim3 grid((unsigned)((n + 255) / 256));
   if (qkv_partial != nullptr) {
     if (bias == nullptr) return LCC_ERR_ARG;
+    if (nsplit < 1 || nsplit > 8) return LCC_ERR_SHAPE;
     rope_kv_append_kernel<1><<<grid, dim3(256), 0, st>>>(nullptr, qkv_partial, nsplit, bias, cos, sin, tok_stream,
                                                          tok_pos, kv_len, kv_base, lay, layer, q_out, S, n_q_heads);
   } else {

@@ -15,6 +15,8 @@
 // Replaces: every nn.Linear / Conv3d of HF modeling_qwen2_vl.py on the path
 //   (PatchEmbed 251-274, VisionAttention.qkv/proj 349-350, VisionMlp 293-301, PatchMerger 277-290,
 //    Qwen2VLAttention q/k/v/o_proj 501-504, Qwen2MLP 453-466, lm_head 1218/1323).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -192,20 +194,26 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMV-like kernel (M <= 16)
+// skinny GEMV-like kernel (M <= 16): HBM-bound weight streaming
 // ------------------------------------------------------------------------------------------------
-// One wave per block.  The wave owns NTILE*16 consecutive W rows and the K range [k_begin, k_end) of
-// split `blockIdx.y`.  Per 64-element step it issues, per tile, two 16-byte loads per lane that together
-// cover one full 128-byte line of each of the 16 rows, plus the matching x fragment (L2/L1 resident).
-// D'[n][m]: lane (m = l&15, g) ends with 4 consecutive n for activation row m.
-template <int NTILE, int MODE>  // MODE 0: fp32 partial slab out[split][M][N]; 1: bf16 out with bias/act; 2: swiglu bf16
-__global__ __launch_bounds__(64) void gemv_skinny_kernel(
+// Block = 4 waves.  The block owns NTILE*16 consecutive W rows and the 64-element K chunks [c_begin, c_end) of split
+// blockIdx.y; wave w takes chunks c_begin + w, + 4, ... (consecutive 128-byte lines of a row alternate between the waves
+// of one block, so a block streams 16 rows x 512 contiguous bytes per round).  W fragments go HBM -> VGPR -> MFMA
+// (no LDS: each byte is used once); per chunk and tile a lane issues two 16-byte loads (the two halves of one line of
+// its row) plus the matching x fragment (L2/L1 resident).  The four partial accumulators are reduced through LDS and
+// wave 0 runs the epilogue.  D'[n][m]: lane (m = l&15, g) ends with 4 consecutive n for activation row m.
+// ~16+ waves per CU x 8-16 KB in flight per wave keeps > 100 KB per CU outstanding, which HBM3E needs at 6+ TB/s.
+template <int NTILE, int MODE>  // MODE 0: fp32 partial slab out[split][M][N]; 1: bf16 out with bias; 2: swiglu bf16
+__global__ __launch_bounds__(256) void gemv_skinny_kernel(
     const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
-    const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int ksplit_len) {
-  const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int chunks_per_split) {
+  constexpr int NW = 4;
+  __shared__ f32x4 red[NW - 1][NTILE][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (NTILE * 16);
   const int split = blockIdx.y;
-  const int kb = split * ksplit_len, ke = min(K, kb + ksplit_len);
+  const int nchunk = (K + 63) >> 6;
+  const int cb = split * chunks_per_split, ce = min(nchunk, cb + chunks_per_split);
 
   const int xm = min(li, M - 1);
   const bf16_t* xp = X + (size_t)xm * ldx + g * 8;
@@ -216,19 +224,24 @@ __global__ __launch_bounds__(64) void gemv_skinny_kernel(
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
 
-  int k = kb;
-  constexpr int UNR = (NTILE == 1) ? 4 : 2;  // 64-element steps in flight
-  for (; k + 64 * UNR <= ke; k += 64 * UNR) {
+  constexpr int UNR = (NTILE == 1) ? 4 : 2;  // chunks in flight per wave
+  int c = cb + wave;
+  for (; c + (UNR - 1) * NW < ce; c += UNR * NW) {
     u32x4 wv[UNR][2][NTILE], xv[UNR][2];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u)
+    for (int u = 0; u < UNR; ++u) {
+      const int k = (c + u * NW) << 6;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        const bool ok = k + h * 32 < K;  // K % 32 == 0: only the very last half chunk can be absent
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + k + u * 64 + h * 32));
-        xv[u][h] = ld16(xp + k + u * 64 + h * 32);
+        for (int t = 0; t < NTILE; ++t)
+          wv[u][h][t] = ok ? __builtin_nontemporal_load((const u32x4*)(wp[t] + k + h * 32)) : zero4;
+        xv[u][h] = ok ? ld16(xp + k + h * 32) : zero4;
       }
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
@@ -236,13 +249,31 @@ __global__ __launch_bounds__(64) void gemv_skinny_kernel(
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h]), acc[t]);
   }
-  for (; k < ke; k += 32) {  // K % 32 == 0
+  for (; c < ce; c += NW) {
+    const int k = c << 6;
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      u32x4 wv = __builtin_nontemporal_load((const u32x4*)(wp[t] + k));
-      acc[t] = mfma16(as_bf16x8(wv), as_bf16x8(ld16(xp + k)), acc[t]);
+    for (int h = 0; h < 2; ++h) {
+      const bool ok = k + h * 32 < K;
+      const u32x4 xq = ok ? ld16(xp + k + h * 32) : zero4;
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        const u32x4 wq = ok ? __builtin_nontemporal_load((const u32x4*)(wp[t] + k + h * 32)) : zero4;
+        acc[t] = mfma16(as_bf16x8(wq), as_bf16x8(xq), acc[t]);
+      }
     }
   }
+
+  // cross-wave reduction
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) red[wave - 1][t][lane] = acc[t];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
 
   if (li >= M) return;
   if (MODE == 0) {
@@ -266,7 +297,7 @@ __global__ __launch_bounds__(64) void gemv_skinny_kernel(
       st8(o + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
     }
   } else {  // swiglu: tile 0 = 16 gate rows, tile 1 = the 16 matching up rows
-    static_assert(MODE != 2 || NTILE == 2, "swiglu needs the gate and up tile in one wave");
+    static_assert(MODE != 2 || NTILE == 2, "swiglu needs the gate and up tile in one block");
     bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
     const int oc = n0 / 2 + g * 4;
     if (n0 < N) {
@@ -302,13 +333,13 @@ int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st) {
   return 0;
 }
 
-// choose the number of K splits of a skinny GEMV so that ~>= 1536 waves are in flight, each wave keeps
-// >= 256 elements of K, and the fp32 slab traffic stays small (S <= 8)
+// number of inter-block K splits of a skinny GEMV: enough blocks (x4 waves) to keep >= ~16 waves per CU in flight,
+// every wave keeps >= ~3 64-element chunks, and the fp32 slab traffic stays small (S <= 8)
 int gemv_num_splits(int N, int K) {
-  const int tiles = (N + 15) / 16;
-  int s = 1;
-  while (s < 8 && tiles * s < 1536 && K / (s * 2) >= 256 && (K % (s * 2 * 32) == 0)) s *= 2;
-  return s;
+  const int tiles = (N + 15) / 16, nchunk = (K + 63) / 64;
+  int s = (1024 + tiles - 1) / tiles;
+  s = std::min(s, std::max(1, nchunk / 12));
+  return std::max(1, std::min(8, s));
 }
 
 int gemm_bf16(const GemmArgs& a, hipStream_t st) {
@@ -320,17 +351,18 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   const bool skinny = a.M <= 16 && (a.K % 32 == 0) && a.epilogue != EPI_QUICK_GELU &&
                       a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
   if (skinny) {
+    const int nchunk = (a.K + 63) / 64;
     if (a.epilogue == EPI_SWIGLU) {
-      gemv_skinny_kernel<2, 2><<<dim3((a.N + 31) / 32, 1), dim3(64), 0, st>>>(
-          a.A, a.lda, a.W, a.ldw, nullptr, a.C, a.ldc, a.M, a.N, a.K, a.K);
+      gemv_skinny_kernel<2, 2><<<dim3((a.N + 31) / 32, 1), dim3(256), 0, st>>>(
+          a.A, a.lda, a.W, a.ldw, nullptr, a.C, a.ldc, a.M, a.N, a.K, nchunk);
     } else if (a.partial != nullptr) {
       const int S = a.nsplit > 0 ? a.nsplit : 1;
-      if (a.K % (S * 32) != 0) return LCC_ERR_SHAPE;
-      gemv_skinny_kernel<1, 0><<<dim3((a.N + 15) / 16, S), dim3(64), 0, st>>>(
-          a.A, a.lda, a.W, a.ldw, nullptr, a.partial, a.N, a.M, a.N, a.K, a.K / S);
+      if (S > nchunk) return LCC_ERR_SHAPE;
+      gemv_skinny_kernel<1, 0><<<dim3((a.N + 15) / 16, S), dim3(256), 0, st>>>(
+          a.A, a.lda, a.W, a.ldw, nullptr, a.partial, a.N, a.M, a.N, a.K, (nchunk + S - 1) / S);
     } else {
-      gemv_skinny_kernel<1, 1><<<dim3((a.N + 15) / 16, 1), dim3(64), 0, st>>>(
-          a.A, a.lda, a.W, a.ldw, a.bias, a.C, a.ldc, a.M, a.N, a.K, a.K);
+      gemv_skinny_kernel<1, 1><<<dim3((a.N + 15) / 16, 1), dim3(256), 0, st>>>(
+          a.A, a.lda, a.W, a.ldw, a.bias, a.C, a.ldc, a.M, a.N, a.K, nchunk);
     }
     return 0;
   }
