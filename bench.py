@@ -126,7 +126,7 @@ def cpu_baseline(cfg_name, args, budget_s=240.0):
                     sample=what + f"; cut by the {budget_s:.0f}s budget after {len(toks)} tokens: prefill {prefill:.1f}s measured, "
                                   f"decode {per_tok:.2f}s/token measured, turn time extrapolated")
     return dict(base, value=None, sample=what + f"; nothing measurable inside the {budget_s:.0f}s budget "
-                                                f"(built={built is not None}, tokens={len(toks)}, cut={cut})")
+                                                f"(built={built is not None}, tokens={len(toks)}, cut={cut}, events={ev[-3:]})")
 
 
 def main():

@@ -40,6 +40,8 @@ def split_clip(num_frames: int, initialized: bool = False) -> List[Tuple[int, in
     (torch.split semantics: the last chunk may be shorter).
     """
     chunks, pos = [], 0
+    if num_frames <= 0:
+        return chunks
     if not initialized:
         stop = min(INITIAL_FPS_FRAMES, num_frames)
         chunks.append((0, stop))

@@ -22,6 +22,9 @@ def emit(**kw):
     print(json.dumps(kw), flush=True)
 
 
+T_IMPORT = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="livecc-7b")
@@ -36,7 +39,7 @@ def main():
     from oracle import hf_oracle as O
     cfg = get_config(a.config)
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    emit(event="imported", seconds=round(time.perf_counter() - T_IMPORT, 2))
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -50,7 +53,9 @@ def main():
     t0 = time.perf_counter()
     with torch.device("meta"):
         m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=torch.bfloat16)
+    emit(event="meta_model", seconds=round(time.perf_counter() - t0, 2))
     m = m.to_empty(device="cpu")
+    emit(event="allocated", seconds=round(time.perf_counter() - t0, 2))
     blk = (torch.randn(1 << 22) * 0.02).to(torch.bfloat16)
     with torch.no_grad():
         for name, p in m.named_parameters():

@@ -1,0 +1,60 @@
+"""ORACLE / TEST INFRASTRUCTURE: generates tests/golden/*.npz from the HF CPU oracle (run in the build container):
+
+    python oracle/make_golden.py
+
+The reference holds no golden vectors for this path, so these fixtures pin the oracle's behaviour at the time
+of generation (transformers 5.15.0, torch 2.10.0): a 3-turn streaming replay at `tiny` shapes with seeded weights,
+frames and prompt ids.  Stored: turn ids, grids, generated tokens, raw logits (fp32 oracle and bf16 oracle), ViT features,
+first-turn position ids / rope_delta.  tests/test_oracle.py re-runs the oracle against them (CPU), tests/test_gpu_golden.py
+checks the HIP path against them (GPU box, no oracle import needed for the comparison itself).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from livecc_amd import protocol  # noqa: E402
+from livecc_amd.config import tiny  # noqa: E402
+from oracle import hf_oracle as O  # noqa: E402
+
+SEED_W, SEED_IN, INIT_SCALE = 0, 1234, 2.0
+FRAMES, H, W, MAX_NEW, PENALTY = 10, 56, 84, 8, 1.05
+
+
+def generate():
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    cfg = tiny()
+    hf16 = O.build_hf_model(cfg, torch.bfloat16, SEED_W, INIT_SCALE)
+    hf32 = O.build_hf_model(cfg, torch.float32, SEED_W, INIT_SCALE)
+    frames = torch.from_numpy(protocol.synth_frames(FRAMES, H, W, seed=SEED_IN, layout="TCHW"))
+    res16 = O.replay_stream(hf16, cfg, frames, protocol.TurnBuilder(cfg, seed=SEED_IN), MAX_NEW, PENALTY, max_turns=3)
+    # fp32 oracle teacher-forced along the bf16 oracle's tokens (identical histories)
+    s32 = O.OracleStream(hf32, cfg)
+    out = dict(n_turns=np.int64(len(res16)))
+    for ti, (r, (a, b)) in enumerate(zip(res16, protocol.split_clip(FRAMES))):
+        pv, grid = O.patchify_normalize_ref(frames[a:b], cfg)
+        r32 = s32.turn(r["turn_ids"], pv, grid, max_new_tokens=MAX_NEW, repetition_penalty=PENALTY, teacher_tokens=r["new_tokens"])
+        out[f"t{ti}_ids"] = np.asarray(r["turn_ids"], dtype=np.int64)
+        out[f"t{ti}_grid"] = np.asarray(grid, dtype=np.int64)
+        out[f"t{ti}_tokens"] = np.asarray(r["new_tokens"], dtype=np.int64)
+        out[f"t{ti}_logits_bf16"] = torch.stack(r["logits"]).numpy().astype(np.float32)
+        out[f"t{ti}_logits_fp32"] = torch.stack(r32["logits"]).numpy().astype(np.float32)
+        out[f"t{ti}_vit_bf16"] = O.vit_forward_ref(hf16, pv, grid).float().numpy()
+        out[f"t{ti}_vit_fp32"] = O.vit_forward_ref(hf32, pv, grid).float().numpy()
+    pos, delta = protocol.rope_index_first_turn(res16[0]["turn_ids"], [res16[0]["grid"]], cfg)
+    out["t0_pos3"], out["rope_delta"] = pos, np.int64(delta)
+    out["meta"] = np.asarray([SEED_W, SEED_IN, FRAMES, H, W, MAX_NEW], dtype=np.int64)
+    return out
+
+
+if __name__ == "__main__":
+    o = generate()
+    path = os.path.join(ROOT, "tests", "golden", "stream_tiny.npz")
+    np.savez_compressed(path, **o)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+    for ti in range(int(o["n_turns"])):
+        print(ti, o[f"t{ti}_grid"].tolist(), o[f"t{ti}_tokens"].tolist())

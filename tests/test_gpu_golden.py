@@ -1,0 +1,63 @@
+"""-m gpu: the HIP path against the COMMITTED golden fixture (tests/golden/stream_tiny.npz, produced by oracle/make_golden.py
+from the HF CPU oracle in the build container).  Same weights (seeded HF init), frames and ids; the fixture's tokens are the
+bf16 oracle's free-running greedy tokens, so this also checks free-running token agreement, not only teacher-forced logits."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import record
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream_tiny.npz")
+
+
+def test_native_stream_against_golden_fixture(dev):
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O
+    g = np.load(GOLDEN)
+    cfg = tiny()
+    seed_w, seed_in, frames_n, H, W, max_new = (int(x) for x in g["meta"])
+    hf16 = O.build_hf_model(cfg, torch.bfloat16, seed_w, 2.0)       # weights only; the oracle is not run here
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=2048, max_new_rows=1024,
+                                                          max_patches=4096, max_history=16)
+    frames = torch.from_numpy(protocol.synth_frames(frames_n, H, W, seed=seed_in, layout="TCHW"))
+    state, past = None, None
+    agree = total = 0
+    worst = 0.0
+    for ti, (a, b) in enumerate(protocol.split_clip(frames_n)[:int(g["n_turns"])]):
+        new = g[f"t{ti}_ids"]
+        ids = new if past is None else np.concatenate([past, new])
+        r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames[a:b], past_key_values=state,
+                            repetition_penalty=1.05, max_new_tokens=max_new, min_new_tokens=max_new, output_logits=True)
+        state = r.past_key_values
+        toks = r.sequences[0, len(ids):].tolist()
+        gold = g[f"t{ti}_tokens"].tolist()
+        # ViT features of this chunk vs the fixture
+        vit = native.get_video_features(frames=frames[a:b].to(dev)).float().cpu().numpy()
+        v32, v16 = g[f"t{ti}_vit_fp32"], g[f"t{ti}_vit_bf16"]
+        assert np.abs(vit - v32).max() <= 1.5 * np.abs(v16 - v32).max() + 1e-3 * np.abs(v32).max()
+        # logits are comparable step by step as long as the histories agree
+        lg = r.logits.float().cpu().numpy()
+        l16, l32 = g[f"t{ti}_logits_bf16"], g[f"t{ti}_logits_fp32"]
+        for k in range(max_new):
+            total += 1
+            if toks[:k] != gold[:k]:
+                break
+            scale = np.abs(l32[k]).max()
+            d = np.abs(lg[k] - l16[k]).max()
+            worst = max(worst, d / scale)
+            assert d <= 6e-2 * scale, f"turn {ti} step {k}: {d} vs scale {scale}"
+            assert np.abs(lg[k] - l32[k]).max() <= 1.5 * np.abs(l16[k] - l32[k]).max() + (1e-3 + 2.0 ** -7) * scale
+            agree += int(toks[k] == gold[k])
+        # continue along the GOLDEN history so that later turns stay comparable
+        past = np.concatenate([ids, np.asarray(gold[:-1], dtype=np.int64)])
+        if toks != gold:
+            state.release()
+            state = None
+            break
+    record("golden_stream_tiny", dict(agree=agree, total=total, worst_rel_dlogit=worst))
+    assert agree >= 0.8 * total, f"only {agree}/{total} free-running greedy tokens equal the golden oracle tokens"

@@ -46,14 +46,17 @@ def _ref_linear(x, w, bias=None, epi=0, residual=None, with_atol=False):
     atol = noise
     if epi == 1:
         t = rb(1.702 * y)
-        atol = noise + 2.0 ** -7 * y.abs() * 1.5
+        pre = y.abs()
         y = rb(y * rb(torch.sigmoid(t)))
+        atol = noise + 2.0 ** -7 * pre * 2.0 + 2.0 ** -7 * y.abs()
     elif epi == 2:
-        atol = noise + 2.0 ** -7 * y.abs() * 1.5
+        pre = y.abs()
         y = rb(torch.nn.functional.gelu(y))
+        atol = noise + 2.0 ** -7 * pre * 2.0 + 2.0 ** -7 * y.abs()
     elif epi == 3:
-        atol = noise + 2.0 ** -7 * y.abs()
+        pre = y.abs()
         y = rb(y + residual.float())
+        atol = noise + 2.0 ** -7 * pre * 1.5 + 2.0 ** -7 * y.abs()
     return (y, atol) if with_atol else y
 
 

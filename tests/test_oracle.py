@@ -1,0 +1,81 @@
+"""Pins the oracle (no GPU): the numpy/torch restatement of the HF video preprocessing against HF's own `patchify` source,
+and the oracle's streaming replay against the committed golden fixture."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from livecc_amd import protocol
+from livecc_amd.config import tiny
+from oracle import hf_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream_tiny.npz")
+
+
+def _hf_patchify():
+    """HF's Qwen2VLVideoProcessor.patchify, executed from its source file without importing the module (the module needs
+    torchvision, which is not installed): HF models/qwen2_vl/video_processing_qwen2_vl.py:236-274."""
+    import transformers
+    path = os.path.join(os.path.dirname(transformers.__file__), "models", "qwen2_vl", "video_processing_qwen2_vl.py")
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "patchify")
+    fn.returns = None
+    for a in fn.args.args:
+        a.annotation = None
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch}
+    exec(compile(ast.fix_missing_locations(mod), path, "exec"), ns)
+    return ns["patchify"]
+
+
+@pytest.mark.parametrize("T,H,W", [(2, 56, 84), (6, 28, 56), (3, 56, 56)])
+def test_patchify_restatement_matches_hf_source(T, H, W):
+    cfg = tiny()
+    f = torch.from_numpy(protocol.synth_frames(T, H, W, seed=2, layout="TCHW"))
+    mine, grid = O.patchify_normalize_ref(f, cfg)
+    mean, std = O.fused_mean_std()
+    x = (f.float() - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)        # torchvision normalize: sub_ then div_
+    flat, gt, gh, gw = _hf_patchify()(None, x.unsqueeze(0), cfg.patch_size, cfg.spatial_merge_size, cfg.temporal_patch_size)
+    assert (gt, gh, gw) == grid
+    assert torch.equal(mine, flat[0])
+
+
+def test_fused_mean_std_constants():
+    mean, std = O.fused_mean_std()
+    from livecc_amd.engine import fused_mean_std
+    m2, s2 = fused_mean_std()
+    assert np.array_equal(mean.numpy(), m2) and np.array_equal(std.numpy(), s2)
+    assert abs(mean[0].item() - 0.48145466 * 255) < 1e-4
+
+
+def test_oracle_reproduces_golden_fixture():
+    """Re-run the bf16 oracle on the fixture's inputs: same tokens (teacher-forced logits within bf16 noise across hosts)."""
+    g = np.load(GOLDEN)
+    cfg = tiny()
+    seed_w, seed_in, frames_n, H, W, max_new = (int(x) for x in g["meta"])
+    hf16 = O.build_hf_model(cfg, torch.bfloat16, seed_w, 2.0)
+    frames = torch.from_numpy(protocol.synth_frames(frames_n, H, W, seed=seed_in, layout="TCHW"))
+    st = O.OracleStream(hf16, cfg)
+    for ti, (a, b) in enumerate(protocol.split_clip(frames_n)[:int(g["n_turns"])]):
+        pv, grid = O.patchify_normalize_ref(frames[a:b], cfg)
+        assert list(grid) == g[f"t{ti}_grid"].tolist()
+        toks = g[f"t{ti}_tokens"].tolist()
+        r = st.turn(g[f"t{ti}_ids"], pv, grid, max_new_tokens=max_new, repetition_penalty=1.05, teacher_tokens=toks)
+        lg = torch.stack(r["logits"]).numpy()
+        ref = g[f"t{ti}_logits_bf16"]
+        assert np.abs(lg - ref).max() <= 0.05 * np.abs(ref).max()
+        own = [int(s.argmax()) for s in r["scores"]]
+        assert sum(int(x == y) for x, y in zip(own, toks)) >= len(toks) - 1
+    pos, delta = protocol.rope_index_first_turn(g["t0_ids"], [g["t0_grid"].tolist()], cfg)
+    assert np.array_equal(pos, g["t0_pos3"]) and delta == int(g["rope_delta"])
+
+
+def test_bf16_oracle_is_close_to_fp32_oracle_in_fixture():
+    """Quantifies the reference's own bf16 error (the scale every parity tolerance is expressed in)."""
+    g = np.load(GOLDEN)
+    for ti in range(int(g["n_turns"])):
+        a, b = g[f"t{ti}_logits_bf16"], g[f"t{ti}_logits_fp32"]
+        rel = np.abs(a - b).max() / np.abs(b).max()
+        assert 1e-4 < rel < 0.06, rel
