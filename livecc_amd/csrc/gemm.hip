@@ -22,6 +22,8 @@
 
 namespace lcc {
 
+__device__ unsigned int lcc_zero_page[64];  // 256 zero bytes: operand source of absent K chunks (address select, no branch)
+
 // ------------------------------------------------------------------------------------------------
 // tiled GEMM
 // ------------------------------------------------------------------------------------------------
@@ -80,14 +82,14 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[AI], rb[BI];
-  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page);
   auto gload = [&](int kt) {
     const int k = kt * BK + chunk * 8;
-    const bool ok = k < K;  // K % 8 == 0: a chunk is entirely inside or outside
+    const bool ok = k < K;  // K % 8 == 0: a chunk is entirely inside or outside (K tail: load zeros, by address select)
 #pragma unroll
-    for (int i = 0; i < AI; ++i) ra[i] = ok ? ld16(aptr[i] + kt * BK) : zero4;
+    for (int i = 0; i < AI; ++i) ra[i] = ld16(ok ? aptr[i] + kt * BK : zp);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) rb[i] = ok ? ld16(bptr[i] + kt * BK) : zero4;
+    for (int i = 0; i < BI; ++i) rb[i] = ld16(ok ? bptr[i] + kt * BK : zp);
   };
   auto sstore = [&](int buf) {
     u32x4* s = smem + buf * STAGE;
@@ -224,43 +226,45 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
-
-  constexpr int UNR = (NTILE == 1) ? 4 : 2;  // chunks in flight per wave
-  int c = cb + wave;
-  for (; c + (UNR - 1) * NW < ce; c += UNR * NW) {
-    u32x4 wv[UNR][2][NTILE], xv[UNR][2];
+  // two-stage software pipeline: the loads of stage i+1 are in flight while stage i is multiplied, so a wave always has
+  // UNR..2*UNR chunks (x 2 x NTILE 16-byte loads per lane) outstanding.  Chunks beyond c_end load nothing (zero operands).
+  constexpr int UNR = 2;           // chunks per stage
+  constexpr int STEP = UNR * NW;   // chunk stride of one stage
+  u32x4 wa[UNR][2][NTILE], xa[UNR][2], wb[UNR][2][NTILE], xb[UNR][2];
+  // loads are unconditional (addresses clamped into the block's valid range) so that the compiler emits straight-line
+  // loads with counted waits; an absent chunk / half chunk is cancelled by zeroing the (shared) x fragment only.
+  const int c_last = max(ce - 1, cb);
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page) + g * 8;
+  auto load_stage = [&](int c0, u32x4 (&wv)[UNR][2][NTILE], u32x4 (&xv)[UNR][2]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int k = (c + u * NW) << 6;
+      const int cc = c0 + u * NW;
+      const int k = min(cc, c_last) << 6;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bool ok = k + h * 32 < K;  // K % 32 == 0: only the very last half chunk can be absent
+        const bool ok = cc < ce && k + h * 32 < K;  // K % 32 == 0: only the very last half chunk can be absent
+        const int kk = min(k + h * 32, K - 32);
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t)
-          wv[u][h][t] = ok ? __builtin_nontemporal_load((const u32x4*)(wp[t] + k + h * 32)) : zero4;
-        xv[u][h] = ok ? ld16(xp + k + h * 32) : zero4;
+        for (int t = 0; t < NTILE; ++t) wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + kk));
+        xv[u][h] = ld16(ok ? xp + kk : zp);   // select on the ADDRESS: no dependent VALU behind the load
       }
     }
+  };
+  auto mma_stage = [&](const u32x4 (&wv)[UNR][2][NTILE], const u32x4 (&xv)[UNR][2]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h]), acc[t]);
-  }
-  for (; c < ce; c += NW) {
-    const int k = c << 6;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bool ok = k + h * 32 < K;
-      const u32x4 xq = ok ? ld16(xp + k + h * 32) : zero4;
-#pragma unroll
-      for (int t = 0; t < NTILE; ++t) {
-        const u32x4 wq = ok ? __builtin_nontemporal_load((const u32x4*)(wp[t] + k + h * 32)) : zero4;
-        acc[t] = mfma16(as_bf16x8(wq), as_bf16x8(xq), acc[t]);
-      }
-    }
+  };
+  int c = cb + wave;
+  load_stage(c, wa, xa);
+  for (; c < ce; c += 2 * STEP) {
+    load_stage(c + STEP, wb, xb);
+    mma_stage(wa, xa);
+    load_stage(c + 2 * STEP, wa, xa);
+    mma_stage(wb, xb);
   }
 
   // cross-wave reduction
