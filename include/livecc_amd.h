@@ -48,9 +48,14 @@ int lcc_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
  * ------------------------------------------------------------------------------------------------ */
 
 /* nn.Linear / Conv3d-as-GEMM:  C[M,N] = A[M,K] * W[N,K]^T (+bias)(+epilogue).  K%8==0, N%16==0.
+ * w_layout 0: W row-major [N,K] (nn.Linear);  1: W pre-packed in MFMA fragment order [N/16][ceil(K/32)][4][16][8]
+ * (element (n,k) at ((n/16*ceil(K/32) + k/32)*4 + (k%32)/8)*128 + (n%16)*8 + k%8, K zero-padded to 32): every wave load
+ * of the weight-streaming path is then one contiguous KB.  The engine stores all Linear weights packed.
  * M<=16 takes the HBM-bound skinny path; `partial` (fp32 [nsplit][M][N], skinny path only) returns raw split-K slabs. */
-int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual, int ldr,
                   void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream);
+/* tuning knob of the skinny kernel (0: 2 chunks single stage, 1: 1-chunk two-stage pipeline, 2: 2-chunk two-stage) */
+int lcc_debug_set_gemv_variant(int variant);
 int lcc_gemv_num_splits(int N, int K);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
 int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream);

@@ -73,7 +73,8 @@ def load():
         "lcc_last_error": (C.c_char_p, []),
         "lcc_version": (C.c_char_p, []),
         "lcc_device_info": (i32, [C.POINTER(i32), C.POINTER(sz), C.c_char_p, i32]),
-        "lcc_gemm_bf16": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+        "lcc_gemm_bf16": (i32, [vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+        "lcc_debug_set_gemv_variant": (i32, [i32]),
         "lcc_gemv_num_splits": (i32, [i32, i32]),
         "lcc_debug_mfma_probe": (i32, [vp, vp, vp, vp]),
         "lcc_patchify_norm_u8": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp]),

@@ -440,33 +440,33 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   }
   HIP_TRY(hipMemsetAsync(vt, 0, (size_t)heads * blocks * 80 * 32 * 2, st));
   GemmArgs g;
-  // K2: patch embed (Conv3d k=s=(2,14,14) == GEMM, no bias)
-  g = GemmArgs(); g.A = patches; g.lda = PD; g.W = e->patch_embed; g.ldw = PD; g.C = x; g.ldc = E; g.M = P; g.N = E; g.K = PD;
+  // K2: patch embed (Conv3d k=s=(2,14,14) == GEMM, no bias; K = 1176 is not a multiple of 32: row-major weight)
+  g = GemmArgs(); g.w_packed = 0; g.A = patches; g.lda = PD; g.W = e->patch_embed; g.ldw = PD; g.C = x; g.ldc = E; g.M = P; g.N = E; g.K = PD;
   LCC_TRY(gemm_bf16(g, st));
   for (int l = 0; l < e->c.vit_depth; ++l) {
     const VitLayerW& L = e->vit[l];
     LCC_TRY(layernorm_bf16(x, L.ln1_w, L.ln1_b, xn, P, E, 1e-6f, st));
-    g = GemmArgs(); g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
+    g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
     LCC_TRY(gemm_bf16(g, st));
     LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));
     LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, st));
-    g = GemmArgs(); g.A = attn; g.lda = E; g.W = L.proj_w; g.ldw = E; g.bias = L.proj_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
+    g = GemmArgs(); g.w_packed = 1; g.A = attn; g.lda = E; g.W = L.proj_w; g.ldw = E; g.bias = L.proj_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
     g.M = P; g.N = E; g.K = E; g.epilogue = LCC_EPI_RESIDUAL;
     LCC_TRY(gemm_bf16(g, st));
     LCC_TRY(layernorm_bf16(x, L.ln2_w, L.ln2_b, xn, P, E, 1e-6f, st));
-    g = GemmArgs(); g.A = xn; g.lda = E; g.W = L.fc1_w; g.ldw = E; g.bias = L.fc1_b; g.C = mlp; g.ldc = MLP; g.M = P; g.N = MLP; g.K = E;
+    g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.fc1_w; g.ldw = E; g.bias = L.fc1_b; g.C = mlp; g.ldc = MLP; g.M = P; g.N = MLP; g.K = E;
     g.epilogue = LCC_EPI_QUICK_GELU;
     LCC_TRY(gemm_bf16(g, st));
-    g = GemmArgs(); g.A = mlp; g.lda = MLP; g.W = L.fc2_w; g.ldw = MLP; g.bias = L.fc2_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
+    g = GemmArgs(); g.w_packed = 1; g.A = mlp; g.lda = MLP; g.W = L.fc2_w; g.ldw = MLP; g.bias = L.fc2_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
     g.M = P; g.N = E; g.K = MLP; g.epilogue = LCC_EPI_RESIDUAL;
     LCC_TRY(gemm_bf16(g, st));
   }
   // merger: LN -> view [P/4, 4E] -> Linear + GELU -> Linear
   LCC_TRY(layernorm_bf16(x, e->mg_ln_w, e->mg_ln_b, xn, P, E, 1e-6f, st));
-  g = GemmArgs(); g.A = xn; g.lda = 4 * E; g.W = e->mg_fc1_w; g.ldw = 4 * E; g.bias = e->mg_fc1_b; g.C = mg; g.ldc = 4 * E;
+  g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = 4 * E; g.W = e->mg_fc1_w; g.ldw = 4 * E; g.bias = e->mg_fc1_b; g.C = mg; g.ldc = 4 * E;
   g.M = P / 4; g.N = 4 * E; g.K = 4 * E; g.epilogue = LCC_EPI_GELU_ERF;
   LCC_TRY(gemm_bf16(g, st));
-  g = GemmArgs(); g.A = mg; g.lda = 4 * E; g.W = e->mg_fc2_w; g.ldw = 4 * E; g.bias = e->mg_fc2_b; g.C = (bf16_t*)out_embeds; g.ldc = H;
+  g = GemmArgs(); g.w_packed = 1; g.A = mg; g.lda = 4 * E; g.W = e->mg_fc2_w; g.ldw = 4 * E; g.bias = e->mg_fc2_b; g.C = (bf16_t*)out_embeds; g.ldc = H;
   g.M = P / 4; g.N = H; g.K = 4 * E;
   LCC_TRY(gemm_bf16(g, st));
   return check_launch("lcc_vit_encode");
@@ -513,7 +513,7 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     const bf16_t* next_norm = (l + 1 < e->c.n_layers) ? e->llm[l + 1].in_norm : e->final_norm;
     GemmArgs g;
     // q/k/v projection (+bias) -> M-RoPE -> in-place KV append
-    g = GemmArgs(); g.A = b.xn; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
+    g = GemmArgs(); g.w_packed = 1; g.A = b.xn; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
     if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_qkv;
       LCC_TRY(gemm_bf16(g, st));
@@ -533,7 +533,7 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       LCC_TRY(attn_prefill_bf16(b.q, b.attn, cx.tile_stream, cx.tile_q0, cx.tile_nq, cx.tile_pos0, e->d_kv_base, e->lay, l,
                                 cx.n_tiles, e->c.n_q_heads, st));
     // o_proj + residual + post-attention RMSNorm
-    g = GemmArgs(); g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
+    g = GemmArgs(); g.w_packed = 1; g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
     if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_o;
       LCC_TRY(gemm_bf16(g, st));
@@ -544,13 +544,13 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       LCC_TRY(rmsnorm_bf16(b.h, L.post_norm, b.xn, S, H, eps, st));
     }
     // SwiGLU MLP
-    g = GemmArgs(); g.A = b.xn; g.lda = H; g.W = L.gate_up_w; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
+    g = GemmArgs(); g.w_packed = 1; g.A = b.xn; g.lda = H; g.W = L.gate_up_w; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
     g.epilogue = LCC_EPI_SWIGLU;
     const bool prof = e->prof_on && cx.skinny && cx.tok_pos == nullptr && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
     if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
     LCC_TRY(gemm_bf16(g, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
-    g = GemmArgs(); g.A = b.act; g.lda = I; g.W = L.down_w; g.ldw = I; g.M = S; g.N = H; g.K = I;
+    g = GemmArgs(); g.w_packed = 1; g.A = b.act; g.lda = I; g.W = L.down_w; g.ldw = I; g.M = S; g.N = H; g.K = I;
     if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_dn;
       LCC_TRY(gemm_bf16(g, st));
@@ -569,7 +569,7 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   const int H = e->c.hidden_size, V = e->c.vocab_size;
   bf16_t* logits = b.logits;
   if (sp && sp->logits_out) logits = (bf16_t*)sp->logits_out + (size_t)step_index * B * V;
-  GemmArgs g; g.A = xn_rows; g.lda = H; g.W = e->lm_head; g.ldw = H; g.C = logits; g.ldc = V; g.M = B; g.N = V; g.K = H;
+  GemmArgs g; g.w_packed = 1; g.A = xn_rows; g.lda = H; g.W = e->lm_head; g.ldw = H; g.C = logits; g.ldc = V; g.M = B; g.N = V; g.K = H;
   LCC_TRY(gemm_bf16(g, st));
   const float pen = sp ? sp->repetition_penalty : 1.0f;
   const int thr_tok = sp ? sp->thr_token : -1;
@@ -728,10 +728,12 @@ static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_hea
     return check_launch(name);                               \
   } while (0)
 
-extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
-                             void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {
+extern "C" int lcc_debug_set_gemv_variant(int variant) { set_gemv_variant(variant); return 0; }
+extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual,
+                             int ldr, void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {
   if (!A || !W || (!C && !partial)) return fail(LCC_ERR_ARG, "lcc_gemm_bf16: null pointer");
-  GemmArgs g; g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = (const bf16_t*)bias;
+  if (w_layout != 0 && w_layout != 1) return fail(LCC_ERR_ARG, "lcc_gemm_bf16: w_layout must be 0 or 1");
+  GemmArgs g; g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.w_packed = w_layout; g.bias = (const bf16_t*)bias;
   g.residual = (const bf16_t*)residual; g.ldr = ldr; g.C = (bf16_t*)C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epilogue = epilogue;
   g.partial = partial; g.nsplit = nsplit;
   if (partial && C == nullptr) g.C = (bf16_t*)partial;  // alignment check only

@@ -31,7 +31,7 @@ template <int BM, int EPI>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
-    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, int w_packed) {
   constexpr int BN = 128, BK = 64;
   constexpr int WM = BM / 2;       // wave tile rows (of A)
   constexpr int MT = WM / 16;      // 16-row MFMA tiles per wave in M
@@ -71,9 +71,13 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
   for (int i = 0; i < BI; ++i) {
     int row = (tid >> 3) + i * 32;
     int gr = min(n0 + row, N - 1);
-    bptr[i] = W + (size_t)gr * ldw + chunk * 8;
+    // row-major [N,K]: row*ldw + chunk*8, k-tile stride 64.  packed [N/16][Kp/32][4 g][16 rows][8]: the 1-KB fragment
+    // sub-tile of (row tile, 32-k block), k-tile (= two 32-k blocks) stride 1024.
+    bptr[i] = w_packed ? W + ((size_t)(gr >> 4) * ((K + 31) >> 5) + (chunk >> 2)) * 512 + (chunk & 3) * 128 + (gr & 15) * 8
+                       : W + (size_t)gr * ldw + chunk * 8;
     boff[i] = BM * 8 + row * 8 + (chunk ^ ((row >> 1) & 7));
   }
+  const int wstride = w_packed ? 1024 : BK;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
 #pragma unroll
     for (int i = 0; i < AI; ++i) ra[i] = ld16(ok ? aptr[i] + kt * BK : zp);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) rb[i] = ld16(ok ? bptr[i] + kt * BK : zp);
+    for (int i = 0; i < BI; ++i) rb[i] = ld16(ok ? bptr[i] + (size_t)kt * wstride : zp);
   };
   auto sstore = [&](int buf) {
     u32x4* s = smem + buf * STAGE;
@@ -184,7 +188,7 @@ template <int BM, int EPI>
 static void launch_tiled(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 127) / 128;
   gemm_tiled_kernel<BM, EPI><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(
-      a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n);
+      a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed);
 }
 
 template <int EPI>
@@ -199,13 +203,20 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
 // skinny GEMV-like kernel (M <= 16): HBM-bound weight streaming
 // ------------------------------------------------------------------------------------------------
 // Block = 4 waves.  The block owns NTILE*16 consecutive W rows and the 64-element K chunks [c_begin, c_end) of split
-// blockIdx.y; wave w takes chunks c_begin + w, + 4, ... (consecutive 128-byte lines of a row alternate between the waves
-// of one block, so a block streams 16 rows x 512 contiguous bytes per round).  W fragments go HBM -> VGPR -> MFMA
-// (no LDS: each byte is used once); per chunk and tile a lane issues two 16-byte loads (the two halves of one line of
-// its row) plus the matching x fragment (L2/L1 resident).  The four partial accumulators are reduced through LDS and
-// wave 0 runs the epilogue.  D'[n][m]: lane (m = l&15, g) ends with 4 consecutive n for activation row m.
-// ~16+ waves per CU x 8-16 KB in flight per wave keeps > 100 KB per CU outstanding, which HBM3E needs at 6+ TB/s.
-template <int NTILE, int MODE>  // MODE 0: fp32 partial slab out[split][M][N]; 1: bf16 out with bias; 2: swiglu bf16
+// blockIdx.y; wave w takes chunks c_begin + w, + 4, ...  W fragments go HBM -> VGPR -> MFMA (no LDS: each byte is used
+// once); per chunk and tile a lane issues two 16-byte loads plus the matching x fragment (L2/L1 resident).  The four
+// partial accumulators are reduced through LDS and wave 0 runs the epilogue.  D'[n][m]: lane (m = l&15, g) ends with 4
+// consecutive n for activation row m.
+//
+// W layouts:  row-major [N,K] (a wave load = 16 rows x 64 B), or PACKED [N/16][K/32][4 g][16 rows][8 k]: the 1-KB
+// A-operand fragment of (row tile, 32-k block) is contiguous in lane order, so every wave load is one contiguous KB and a
+// block streams one contiguous 16*K*2-byte region per tile -- linear DRAM streams instead of 64-byte row segments.
+//
+// PIPE 0: UNR chunks are loaded, then multiplied (latency hidden by ~20 resident waves per CU);
+// PIPE 1: two-stage software pipeline (the next stage's loads are in flight while this one is multiplied).
+__device__ unsigned int lcc_zero_page_g[64];  // 256 zero bytes: x operand of absent K chunks (address select, no branch)
+
+template <int NTILE, int MODE, bool PACKED, int UNR, int PIPE>
 __global__ __launch_bounds__(256) void gemv_skinny_kernel(
     const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
     const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int chunks_per_split) {
@@ -214,39 +225,37 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (NTILE * 16);
   const int split = blockIdx.y;
-  const int nchunk = (K + 63) >> 6;
+  const int nchunk = (K + 63) >> 6, K32 = (K + 31) >> 5;
   const int cb = split * chunks_per_split, ce = min(nchunk, cb + chunks_per_split);
 
   const int xm = min(li, M - 1);
   const bf16_t* xp = X + (size_t)xm * ldx + g * 8;
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_g) + g * 8;
   const bf16_t* wp[NTILE];
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) wp[t] = W + (size_t)min(n0 + t * 16 + li, N - 1) * ldw + g * 8;
+  for (int t = 0; t < NTILE; ++t)
+    wp[t] = PACKED ? W + (size_t)((n0 >> 4) + t) * K32 * 512 + lane * 8
+                   : W + (size_t)min(n0 + t * 16 + li, N - 1) * ldw + g * 8;
 
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // two-stage software pipeline: the loads of stage i+1 are in flight while stage i is multiplied, so a wave always has
-  // UNR..2*UNR chunks (x 2 x NTILE 16-byte loads per lane) outstanding.  Chunks beyond c_end load nothing (zero operands).
-  constexpr int UNR = 2;           // chunks per stage
-  constexpr int STEP = UNR * NW;   // chunk stride of one stage
-  u32x4 wa[UNR][2][NTILE], xa[UNR][2], wb[UNR][2][NTILE], xb[UNR][2];
-  // loads are unconditional (addresses clamped into the block's valid range) so that the compiler emits straight-line
-  // loads with counted waits; an absent chunk / half chunk is cancelled by zeroing the (shared) x fragment only.
-  const int c_last = max(ce - 1, cb);
-  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page) + g * 8;
+
+  // loads are unconditional (32-k block index clamped into range) so that the compiler emits straight-line loads with
+  // counted waits; an absent block is cancelled by pointing the (shared) x fragment at a zero page.
   auto load_stage = [&](int c0, u32x4 (&wv)[UNR][2][NTILE], u32x4 (&xv)[UNR][2]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int cc = c0 + u * NW;
-      const int k = min(cc, c_last) << 6;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bool ok = cc < ce && k + h * 32 < K;  // K % 32 == 0: only the very last half chunk can be absent
-        const int kk = min(k + h * 32, K - 32);
+        const int kb = 2 * cc + h;                        // 32-k block
+        const bool ok = cc < ce && kb < K32;              // wave-uniform
+        const int kbc = min(kb, K32 - 1);
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + kk));
-        xv[u][h] = ld16(ok ? xp + kk : zp);   // select on the ADDRESS: no dependent VALU behind the load
+        for (int t = 0; t < NTILE; ++t)
+          wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)kbc * (PACKED ? 512 : 32)));
+        xv[u][h] = ld16(ok ? xp + kbc * 32 : zp);
       }
     }
   };
@@ -258,13 +267,23 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h]), acc[t]);
   };
-  int c = cb + wave;
-  load_stage(c, wa, xa);
-  for (; c < ce; c += 2 * STEP) {
-    load_stage(c + STEP, wb, xb);
-    mma_stage(wa, xa);
-    load_stage(c + 2 * STEP, wa, xa);
-    mma_stage(wb, xb);
+  constexpr int STEP = UNR * NW;  // chunk stride of one stage
+  if (PIPE == 0) {
+    for (int c = cb + wave; c < ce; c += STEP) {
+      u32x4 wa[UNR][2][NTILE], xa[UNR][2];
+      load_stage(c, wa, xa);
+      mma_stage(wa, xa);
+    }
+  } else {
+    u32x4 wa[UNR][2][NTILE], xa[UNR][2], wb[UNR][2][NTILE], xb[UNR][2];
+    int c = cb + wave;
+    load_stage(c, wa, xa);
+    for (; c < ce; c += 2 * STEP) {
+      load_stage(c + STEP, wb, xb);
+      mma_stage(wa, xa);
+      load_stage(c + 2 * STEP, wa, xa);
+      mma_stage(wb, xb);
+    }
   }
 
   // cross-wave reduction
@@ -313,6 +332,28 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   }
 }
 
+static int g_gemv_variant = 0;  // 0: UNR2 single stage; 1: UNR1 two-stage pipeline; 2: UNR2 two-stage pipeline
+void set_gemv_variant(int v) { g_gemv_variant = v; }
+
+template <int NTILE, int MODE, bool PACKED>
+static void launch_gemv(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
+  switch (g_gemv_variant) {
+    case 1:
+      gemv_skinny_kernel<NTILE, MODE, PACKED, 1, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps);
+      break;
+    case 2:
+      gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps);
+      break;
+    default:
+      gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 0><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps);
+  }
+}
+template <int NTILE, int MODE>
+static void launch_gemv_l(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
+  if (a.w_packed) launch_gemv<NTILE, MODE, true>(grid, a, out, ldo, cps, st);
+  else launch_gemv<NTILE, MODE, false>(grid, a, out, ldo, cps, st);
+}
+
 // layout probe (tests/test_gpu_ops.py::test_mfma_layout_probe): D[16x16] = A[16x32] * B[32x16] with the fragment maps of
 // common.h, one wave.  Verifies the operand/result lane maps every kernel in this library relies on.
 __global__ __launch_bounds__(64) void mfma_probe_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
@@ -348,7 +389,7 @@ int gemv_num_splits(int N, int K) {
 
 int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
-  if ((a.K & 7) || (a.N & 15) || (a.lda & 7) || (a.ldw & 7) || (a.ldc & 3)) return LCC_ERR_SHAPE;
+  if ((a.K & 7) || (a.N & 15) || (a.lda & 7) || (!a.w_packed && (a.ldw & 7)) || (a.ldc & 3)) return LCC_ERR_SHAPE;
   if ((((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) != 0) return LCC_ERR_ALIGN;
   if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
   if (a.epilogue == EPI_RESIDUAL && a.residual == nullptr) return LCC_ERR_ARG;
@@ -357,16 +398,13 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if (skinny) {
     const int nchunk = (a.K + 63) / 64;
     if (a.epilogue == EPI_SWIGLU) {
-      gemv_skinny_kernel<2, 2><<<dim3((a.N + 31) / 32, 1), dim3(256), 0, st>>>(
-          a.A, a.lda, a.W, a.ldw, nullptr, a.C, a.ldc, a.M, a.N, a.K, nchunk);
+      launch_gemv_l<2, 2>(dim3((a.N + 31) / 32, 1), a, a.C, a.ldc, nchunk, st);
     } else if (a.partial != nullptr) {
       const int S = a.nsplit > 0 ? a.nsplit : 1;
       if (S > nchunk) return LCC_ERR_SHAPE;
-      gemv_skinny_kernel<1, 0><<<dim3((a.N + 15) / 16, S), dim3(256), 0, st>>>(
-          a.A, a.lda, a.W, a.ldw, nullptr, a.partial, a.N, a.M, a.N, a.K, (nchunk + S - 1) / S);
+      launch_gemv_l<1, 0>(dim3((a.N + 15) / 16, S), a, a.partial, a.N, (nchunk + S - 1) / S, st);
     } else {
-      gemv_skinny_kernel<1, 1><<<dim3((a.N + 15) / 16, 1), dim3(256), 0, st>>>(
-          a.A, a.lda, a.W, a.ldw, a.bias, a.C, a.ldc, a.M, a.N, a.K, nchunk);
+      launch_gemv_l<1, 1>(dim3((a.N + 15) / 16, 1), a, a.C, a.ldc, nchunk, st);
     }
     return 0;
   }

@@ -13,7 +13,8 @@ typedef unsigned short bf16_t;
 // ---- GEMM (gemm.hip) ----
 struct GemmArgs {
   const bf16_t* A = nullptr; int lda = 0;       // [M,K]
-  const bf16_t* W = nullptr; int ldw = 0;       // [N,K]
+  const bf16_t* W = nullptr; int ldw = 0;       // [N,K] row-major, or packed fragments (w_packed, ldw ignored)
+  int w_packed = 0;                             // 1: [N/16][ceil(K/32)][4][16][8] (see gemm.hip)
   const bf16_t* bias = nullptr;                 // [N] or null
   const bf16_t* residual = nullptr; int ldr = 0;
   bf16_t* C = nullptr; int ldc = 0;             // [M,N] (swiglu: [M,N/2])
@@ -23,6 +24,7 @@ struct GemmArgs {
 };
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
 int gemv_num_splits(int N, int K);
+void set_gemv_variant(int v);
 int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
 
 // ---- elementwise / normalisation / layout (elementwise.hip) ----

@@ -31,29 +31,45 @@ def _chk(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
     return t.data_ptr()
 
 
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N,K] -> MFMA-fragment order [N/16][ceil(K/32)][4][16][8] (flat), K zero-padded to 32.
+    Element (n,k) lands at ((n//16 * K32 + k//32) * 4 + (k%32)//8) * 128 + (n%16)*8 + k%8 (include/livecc_amd.h)."""
+    N, K = w.shape
+    assert N % 16 == 0
+    K32 = (K + 31) // 32
+    if K32 * 32 != K:
+        w = torch.nn.functional.pad(w, (0, K32 * 32 - K))
+    return w.view(N // 16, 16, K32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
-           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = epilogue(x @ w.T + bias); x [M,K] bf16, w [N,K] bf16."""
+           residual: Optional[torch.Tensor] = None, packed_shape: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """y = epilogue(x @ w.T + bias); x [M,K] bf16; w [N,K] bf16 row-major, or a packed weight (pack_weight) with
+    packed_shape=(N,K)."""
     M, K = x.shape
-    N = w.shape[0]
-    assert w.shape[1] == K
+    N = w.shape[0] if packed_shape is None else packed_shape[0]
+    assert (w.shape[1] if packed_shape is None else packed_shape[1]) == K
     out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K,
+    _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K, 0 if packed_shape is None else 1,
                                  _chk(bias, torch.bfloat16, "bias"), _chk(residual, torch.bfloat16, "residual"), N,
                                  out.data_ptr(), out.shape[1], M, N, K, epilogue, None, 0, _st(x)), "lcc_gemm_bf16")
     return out
 
 
-def linear_partial(x: torch.Tensor, w: torch.Tensor, nsplit: int) -> torch.Tensor:
+def linear_partial(x: torch.Tensor, w: torch.Tensor, nsplit: int, packed_shape: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """Skinny split-K path: fp32 slabs [nsplit, M, N] (M <= 16)."""
     M, K = x.shape
-    N = w.shape[0]
+    N = w.shape[0] if packed_shape is None else packed_shape[0]
     out = torch.empty(nsplit, M, N, dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K, None, None, 0, None, N,
-                                 M, N, K, EPI_NONE, out.data_ptr(), nsplit, _st(x)), "lcc_gemm_bf16(partial)")
+    _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K, 0 if packed_shape is None else 1,
+                                 None, None, 0, None, N, M, N, K, EPI_NONE, out.data_ptr(), nsplit, _st(x)), "lcc_gemm_bf16(partial)")
     return out
+
+
+def set_gemv_variant(v: int) -> None:
+    _lib.load().lcc_debug_set_gemv_variant(int(v))
 
 
 def gemv_num_splits(N: int, K: int) -> int:

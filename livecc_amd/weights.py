@@ -41,10 +41,20 @@ def weight_shapes(cfg: LiveCCConfig) -> List[Tuple[str, Tuple[int, ...]]]:
         out += [(p + "in_norm", (H,)), (p + "qkv_w", (cfg.qkv_dim, H)), (p + "qkv_b", (cfg.qkv_dim,)),
                 (p + "o_w", (H, cfg.q_dim)), (p + "post_norm", (H,)), (p + "gate_up_w", (2 * I, H)),
                 (p + "down_w", (H, I))]
-    out += [("final_norm", (H,))]
-    if not cfg.tie_word_embeddings:
-        out += [("lm_head", (cfg.vocab_size, H))]
+    out += [("final_norm", (H,)), ("lm_head", (cfg.vocab_size, H))]   # tied checkpoints: a packed copy of `embed`
     return out
+
+
+# matrices kept row-major: the Conv3d-as-GEMM weight (K = 1176 is not a multiple of 32) and the embedding table (gathered by
+# row).  Every other 2-D weight is stored PACKED in MFMA fragment order (ops.pack_weight / include/livecc_amd.h) so that
+# the weight-streaming decode kernels read linear 1-KB bursts.
+ROW_MAJOR = ("vit.patch_embed", "embed")
+
+
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0, (N, K)
+    return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
@@ -72,16 +82,29 @@ class WeightArena:
         self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(self.device)
 
     def view(self, name: str) -> torch.Tensor:
-        if name == "lm_head" and self.cfg.tie_word_embeddings:
-            name = "embed"
+        """Storage view [N,K]-shaped; for packed weights the bytes are in fragment order (use `logical` to read values)."""
         o, n, shp = self.offsets[name]
         return self.flat[o:o + n].view(*shp)
 
+    def is_packed(self, name: str) -> bool:
+        return len(self.offsets[name][2]) == 2 and name not in ROW_MAJOR
+
+    def logical(self, name: str) -> torch.Tensor:
+        """Row-major [N,K] values of a (possibly packed) weight (tests / export)."""
+        v = self.view(name)
+        if not self.is_packed(name):
+            return v
+        N, K = v.shape
+        return v.reshape(N // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(N, K)
+
+    def store(self, name: str, t: torch.Tensor) -> None:
+        v = self.view(name)
+        assert tuple(t.shape) == tuple(v.shape), f"{name}: {tuple(t.shape)} vs {tuple(v.shape)}"
+        t = t.to(self.device, dtype=torch.bfloat16)
+        v.copy_(pack_weight(t) if self.is_packed(name) else t)
+
     def names(self) -> List[str]:
-        n = [s[0] for s in self.shapes]
-        if self.cfg.tie_word_embeddings:
-            n.append("lm_head")
-        return n
+        return [s[0] for s in self.shapes]
 
     def nbytes(self) -> int:
         return self.flat.numel() * 2
@@ -94,7 +117,7 @@ class WeightArena:
         g = torch.Generator(device=self.device).manual_seed(seed)
         for name, shp in self.shapes:
             v = self.view(name)
-            if len(shp) >= 2:
+            if len(shp) >= 2:   # i.i.d. values: the packed order of a random matrix is a random matrix
                 v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(std))
             elif name.endswith("_b"):
                 v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(0.05))
@@ -107,10 +130,7 @@ class WeightArena:
         """Fill from an HF state dict accessor (tensor by HF name; any float dtype; CPU or GPU)."""
         cfg = self.cfg
 
-        def put(name, t):
-            v = self.view(name)
-            assert tuple(t.shape) == tuple(v.shape), f"{name}: {tuple(t.shape)} vs {tuple(v.shape)}"
-            v.copy_(t.to(self.device, dtype=torch.bfloat16))
+        put = self.store
 
         put("vit.patch_embed", sd_get("visual.patch_embed.proj.weight").reshape(cfg.vit_embed_dim, -1))
         for i in range(cfg.vit_depth):
@@ -134,8 +154,7 @@ class WeightArena:
             put(p + "gate_up_w", interleave_gate_up(sd_get(s + "mlp.gate_proj.weight"), sd_get(s + "mlp.up_proj.weight")))
             put(p + "down_w", sd_get(s + "mlp.down_proj.weight"))
         put("final_norm", sd_get("language_model.norm.weight"))
-        if not cfg.tie_word_embeddings:
-            put("lm_head", sd_get("lm_head.weight"))
+        put("lm_head", sd_get("language_model.embed_tokens.weight") if cfg.tie_word_embeddings else sd_get("lm_head.weight"))
         return self
 
 

@@ -41,7 +41,7 @@ def test_no_torch_or_cxx_types_in_the_header():
 def test_version_and_error_paths_without_gpu(lib):
     assert b"gfx950" in lib.lcc_version()
     # argument validation happens before any device work
-    assert lib.lcc_gemm_bf16(None, 0, None, 0, None, None, 0, None, 0, 1, 16, 8, 0, None, 0, None) != 0
+    assert lib.lcc_gemm_bf16(None, 0, None, 0, 0, None, None, 0, None, 0, 1, 16, 8, 0, None, 0, None) != 0
     assert b"null" in lib.lcc_last_error()
     assert lib.lcc_engine_create(None, None) is None
     cfg = _lib.ModelConfig(2048, 256, 512, 2, 2, 1, 64, 1e-6, 16, 24, 24, 2, 160, 2, 640, 1176, 2)   # head_dim 64: rejected

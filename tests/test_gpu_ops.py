@@ -63,20 +63,22 @@ def _ref_linear(x, w, bias=None, epi=0, residual=None, with_atol=False):
 @pytest.mark.parametrize("M,N,K", [(200, 512, 256), (386, 1280, 1176), (130, 480, 160), (64, 1024, 640), (1456, 3840, 1280),
                                    (17, 256, 512), (300, 4608, 3584)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-def test_gemm_tiled(dev, M, N, K, epi):
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_tiled(dev, M, N, K, epi, packed):
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
     res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
-    got = ops.linear(x, w, b, epi, res)
+    got = ops.linear(x, ops.pack_weight(w), b, epi, res, packed_shape=(N, K)) if packed else ops.linear(x, w, b, epi, res)
     ref, atol = _ref_linear(x, w, b, epi, res, with_atol=True)
     assert_bf16_close(got, ref, f"gemm_tiled[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
 @pytest.mark.parametrize("M,I,K", [(100, 512, 256), (386, 2432, 896)])
-def test_gemm_tiled_swiglu(dev, M, I, K):
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_tiled_swiglu(dev, M, I, K, packed):
     from livecc_amd import ops
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
-    got = ops.linear(x, w, None, ops.EPI_SWIGLU)
+    got = ops.linear(x, ops.pack_weight(w), None, ops.EPI_SWIGLU, packed_shape=(2 * I, K)) if packed else ops.linear(x, w, None, ops.EPI_SWIGLU)
     ref, atol = _ref_linear(x, w, None, 4, with_atol=True)
     assert_bf16_close(got, ref, f"gemm_tiled_swiglu[{M}x{I}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
@@ -92,15 +94,26 @@ def test_gemm_no_bias_identity_layout(dev):
 
 
 @pytest.mark.parametrize("M", [1, 3, 8, 16])
-@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944)])
-def test_gemv_skinny(dev, M, N, K):
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1024, 160)])
+@pytest.mark.parametrize("packed,variant", [(False, 0), (True, 0), (True, 1), (True, 2), (False, 2)])
+def test_gemv_skinny(dev, M, N, K, packed, variant):
     from livecc_amd import ops
+    ops.set_gemv_variant(variant)
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.03, 2), _rand((N,), dev, 0.1, 3)
-    got = ops.linear(x, w, b)
+    ps = (N, K) if packed else None
+    if packed:
+        w_row, w = w, ops.pack_weight(w)
+    else:
+        w_row = w
+    try:
+        got = ops.linear(x, w, b, packed_shape=ps)
+        S = ops.gemv_num_splits(N, K)
+        part = ops.linear_partial(x, w, S, packed_shape=ps)
+    finally:
+        ops.set_gemv_variant(0)
+    w = w_row
     ref, atol = _ref_linear(x, w, b, with_atol=True)
     assert_bf16_close(got, ref, f"gemv[{M}x{N}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
-    S = ops.gemv_num_splits(N, K)
-    part = ops.linear_partial(x, w, S)
     ref = x.float() @ w.float().t()
     err = (part.sum(0) - ref).abs().max().item()
     record(f"gemv_partial[{M}x{N}x{K},S{S}]", dict(max_abs=err, scale=float(ref.abs().max())))
@@ -108,11 +121,12 @@ def test_gemv_skinny(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M", [1, 7, 16])
-def test_gemv_swiglu(dev, M):
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemv_swiglu(dev, M, packed):
     from livecc_amd import ops
     I, K = 2432, 896
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
-    got = ops.linear(x, w, None, ops.EPI_SWIGLU)
+    got = ops.linear(x, ops.pack_weight(w), None, ops.EPI_SWIGLU, packed_shape=(2 * I, K)) if packed else ops.linear(x, w, None, ops.EPI_SWIGLU)
     ref, atol = _ref_linear(x, w, None, 4, with_atol=True)
     assert_bf16_close(got, ref, f"gemv_swiglu[{M}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 

@@ -18,6 +18,18 @@ def test_interleave_gate_up():
     assert torch.equal(w[0:16], g[0:16]) and torch.equal(w[16:32], u[0:16]) and torch.equal(w[32:48], g[16:32])
 
 
+def test_pack_weight_index_formula():
+    """packed[((n//16*K32 + k//32)*4 + (k%32)//8)*128 + (n%16)*8 + k%8] == W[n,k]  (include/livecc_amd.h)"""
+    from livecc_amd.weights import pack_weight
+    N, K = 48, 96
+    w = torch.arange(N * K, dtype=torch.float32).view(N, K)
+    p = pack_weight(w).reshape(-1)
+    K32 = K // 32
+    for n, k in [(0, 0), (5, 7), (17, 33), (47, 95), (31, 64), (16, 8)]:
+        idx = ((n // 16 * K32 + k // 32) * 4 + (k % 32) // 8) * 128 + (n % 16) * 8 + k % 8
+        assert p[idx] == w[n, k]
+
+
 def test_weight_shapes_cover_7b_param_count():
     n = 0
     for name, shp in weight_shapes(livecc_7b()):
@@ -25,7 +37,7 @@ def test_weight_shapes_cover_7b_param_count():
         for s in shp:
             k *= s
         n += k
-    assert abs(n / 1e9 - 8.291) < 0.005          # 8.291 B parameters
+    assert abs(n / 1e9 - 8.291) < 0.005          # 8.291 B parameters (7B: lm_head untied)
 
 
 def test_arena_from_hf_state_dict_cpu():
@@ -36,9 +48,10 @@ def test_arena_from_hf_state_dict_cpu():
     a = from_hf_model(hf, cfg, "cpu")
     sd = hf.state_dict()
     q = sd["model.language_model.layers.1.self_attn.q_proj.weight"]
-    assert torch.equal(a.view("llm.1.qkv_w")[:q.shape[0]], q)
+    assert torch.equal(a.logical("llm.1.qkv_w")[:q.shape[0]], q)
+    assert a.is_packed("llm.1.qkv_w") and not a.is_packed("embed") and not a.is_packed("vit.patch_embed")
     gate, up = sd["model.language_model.layers.0.mlp.gate_proj.weight"], sd["model.language_model.layers.0.mlp.up_proj.weight"]
-    gu = a.view("llm.0.gate_up_w")
+    gu = a.logical("llm.0.gate_up_w")
     assert torch.equal(gu[32:48], gate[16:32]) and torch.equal(gu[48:64], up[16:32])
     pe = sd["model.visual.patch_embed.proj.weight"]
     assert torch.equal(a.view("vit.patch_embed"), pe.reshape(pe.shape[0], -1))

@@ -48,6 +48,6 @@ def record(name, d):
     try:
         os.makedirs(OUT, exist_ok=True)
         with open(os.path.join(OUT, "parity_report.json"), "w") as f:
-            json.dump(_REC, f, indent=1, sort_keys=True)
+            json.dump(_REC, f, indent=1, sort_keys=True, default=float)
     except OSError:
         pass
