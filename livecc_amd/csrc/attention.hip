@@ -321,17 +321,18 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(
   const int hq = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const int G = n_q_heads / n_kv_heads, hk = hq / G, j = hq % G;
   const size_t slot0 = (((size_t)b * n_kv_heads + hk) * nsplit) * 16 + j;
-  float M = -INFINITY;
-#pragma unroll 8
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(slot0 + (size_t)s * 16) * 2]);
-  float num = 0.f, den = 0.f;
+  // single pass with online rescaling: the loads of all splits are independent (8 in flight), only the scalar chain is serial
+  float M = -INFINITY, num = 0.f, den = 0.f;
 #pragma unroll 8
   for (int s = 0; s < nsplit; ++s) {
     const size_t slot = slot0 + (size_t)s * 16;
-    const float m = ws_ml[slot * 2], l = ws_ml[slot * 2 + 1];
-    const float w = (m == -INFINITY) ? 0.f : exp2f(m - M);
-    num += w * ws_o[slot * D + d];
-    den += w * l;
+    const float m = ws_ml[slot * 2], l = ws_ml[slot * 2 + 1], o = ws_o[slot * D + d];
+    const float Mn = fmaxf(M, m);
+    const float a = (M == -INFINITY) ? 0.f : exp2f(M - Mn);     // rescale of what was accumulated so far
+    const float w = (m == -INFINITY) ? 0.f : exp2f(m - Mn);
+    num = num * a + w * o;
+    den = den * a + w * l;
+    M = Mn;
   }
   out[((size_t)b * n_q_heads + hq) * D + d] = f2bf(num / den);
 }

@@ -141,7 +141,7 @@ int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y,
 // `residual + hidden_states` on bf16 tensors (decoder layer 604, 610): fp32 add, one rounding.
 // DELTA 0: none; 1: bf16 delta [rows,dim]; 2: fp32 split-K slabs [nsplit][rows][dim] (summed in slab order,
 // rounded to bf16 like the Linear output they stand for).
-template <int NW, int MAXC, int DELTA>
+template <int NW, int MAXC, int DELTA, int NS>
 __global__ __launch_bounds__(NW * 64) void add_rmsnorm_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ dbf,
                                                               const float* __restrict__ dpart, int nsplit, int rows,
                                                               const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
@@ -164,18 +164,14 @@ __global__ __launch_bounds__(NW * 64) void add_rmsnorm_kernel(bf16_t* __restrict
         for (int e = 0; e < 4; ++e) { v[c][2 * e] = rbf(v[c][2 * e] + lo2f(d[e])); v[c][2 * e + 1] = rbf(v[c][2 * e + 1] + hi2f(d[e])); }
       } else if (DELTA == 2) {
         float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x4 pa[8], pb[8];  // all slabs are loaded before the first add: one L2 round trip instead of nsplit
+        f32x4 pa[NS], pb[NS];  // NS is a compile-time slab count: straight-line loads, one L2/MALL round trip
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
-          if (sp < nsplit) {
-            const float* pp = dpart + ((size_t)sp * rows + row) * dim + ch * 8;
-            pa[sp] = *reinterpret_cast<const f32x4*>(pp); pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
-          } else {
-            pa[sp] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[sp] = pa[sp];
-          }
+        for (int sp = 0; sp < NS; ++sp) {
+          const float* pp = dpart + ((size_t)sp * rows + row) * dim + ch * 8;
+          pa[sp] = *reinterpret_cast<const f32x4*>(pp); pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
         }
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp)   // slab order (adding +0.0 for absent slabs is exact)
+        for (int sp = 0; sp < NS; ++sp)   // slab order
 #pragma unroll
           for (int e = 0; e < 4; ++e) { d[e] += pa[sp][e]; d[4 + e] += pb[sp][e]; }
 #pragma unroll
@@ -214,12 +210,17 @@ int add_rmsnorm_bf16(bf16_t* h, const bf16_t* delta_bf16, const float* delta_par
   if ((dim & 7) || dim > 4 * 64 * 8 * 4) return LCC_ERR_SHAPE;
   if (delta_bf16 != nullptr && delta_partial != nullptr) return LCC_ERR_ARG;
   if (delta_partial != nullptr && (nsplit < 1 || nsplit > 8)) return LCC_ERR_SHAPE;
-  if (delta_partial != nullptr)
-    add_rmsnorm_kernel<4, 4, 2><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, delta_partial, nsplit, rows, w, y, dim, eps);
-  else if (delta_bf16 != nullptr)
-    add_rmsnorm_kernel<4, 4, 1><<<dim3(rows), dim3(256), 0, st>>>(h, delta_bf16, nullptr, 0, rows, w, y, dim, eps);
+  if (delta_partial != nullptr) {
+#define LCC_ADDN(NS) add_rmsnorm_kernel<4, 4, 2, NS><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, delta_partial, nsplit, rows, w, y, dim, eps)
+    switch (nsplit) {
+      case 1: LCC_ADDN(1); break; case 2: LCC_ADDN(2); break; case 3: LCC_ADDN(3); break; case 4: LCC_ADDN(4); break;
+      case 5: LCC_ADDN(5); break; case 6: LCC_ADDN(6); break; case 7: LCC_ADDN(7); break; default: LCC_ADDN(8); break;
+    }
+#undef LCC_ADDN
+  } else if (delta_bf16 != nullptr)
+    add_rmsnorm_kernel<4, 4, 1, 1><<<dim3(rows), dim3(256), 0, st>>>(h, delta_bf16, nullptr, 0, rows, w, y, dim, eps);
   else
-    add_rmsnorm_kernel<4, 4, 0><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, nullptr, 0, rows, w, y, dim, eps);
+    add_rmsnorm_kernel<4, 4, 0, 1><<<dim3(rows), dim3(256), 0, st>>>(h, nullptr, nullptr, 0, rows, w, y, dim, eps);
   return 0;
 }
 
@@ -339,8 +340,8 @@ int mrope_table_decode(const int32_t* slots, const int32_t* pos, const float* in
 // One thread = 8 channels c..c+7 (c < 64) and partners c+64: 8 threads per rope head; 16 threads per V head.
 // QSRC 0: qkv bf16 [S, ld]; 1: fp32 split-K slabs [nsplit][S][ld] + bias (decode path).
 // ------------------------------------------------------------------------------------------------
-template <int QSRC>
-LCC_DEVICE void load8(const bf16_t* qkv, const float* part, int nsplit, int S, const bf16_t* bias, int s, int ld,
+template <int QSRC, int NS>
+LCC_DEVICE void load8(const bf16_t* qkv, const float* part, int S, const bf16_t* bias, int s, int ld,
                       int col, float (&v)[8]) {
   if (QSRC == 0) {
     const u32x4 a = ld16(qkv + (size_t)s * ld + col);
@@ -349,18 +350,14 @@ LCC_DEVICE void load8(const bf16_t* qkv, const float* part, int nsplit, int S, c
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    f32x4 pa[8], pb[8];
+    f32x4 pa[NS], pb[NS];
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp) {
-      if (sp < nsplit) {
-        const float* pp = part + ((size_t)sp * S + s) * ld + col;
-        pa[sp] = *reinterpret_cast<const f32x4*>(pp); pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
-      } else {
-        pa[sp] = (f32x4){0.f, 0.f, 0.f, 0.f}; pb[sp] = pa[sp];
-      }
+    for (int sp = 0; sp < NS; ++sp) {
+      const float* pp = part + ((size_t)sp * S + s) * ld + col;
+      pa[sp] = *reinterpret_cast<const f32x4*>(pp); pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
     }
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp)
+    for (int sp = 0; sp < NS; ++sp)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] += pa[sp][e]; v[4 + e] += pb[sp][e]; }
     const u32x4 bq = ld16(bias + col);
@@ -369,9 +366,9 @@ LCC_DEVICE void load8(const bf16_t* qkv, const float* part, int nsplit, int S, c
   }
 }
 
-template <int QSRC>
+template <int QSRC, int NS>
 __global__ __launch_bounds__(256) void rope_kv_append_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ part, int nsplit, const bf16_t* __restrict__ bias,
+    const bf16_t* __restrict__ qkv, const float* __restrict__ part, const bf16_t* __restrict__ bias,
     const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn, const int32_t* __restrict__ tok_stream,
     const int32_t* __restrict__ tok_pos, const int32_t* __restrict__ kv_len, bf16_t* const* __restrict__ kv_base,
     KvLayout lay, int layer, bf16_t* __restrict__ q_out, int S, int n_q_heads) {
@@ -389,8 +386,8 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(
   if (it < (n_q_heads + hkv) * 8) {
     const int head = it >> 3, c0 = (it & 7) * 8;
     float x1[8], x2[8], o1[8], o2[8];
-    load8<QSRC>(qkv, part, nsplit, S, bias, s, ld, head * D + c0, x1);
-    load8<QSRC>(qkv, part, nsplit, S, bias, s, ld, head * D + c0 + 64, x2);
+    load8<QSRC, NS>(qkv, part, S, bias, s, ld, head * D + c0, x1);
+    load8<QSRC, NS>(qkv, part, S, bias, s, ld, head * D + c0 + 64, x2);
     const u32x4 cq = ld16(cs + (size_t)s * 64 + c0), sq = ld16(sn + (size_t)s * 64 + c0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -410,7 +407,7 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(
     it -= (n_q_heads + hkv) * 8;
     const int hv = it >> 4, c0 = (it & 15) * 8;
     float x[8];
-    load8<QSRC>(qkv, part, nsplit, S, bias, s, ld, (n_q_heads + hkv + hv) * D + c0, x);
+    load8<QSRC, NS>(qkv, part, S, bias, s, ld, (n_q_heads + hkv + hv) * D + c0, x);
     bf16_t* dst = base + lay.kv_stride() + (size_t)hv * lay.head_stride() + ((size_t)(slot >> 5) * D + c0) * 32 + (slot & 31);
 #pragma unroll
     for (int e = 0; e < 8; ++e) dst[e * 32] = f2bf(x[e]);
@@ -430,11 +427,16 @@ int rope_kv_append_bf16(const bf16_t* qkv_bf16, const float* qkv_partial, int ns
   if (qkv_partial != nullptr) {
     if (bias == nullptr) return LCC_ERR_ARG;
     if (nsplit < 1 || nsplit > 8) return LCC_ERR_SHAPE;
-    rope_kv_append_kernel<1><<<grid, dim3(256), 0, st>>>(nullptr, qkv_partial, nsplit, bias, cos, sin, tok_stream,
-                                                         tok_pos, kv_len, kv_base, lay, layer, q_out, S, n_q_heads);
+#define LCC_ROPEN(NS) rope_kv_append_kernel<1, NS><<<grid, dim3(256), 0, st>>>(nullptr, qkv_partial, bias, cos, sin, tok_stream, \
+                                                               tok_pos, kv_len, kv_base, lay, layer, q_out, S, n_q_heads)
+    switch (nsplit) {
+      case 1: LCC_ROPEN(1); break; case 2: LCC_ROPEN(2); break; case 3: LCC_ROPEN(3); break; case 4: LCC_ROPEN(4); break;
+      case 5: LCC_ROPEN(5); break; case 6: LCC_ROPEN(6); break; case 7: LCC_ROPEN(7); break; default: LCC_ROPEN(8); break;
+    }
+#undef LCC_ROPEN
   } else {
-    rope_kv_append_kernel<0><<<grid, dim3(256), 0, st>>>(qkv_bf16, nullptr, 0, nullptr, cos, sin, tok_stream, tok_pos,
-                                                         kv_len, kv_base, lay, layer, q_out, S, n_q_heads);
+    rope_kv_append_kernel<0, 1><<<grid, dim3(256), 0, st>>>(qkv_bf16, nullptr, nullptr, cos, sin, tok_stream, tok_pos, kv_len,
+                                                            kv_base, lay, layer, q_out, S, n_q_heads);
   }
   return 0;
 }

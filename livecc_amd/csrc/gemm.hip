@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   }
 }
 
-static int g_gemv_variant = 0;  // 0: UNR2 single stage; 1: UNR1 two-stage pipeline; 2: UNR2 two-stage pipeline
+static int g_gemv_variant = 1;  // 0: UNR2 single stage; 1: UNR1 two-stage pipeline (default: best measured); 2: UNR2 two-stage
 void set_gemv_variant(int v) { g_gemv_variant = v; }
 
 template <int NTILE, int MODE, bool PACKED>

@@ -68,6 +68,9 @@ def linear_partial(x: torch.Tensor, w: torch.Tensor, nsplit: int, packed_shape: 
     return out
 
 
+GEMV_DEFAULT_VARIANT = 1
+
+
 def set_gemv_variant(v: int) -> None:
     _lib.load().lcc_debug_set_gemv_variant(int(v))
 

@@ -110,7 +110,7 @@ def test_gemv_skinny(dev, M, N, K, packed, variant):
         S = ops.gemv_num_splits(N, K)
         part = ops.linear_partial(x, w, S, packed_shape=ps)
     finally:
-        ops.set_gemv_variant(0)
+        ops.set_gemv_variant(ops.GEMV_DEFAULT_VARIANT)
     w = w_row
     ref, atol = _ref_linear(x, w, b, with_atol=True)
     assert_bf16_close(got, ref, f"gemv[{M}x{N}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)

@@ -39,7 +39,7 @@ def time_gemv(M, N, K, packed, variant, mode, iters=40):
         e1.record()
         e1.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
-    ops.set_gemv_variant(0)
+    ops.set_gemv_variant(ops.GEMV_DEFAULT_VARIANT)
     ts.sort()
     med = ts[len(ts) // 2]
     gb = N * K * 2 / 1e9
