@@ -90,10 +90,11 @@ int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_partial, int 
                             const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* tok_pos,
                             const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer, void* q_out, int S,
                             int n_q_heads, void* stream);
-/* Qwen2VLAttention core (Q2VL:537-556): causal GQA over the in-place cache */
+/* Qwen2VLAttention core (Q2VL:537-556): causal GQA over the in-place cache.  A tile = up to tile_rows (16 or 32)
+ * consecutive new rows of one stream: slot, first row in q, valid rows, cache index of the first row. */
 int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0,
                           const int32_t* tile_nq, const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay,
-                          int layer, int n_tiles, int n_q_heads, void* stream);
+                          int layer, int n_tiles, int n_q_heads, int tile_rows, void* stream);
 /* decode: row b belongs to slot slots[b]; attends to kv_len[slot]+1 keys (its own K/V already appended) */
 int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
                          lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream);

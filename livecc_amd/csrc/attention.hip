@@ -313,28 +313,47 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
   }
 }
 
-// grid = (Hq, B), 128 threads: thread d merges the splits of one head.
-__global__ __launch_bounds__(128) void attn_decode_combine_kernel(
+// grid = (Hq, B), 256 threads = 8 split groups x 32 lanes (4 consecutive d each).  Group q merges splits q, q+8, ...
+// with all its loads in flight at once; the 8 partial (m, num, den) triples are merged through LDS.
+__global__ __launch_bounds__(256) void attn_decode_combine_kernel(
     const float* __restrict__ ws_o, const float* __restrict__ ws_ml, bf16_t* __restrict__ out, int n_q_heads,
     int n_kv_heads, int nsplit) {
-  constexpr int D = 128;
-  const int hq = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  constexpr int D = 128, NG = 8;
+  __shared__ float sm[NG][32][6];
+  const int hq = blockIdx.x, b = blockIdx.y, t = threadIdx.x, dl = t & 31, grp = t >> 5;
   const int G = n_q_heads / n_kv_heads, hk = hq / G, j = hq % G;
   const size_t slot0 = (((size_t)b * n_kv_heads + hk) * nsplit) * 16 + j;
-  // single pass with online rescaling: the loads of all splits are independent (8 in flight), only the scalar chain is serial
-  float M = -INFINITY, num = 0.f, den = 0.f;
+  float M = -INFINITY, den = 0.f;
+  f32x4 num = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-  for (int s = 0; s < nsplit; ++s) {
+  for (int s = grp; s < nsplit; s += NG) {
     const size_t slot = slot0 + (size_t)s * 16;
-    const float m = ws_ml[slot * 2], l = ws_ml[slot * 2 + 1], o = ws_o[slot * D + d];
+    const float m = ws_ml[slot * 2], l = ws_ml[slot * 2 + 1];
+    const f32x4 o = *reinterpret_cast<const f32x4*>(ws_o + slot * D + dl * 4);
     const float Mn = fmaxf(M, m);
-    const float a = (M == -INFINITY) ? 0.f : exp2f(M - Mn);     // rescale of what was accumulated so far
+    const float a = (M == -INFINITY) ? 0.f : exp2f(M - Mn);
     const float w = (m == -INFINITY) ? 0.f : exp2f(m - Mn);
-    num = num * a + w * o;
+    num = num * a + o * w;
     den = den * a + w * l;
     M = Mn;
   }
-  out[((size_t)b * n_q_heads + hq) * D + d] = f2bf(num / den);
+  sm[grp][dl][0] = M; sm[grp][dl][1] = den;
+  sm[grp][dl][2] = num[0]; sm[grp][dl][3] = num[1]; sm[grp][dl][4] = num[2]; sm[grp][dl][5] = num[3];
+  __syncthreads();
+  if (grp != 0) return;
+  float MM = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < NG; ++q) MM = fmaxf(MM, sm[q][dl][0]);
+  float dd = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+#pragma unroll
+  for (int q = 0; q < NG; ++q) {
+    const float m = sm[q][dl][0];
+    const float w = (m == -INFINITY) ? 0.f : exp2f(m - MM);
+    dd += w * sm[q][dl][1];
+    n0 += w * sm[q][dl][2]; n1 += w * sm[q][dl][3]; n2 += w * sm[q][dl][4]; n3 += w * sm[q][dl][5];
+  }
+  const float inv = 1.f / dd;
+  st8(out + ((size_t)b * n_q_heads + hq) * D + dl * 4, (u32x2){pack2(n0 * inv, n1 * inv), pack2(n2 * inv, n3 * inv)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,11 +373,15 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
 
 int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0,
                       const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
-                      int layer, int n_tiles, int n_q_heads, hipStream_t st) {
+                      int layer, int n_tiles, int n_q_heads, int tile_rows, hipStream_t st) {
   if (n_tiles <= 0) return 0;
-  if (lay.head_dim != 128 || (lay.lmax & 31)) return LCC_ERR_SHAPE;
-  attn_prefill_kernel<2><<<dim3((n_tiles + 3) / 4, n_q_heads), dim3(256), 0, st>>>(
-      q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128));
+  if (lay.head_dim != 128 || (lay.lmax & 31) || (tile_rows != 16 && tile_rows != 32)) return LCC_ERR_SHAPE;
+  if (tile_rows == 32)
+    attn_prefill_kernel<2><<<dim3((n_tiles + 3) / 4, n_q_heads), dim3(256), 0, st>>>(
+        q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128));
+  else  // few query rows (a streaming chunk against a long cache): 16-row tiles double the number of waves
+    attn_prefill_kernel<1><<<dim3((n_tiles + 3) / 4, n_q_heads), dim3(256), 0, st>>>(
+        q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128));
   return 0;
 }
 
@@ -368,7 +391,7 @@ int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const i
   if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
   attn_decode_kernel<<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
       q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128));
-  attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
+  attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(256), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
                                                                        lay.n_kv_heads, nsplit);
   return 0;
 }

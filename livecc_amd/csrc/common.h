@@ -90,6 +90,7 @@ enum Epilogue : int {
   EPI_GELU_ERF = 2,    // C = gelu(bf16(acc + bias))
   EPI_RESIDUAL = 3,    // C = bf16(residual + bf16(acc + bias))
   EPI_SWIGLU = 4,      // W rows interleaved [16 gate | 16 up]; C[:, n/2] = bf16(silu(bf16 g) * bf16 u)
+  EPI_PARTIAL = 5,     // internal: raw fp32 split-K slab [split][M][N] (consumer reduces, adds bias, rounds)
 };
 
 }  // namespace lcc

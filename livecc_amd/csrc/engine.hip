@@ -138,7 +138,7 @@ size_t lcc_engine::llm_ws_bytes() const {
   t += align_up(S * qd * 2) * 2;             // q, attn
   t += align_up(S * I * 2);                  // act
   t += align_up(S * 64 * 2) * 2;             // cos, sin
-  t += align_up((size_t)MAX_SPLIT * 16 * std::max<size_t>(qkvd, H) * 4);  // split-K slabs
+  t += align_up(std::max((size_t)MAX_SPLIT * 16 * std::max<size_t>(qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H) * 4);  // split-K slabs
   t += align_up(B * H * 2) * 2;              // last_h, last_xn
   t += align_up(B * V * 2);                  // logits
   t += align_up(B * c.n_kv_heads * 64 * 16 * 128 * 4) + align_up(B * c.n_kv_heads * 64 * 16 * 2 * 4);  // decode attn ws
@@ -214,7 +214,7 @@ extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
 extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->lay.total() * 2; }
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
   const size_t S = e->lim.max_new_rows, P = e->lim.max_patches, B = e->lim.max_slots;
-  const size_t llm = (7 * S + 4 * (S / 32 + B + 1) + 4 * B + 64) * 4;
+  const size_t llm = (7 * S + 4 * (S / 16 + B + 1) + 4 * B + 64) * 4;
   const size_t vit = (P + 5 * (P / 16 + 64) + 64) * 4;
   return align_up(std::max(llm, vit) + 4096, 4096) * META_RING;
 }
@@ -486,7 +486,7 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
   b->h = cv.take<bf16_t>(S * H); b->xn = cv.take<bf16_t>(S * H); b->qkv = cv.take<bf16_t>(S * e->qkvd);
   b->q = cv.take<bf16_t>(S * e->qd); b->attn = cv.take<bf16_t>(S * e->qd); b->act = cv.take<bf16_t>(S * I);
   b->cos = cv.take<bf16_t>(S * 64); b->sin = cv.take<bf16_t>(S * 64);
-  b->partial = cv.take<float>((size_t)MAX_SPLIT * 16 * std::max<size_t>(e->qkvd, H));
+  b->partial = cv.take<float>(std::max((size_t)MAX_SPLIT * 16 * std::max<size_t>(e->qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H));
   b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H); b->logits = cv.take<bf16_t>(B * V);
   b->ws_o = cv.take<float>(B * e->c.n_kv_heads * 64 * 16 * 128); b->ws_ml = cv.take<float>(B * e->c.n_kv_heads * 64 * 16 * 2);
   if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small");
@@ -498,7 +498,7 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
 struct LayerCtx {
   int S; bool skinny;
   const int32_t *tok_stream, *tok_pos;          // prefill: explicit positions; decode: tok_pos == nullptr
-  const int32_t *tile_stream, *tile_q0, *tile_nq, *tile_pos0; int n_tiles;  // prefill attention tiles
+  const int32_t *tile_stream, *tile_q0, *tile_nq, *tile_pos0; int n_tiles, tile_rows;  // prefill attention tiles
   const int32_t* slots; int B; int nsplit_attn;  // decode attention
 };
 int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream_t st) {
@@ -507,6 +507,9 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
   const int sp_qkv = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(e->qkvd, H)) : 0;
   const int sp_o = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(H, e->qd)) : 0;
   const int sp_dn = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(H, I)) : 0;
+  // prefill with few output tiles (N = hidden): split-K slabs, reduced by the fused residual-add + RMSNorm kernel
+  const int tp_o = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, e->qd);
+  const int tp_dn = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, I);
   LCC_TRY(rmsnorm_bf16(b.h, e->llm[0].in_norm, b.xn, S, H, eps, st));
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
@@ -531,13 +534,17 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
                                b.ws_o, b.ws_ml, st));
     else
       LCC_TRY(attn_prefill_bf16(b.q, b.attn, cx.tile_stream, cx.tile_q0, cx.tile_nq, cx.tile_pos0, e->d_kv_base, e->lay, l,
-                                cx.n_tiles, e->c.n_q_heads, st));
+                                cx.n_tiles, e->c.n_q_heads, cx.tile_rows, st));
     // o_proj + residual + post-attention RMSNorm
     g = GemmArgs(); g.w_packed = 1; g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
     if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_o;
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, sp_o, L.post_norm, b.xn, S, H, eps, st));
+    } else if (tp_o > 1) {
+      g.partial = b.partial; g.nsplit = tp_o;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, tp_o, L.post_norm, b.xn, S, H, eps, st));
     } else {
       g.residual = b.h; g.ldr = H; g.C = b.h; g.ldc = H; g.epilogue = LCC_EPI_RESIDUAL;
       LCC_TRY(gemm_bf16(g, st));
@@ -555,6 +562,10 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       g.partial = b.partial; g.nsplit = sp_dn;
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, sp_dn, next_norm, b.xn, S, H, eps, st));
+    } else if (tp_dn > 1) {
+      g.partial = b.partial; g.nsplit = tp_dn;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, tp_dn, (l + 1 < e->c.n_layers) ? next_norm : nullptr, b.xn, S, H, eps, st));
     } else {
       g.residual = b.h; g.ldr = H; g.C = b.h; g.ldc = H; g.epilogue = LCC_EPI_RESIDUAL;
       LCC_TRY(gemm_bf16(g, st));
@@ -607,12 +618,14 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
 
   // host tables
   std::vector<int32_t> tok_stream(S), tok_pos(S), last_row(n_streams), tile_stream, tile_q0, tile_nq, tile_pos0;
+  // 32-row query tiles unless that leaves the GPU mostly idle (a 386-row chunk: 13 tiles x 28 heads = 364 waves)
+  const int tile_rows = ((long)((S + 31) / 32) * e->c.n_q_heads >= 2048) ? 32 : 16;
   int row = 0;
   for (int b = 0; b < n_streams; ++b) {
     const int past = e->h_kv_len[slots[b]];
     for (int i = 0; i < n_new[b]; ++i) { tok_stream[row + i] = slots[b]; tok_pos[row + i] = past + i; }
-    for (int q = 0; q < n_new[b]; q += 32) {
-      tile_stream.push_back(slots[b]); tile_q0.push_back(row + q); tile_nq.push_back(std::min(32, n_new[b] - q)); tile_pos0.push_back(past + q);
+    for (int q = 0; q < n_new[b]; q += tile_rows) {
+      tile_stream.push_back(slots[b]); tile_q0.push_back(row + q); tile_nq.push_back(std::min(tile_rows, n_new[b] - q)); tile_pos0.push_back(past + q);
     }
     row += n_new[b];
     last_row[b] = row - 1;
@@ -639,7 +652,7 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
 
   LayerCtx cx{};
   cx.S = S; cx.skinny = S <= 16; cx.tok_stream = d_tok_stream; cx.tok_pos = d_tok_pos;
-  cx.tile_stream = d_ts; cx.tile_q0 = d_tq; cx.tile_nq = d_tn; cx.tile_pos0 = d_tp; cx.n_tiles = n_tiles;
+  cx.tile_stream = d_ts; cx.tile_q0 = d_tq; cx.tile_nq = d_tn; cx.tile_pos0 = d_tp; cx.n_tiles = n_tiles; cx.tile_rows = tile_rows;
   cx.slots = d_slots; cx.B = n_streams; cx.nsplit_attn = 1;
   LCC_TRY(run_layers(e, bf, cx, st));
 
@@ -798,10 +811,10 @@ extern "C" int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_pa
 }
 extern "C" int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                                      const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay, int layer, int n_tiles,
-                                     int n_q_heads, void* stream) {
+                                     int n_q_heads, int tile_rows, void* stream) {
   if (!q || !out || !tile_stream || !tile_q0 || !tile_nq || !tile_pos0 || !kv_base) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(attn_prefill_bf16((const bf16_t*)q, (bf16_t*)out, tile_stream, tile_q0, tile_nq, tile_pos0, (bf16_t* const*)kv_base, to_lay(lay),
-                           layer, n_tiles, n_q_heads, (hipStream_t)stream), "lcc_attn_prefill_bf16");
+                           layer, n_tiles, n_q_heads, tile_rows, (hipStream_t)stream), "lcc_attn_prefill_bf16");
 }
 extern "C" int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
                                     lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream) {

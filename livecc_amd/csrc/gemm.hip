@@ -31,7 +31,8 @@ template <int BM, int EPI>
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
-    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, int w_packed) {
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, int w_packed,
+    float* __restrict__ partial, int kt_per_split) {
   constexpr int BN = 128, BK = 64;
   constexpr int WM = BM / 2;       // wave tile rows (of A)
   constexpr int MT = WM / 16;      // 16-row MFMA tiles per wave in M
@@ -103,15 +104,17 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     for (int i = 0; i < BI; ++i) s[boff[i]] = rb[i];
   };
 
-  const int nkt = (K + BK - 1) / BK;
-  gload(0);
+  // split-K (EPI_PARTIAL): blockIdx.y owns k-tiles [kt0, nkt)
+  const int kt0 = (EPI == EPI_PARTIAL) ? blockIdx.y * kt_per_split : 0;
+  const int nkt = (EPI == EPI_PARTIAL) ? min((K + BK - 1) / BK, kt0 + kt_per_split) : (K + BK - 1) / BK;
+  gload(kt0);
   sstore(0);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt0; kt < nkt; ++kt) {
     const bool more = kt + 1 < nkt;
     if (more) gload(kt + 1);
-    const u32x4* s = smem + (kt & 1) * STAGE;
+    const u32x4* s = smem + ((kt - kt0) & 1) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fa[MT], fb[NT];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
-    if (more) sstore((kt + 1) & 1);
+    if (more) sstore((kt + 1 - kt0) & 1);
     __syncthreads();
   }
 
@@ -140,7 +143,13 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * WM + i * 16 + li;
     if (m >= M) continue;
-    if (EPI == EPI_SWIGLU) {
+    if (EPI == EPI_PARTIAL) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + g * 4;
+        if (n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j];
+      }
+    } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
       for (int j = 0; j < NT; j += 2) {
         const int n = n0 + wn * 64 + j * 16 + g * 4;  // column in the interleaved [gate16|up16] space
@@ -187,8 +196,10 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
 template <int BM, int EPI>
 static void launch_tiled(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 127) / 128;
-  gemm_tiled_kernel<BM, EPI><<<dim3(tiles_m * tiles_n), dim3(256), 0, st>>>(
-      a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed);
+  const int nkt = (a.K + 63) / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
+  gemm_tiled_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), 0, st>>>(
+      a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
+      (nkt + S - 1) / S);
 }
 
 template <int EPI>
@@ -387,6 +398,15 @@ int gemv_num_splits(int N, int K) {
   return std::max(1, std::min(8, s));
 }
 
+// split-K factor for a tiled GEMM whose output grid alone cannot fill 256 CUs (e.g. M = 386, N = 3584: 196 tiles)
+int gemm_tiled_num_splits(int M, int N, int K) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
+  if (tiles >= 400 || M > 4096) return 1;
+  int s = (int)((640 + tiles - 1) / tiles);
+  s = std::min(s, std::max(1, ((K + 63) / 64) / 8));
+  return std::max(1, std::min(4, s));
+}
+
 int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
   if ((a.K & 7) || (a.N & 15) || (a.lda & 7) || (!a.w_packed && (a.ldw & 7)) || (a.ldc & 3)) return LCC_ERR_SHAPE;
@@ -408,7 +428,11 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
     }
     return 0;
   }
-  if (a.partial != nullptr) return LCC_ERR_ARG;  // partial slabs only exist on the skinny path
+  if (a.partial != nullptr) {   // split-K slabs on the tiled path (prefill GEMMs with few output tiles)
+    if (a.epilogue != EPI_NONE || a.nsplit < 1 || a.nsplit > 8 || a.nsplit > (a.K + 63) / 64) return LCC_ERR_ARG;
+    launch_tiled<64, EPI_PARTIAL>(a, st);
+    return 0;
+  }
   switch (a.epilogue) {
     case EPI_NONE: launch_tiled_bm<EPI_NONE>(a, st); break;
     case EPI_QUICK_GELU: launch_tiled_bm<EPI_QUICK_GELU>(a, st); break;

@@ -18,12 +18,13 @@ struct GemmArgs {
   const bf16_t* bias = nullptr;                 // [N] or null
   const bf16_t* residual = nullptr; int ldr = 0;
   bf16_t* C = nullptr; int ldc = 0;             // [M,N] (swiglu: [M,N/2])
-  float* partial = nullptr; int nsplit = 0;     // skinny path only: fp32 slabs [nsplit][M][N]
+  float* partial = nullptr; int nsplit = 0;     // fp32 split-K slabs [nsplit][M][N] instead of C (consumer reduces)
   int M = 0, N = 0, K = 0;
   int epilogue = 0;
 };
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
 int gemv_num_splits(int N, int K);
+int gemm_tiled_num_splits(int M, int N, int K);
 void set_gemv_variant(int v);
 int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
 
@@ -66,7 +67,7 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
                   int heads, int total_blocks, hipStream_t st);
 int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0,
                       const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
-                      int layer, int n_tiles, int n_q_heads, hipStream_t st);
+                      int layer, int n_tiles, int n_q_heads, int tile_rows, hipStream_t st);
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
                      KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
 

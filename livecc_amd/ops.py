@@ -221,20 +221,21 @@ def rope_kv_append(qkv: Optional[torch.Tensor], cos, sin, tok_stream, tok_pos, k
     return q
 
 
-def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tuple[int, int, int]], n_q_heads: int):
+def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tuple[int, int, int]], n_q_heads: int,
+                 tile_rows: int = 32):
     """segments: (slot, n_new, past_len) per stream, rows packed in that order."""
     ts, tq, tn, tp = [], [], [], []
     row = 0
     for slot, n_new, past in segments:
-        for o in range(0, n_new, 32):
-            ts.append(slot); tq.append(row + o); tn.append(min(32, n_new - o)); tp.append(past + o)
+        for o in range(0, n_new, tile_rows):
+            ts.append(slot); tq.append(row + o); tn.append(min(tile_rows, n_new - o)); tp.append(past + o)
         row += n_new
     dev = q.device
     out = torch.empty_like(q)
     a, b, c, d = _i32(ts, dev), _i32(tq, dev), _i32(tn, dev), _i32(tp, dev)
     _lib.check(_lib.load().lcc_attn_prefill_bf16(_chk(q, torch.bfloat16, "q"), out.data_ptr(), a.data_ptr(), b.data_ptr(),
                                                  c.data_ptr(), d.data_ptr(), kv.ptrs.data_ptr(), kv.lay, layer, len(ts),
-                                                 n_q_heads, _st(q)), "lcc_attn_prefill_bf16")
+                                                 n_q_heads, tile_rows, _st(q)), "lcc_attn_prefill_bf16")
     return out
 
 

@@ -120,6 +120,25 @@ def test_gemv_skinny(dev, M, N, K, packed, variant):
     assert err <= 2e-5 * float(ref.abs().max()) * math.sqrt(K / 256) + 1e-5, f"split-K slabs: {err}"
 
 
+@pytest.mark.parametrize("M,N,K,S", [(100, 512, 1024, 2), (386, 3584, 3584, 4), (70, 256, 640, 3)])
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemm_tiled_splitk_slabs(dev, M, N, K, S, packed):
+    """prefill split-K: fp32 slabs [S][M][N] whose sum is the product (reduced by add_rmsnorm in the engine)."""
+    from livecc_amd import ops
+    x, w = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2)
+    part = ops.linear_partial(x, ops.pack_weight(w) if packed else w, S, packed_shape=(N, K) if packed else None)
+    ref = x.float() @ w.float().t()
+    err = (part.sum(0) - ref).abs().max().item()
+    assert err <= 2e-5 * float(ref.abs().max()) * math.sqrt(K / 256) + 1e-5, f"split-K slabs: {err}"
+    h = _rand((M, N), dev, 1.0, 3)
+    wn = _rand((N,), dev, 1.0, 4)
+    h2 = h.clone()
+    y = ops.add_rmsnorm_(h2, wn, 1e-6, partial=part)
+    h_ref = rb(h.float() + rb(part.sum(0)))
+    assert_bf16_close(h2, h_ref, f"splitk_add[{M}x{N}x{K}]", 1.0, 5e-3, atol=32 * 2.0 ** -24 * (x.float().abs() @ w.float().abs().t()))
+    assert_bf16_close(y, _ref_rmsnorm(h2, wn, 1e-6), f"splitk_add_rmsnorm[{M}x{N}x{K}]", 1.0, 5e-3)
+
+
 @pytest.mark.parametrize("M", [1, 7, 16])
 @pytest.mark.parametrize("packed", [False, True])
 def test_gemv_swiglu(dev, M, packed):
@@ -315,9 +334,10 @@ def test_rope_append_prefill_decode_attention(dev, Hq, Hkv):
         K, V = torch.cat(k_all), torch.cat(v_all)
         assert torch.equal(kv.k_view(slot, layer)[:, :past + S].float(), K.transpose(0, 1)), "K cache append"
         assert torch.equal(kv.v_view(slot, layer)[:, :past + S].float(), V.transpose(0, 1)), "V cache append (blocked-transposed)"
-        got = ops.attn_prefill(q_got, kv, layer, [(slot, S, past)], Hq)
         ref = _ref_attn_causal(q_ref, K, V, past)
-        _check_attn(got.view(S, Hq, D), rb(ref), f"attn_prefill[Hq{Hq},turn{turn}]")
+        for tr in (32, 16):
+            got = ops.attn_prefill(q_got, kv, layer, [(slot, S, past)], Hq, tile_rows=tr)
+            _check_attn(got.view(S, Hq, D), rb(ref), f"attn_prefill[Hq{Hq},turn{turn},rows{tr}]")
         past += S
     # decode: one new token, appended at kv_len through the device counter path, several split counts
     qkv = _rand((1, qkv_dim), dev, 1.0, 99)
