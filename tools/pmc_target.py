@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""Target of the rocprofv3 PMC passes (tools/run_profiles.sh): launches ONLY the dominant kernel of the bench -- the decode
+gate/up weight-streaming GEMV at LiveCC-7B shapes (packed weights, M = 1) -- a few times over rotating weight buffers
+(> 256 MiB Infinity Cache in total), so that the per-dispatch FETCH_SIZE / WRITE_SIZE counters can be read per launch."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from livecc_amd import ops  # noqa: E402
+
+H, I = 3584, 18944
+dev = torch.device("cuda:0")
+ws = [(torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
+x = torch.randn(1, H, device=dev).to(torch.bfloat16)
+for i in range(12):
+    ops.linear(x, ws[i % 3], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
+torch.cuda.synchronize()
+print("ok")

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the MI355X box (via gpurun): rocprofv3 kernel stats of the bench + separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the
+# dominant kernel.  Only the small summary CSVs are kept under gpurun_out/ (the kernel traces are tens of MB).
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+TAG=${1:-r01}
+export TMPDIR=/tmp
+cd /tmp
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 1 --warmup 1 --cpu-baseline off > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+find $OUT/stats -name '*kernel_trace.csv' -delete
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o gemv -- python $R/tools/pmc_target.py > $OUT/pmc_$C.log 2>&1
+  find $OUT/pmc_$C -name '*kernel_trace.csv' -delete
+done
+python $R/tools/summarize_pmc.py $OUT > $OUT/roofline_traffic.json 2> $OUT/summarize.err
+cat $OUT/roofline_traffic.json
+ls -R $OUT | head -40
