@@ -742,6 +742,7 @@ static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_hea
   } while (0)
 
 extern "C" int lcc_debug_set_gemv_variant(int variant) { set_gemv_variant(variant); return 0; }
+extern "C" int lcc_debug_set_gemm_variant(int variant) { set_gemm_variant(variant); return 0; }
 extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual,
                              int ldr, void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {
   if (!A || !W || (!C && !partial)) return fail(LCC_ERR_ARG, "lcc_gemm_bf16: null pointer");

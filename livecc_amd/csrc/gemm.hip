@@ -22,7 +22,66 @@
 
 namespace lcc {
 
-__device__ unsigned int lcc_zero_page[64];  // 256 zero bytes: operand source of absent K chunks (address select, no branch)
+__device__ unsigned int lcc_zero_page[256];  // 1 KB of zeros: operand source of absent K chunks (address select, no branch)
+
+// epilogue shared by the tiled kernels.  acc[i][j][r] = C[mbase + i*16 + li][nbase + j*16 + g*4 + r] (swapped operands).
+template <int EPI, int MT, int NT>
+LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int ocbase, int li, int g,
+                              const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+                              bf16_t* __restrict__ C, int ldc, int M, int N, float* __restrict__ partial) {
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mbase + i * 16 + li;
+    if (m >= M) continue;
+    if (EPI == EPI_PARTIAL) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        if (n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j];
+      }
+    } else if (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        const int n = nbase + j * 16 + g * 4;  // column in the interleaved [gate16|up16] space
+        if (n >= N) continue;
+        const int oc = ocbase + (j / 2) * 16 + g * 4;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float gate = rbf(acc[i][j][r]), up = rbf(acc[i][j + 1][r]);
+          o[r] = silu_bf16(gate) * up;
+        }
+        st8(C + (size_t)m * ldc + oc, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = nbase + j * 16 + g * 4;
+        if (n >= N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (bias != nullptr) {
+          u32x2 b = ld8(bias + n);
+          v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        if (EPI == EPI_QUICK_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = quick_gelu_bf16(v[r]);
+        } else if (EPI == EPI_GELU_ERF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf_bf16(v[r]);
+        } else if (EPI == EPI_RESIDUAL) {
+          u32x2 q = ld8(residual + (size_t)m * ldr + n);
+          v[0] += lo2f(q.x); v[1] += hi2f(q.x); v[2] += lo2f(q.y); v[3] += hi2f(q.y);
+        }
+        st8(C + (size_t)m * ldc + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // tiled GEMM
@@ -138,65 +197,143 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     __syncthreads();
   }
 
-  // epilogue: lane owns C[m][n..n+3], m = .. + li, n = .. + g*4
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiled GEMM v2: LDS-DMA (global_load_lds, 16 B/lane) into a 3-stage LDS ring, counted vmcnt, raw s_barrier
+// ------------------------------------------------------------------------------------------------
+// Both operands live in LDS in MFMA FRAGMENT ORDER: a 1-KB sub-tile = (16 rows, 32 k) as [4 g][16 rows][8 k], i.e. exactly
+// the 64 lanes' 16-byte operands in lane order.  global_load_lds writes wave-uniform-base + lane*16, so one DMA instruction
+// fills one sub-tile, and the fragment read is a linear, conflict-free ds_read_b128 (lane reads slot `lane`).  With packed
+// weights the W sub-tile is also contiguous in HBM (one 1-KB burst per instruction); row-major operands (activations, or
+// an unpacked W) are gathered as 16 rows x 64 B by the per-lane source addresses.
+// Pipeline per k-tile:  wait(tile kt landed, leave tile kt+1 in flight) -> s_barrier -> issue DMA of tile kt+2 into the
+// stage that was consumed in iteration kt-1 -> MFMAs of tile kt.   No VGPR staging, no ds_write.
+template <int BM, int EPI>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, int w_packed,
+    float* __restrict__ partial, int kt_per_split) {
+  constexpr int BN = 128, BK = 64, NSTAGE = 3;
+  constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
+  constexpr int A_SUB = (BM / 16) * 2;          // 1-KB sub-tiles of the A tile (row tiles x 2 k-blocks)
+  constexpr int B_SUB = (BN / 16) * 2;
+  constexpr int STAGE = (A_SUB + B_SUB) * 64;   // 16-byte units per stage
+  constexpr int A_PER_WAVE = A_SUB / 4, B_PER_WAVE = B_SUB / 4;
+  constexpr int G = A_PER_WAVE + B_PER_WAVE;    // DMA instructions per wave (= per thread) per k-tile
+  extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
+
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, g = lane >> 4;
+  const int K32 = (K + 31) >> 5;
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page) + lane * 8;
+
+  // per-lane source pointers of this wave's sub-tiles at k-block 0 (advanced by kb*kstep per k-block)
+  const bf16_t* asrc[A_PER_WAVE];
+  const bf16_t* bsrc[B_PER_WAVE];
+  int akb[A_PER_WAVE], bkb[B_PER_WAVE];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * WM + i * 16 + li;
-    if (m >= M) continue;
-    if (EPI == EPI_PARTIAL) {
+  for (int q = 0; q < A_PER_WAVE; ++q) {
+    const int st = wave * A_PER_WAVE + q, rt = st >> 1;
+    akb[q] = st & 1;
+    asrc[q] = A + (size_t)min(m0 + rt * 16 + li, M - 1) * lda + g * 8;
+  }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + g * 4;
-        if (n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j];
-      }
-    } else if (EPI == EPI_SWIGLU) {
+  for (int q = 0; q < B_PER_WAVE; ++q) {
+    const int st = wave * B_PER_WAVE + q, rt = st >> 1;
+    bkb[q] = st & 1;
+    const int row = min(n0 + rt * 16 + li, N - 1);
+    bsrc[q] = w_packed ? W + (size_t)(row >> 4) * K32 * 512 + lane * 8 : W + (size_t)row * ldw + g * 8;
+  }
+  const int bstep = w_packed ? 512 : 32;   // elements per 32-k block
+
+  auto issue = [&](int kt, int stage) {
+    u32x4* sbase = dsmem + stage * STAGE;
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        const int n = n0 + wn * 64 + j * 16 + g * 4;  // column in the interleaved [gate16|up16] space
-        if (n >= N) continue;
-        const int oc = (n0 + wn * 64) / 2 + (j / 2) * 16 + g * 4;
-        float o[4];
+    for (int q = 0; q < A_PER_WAVE; ++q) {
+      const int kb = kt * 2 + akb[q];
+      const bf16_t* src = (kb * 32 + g * 8 < K) ? asrc[q] + kb * 32 : zp;   // A: K % 8 == 0, chunk inside or outside
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gate = rbf(acc[i][j][r]), up = rbf(acc[i][j + 1][r]);
-          o[r] = silu_bf16(gate) * up;
-        }
-        st8(C + (size_t)m * ldc + oc, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
-      }
+    for (int q = 0; q < B_PER_WAVE; ++q) {
+      const int kb = kt * 2 + bkb[q];
+      const bool ok = w_packed ? (kb < K32) : (kb * 32 + g * 8 < K);
+      const bf16_t* src = ok ? bsrc[q] + (size_t)kb * bstep : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (A_SUB + wave * B_PER_WAVE + q) * 64), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int kt0 = (EPI == EPI_PARTIAL) ? blockIdx.y * kt_per_split : 0;
+  const int nkt = (EPI == EPI_PARTIAL) ? min((K + BK - 1) / BK, kt0 + kt_per_split) : (K + BK - 1) / BK;
+  issue(kt0, 0);
+  if (kt0 + 1 < nkt) issue(kt0 + 1, 1);
+
+  for (int kt = kt0; kt < nkt; ++kt) {
+    // tile kt landed (this wave's pieces); the G DMAs of tile kt+1 may stay in flight across the barrier
+    if (kt + 1 < nkt) {
+      if (G == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile kt are in LDS; everyone finished reading tile kt-1
+    if (kt + 2 < nkt) issue(kt + 2, (kt + 2 - kt0) % NSTAGE);
+    const u32x4* s = dsmem + ((kt - kt0) % NSTAGE) * STAGE;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + g * 4;
-        if (n >= N) continue;
-        float v[4];
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[MT], fb[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        if (bias != nullptr) {
-          u32x2 b = ld8(bias + n);
-          v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
-        }
+      for (int i = 0; i < MT; ++i) fa[i] = as_bf16x8(s[((wm * MT + i) * 2 + kk) * 64 + lane]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-        if (EPI == EPI_QUICK_GELU) {
+      for (int j = 0; j < NT; ++j) fb[j] = as_bf16x8(s[(A_SUB + (wn * NT + j) * 2 + kk) * 64 + lane]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = quick_gelu_bf16(v[r]);
-        } else if (EPI == EPI_GELU_ERF) {
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf_bf16(v[r]);
-        } else if (EPI == EPI_RESIDUAL) {
-          u32x2 q = ld8(residual + (size_t)m * ldr + n);
-          v[0] += lo2f(q.x); v[1] += hi2f(q.x); v[2] += lo2f(q.y); v[3] += hi2f(q.y);
-        }
-        st8(C + (size_t)m * ldc + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
-      }
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
   }
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
 }
+
+static int g_gemm_variant = 1;  // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel
+void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 template <int BM, int EPI>
 static void launch_tiled(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 127) / 128;
   const int nkt = (a.K + 63) / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
+  if (g_gemm_variant == 1) {
+    constexpr size_t lds = (size_t)3 * ((BM / 16) * 2 + 16) * 1024;   // 96 KB (BM 128) / 72 KB (BM 64)
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    gemm_glds_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), lds, st>>>(
+        a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
+        (nkt + S - 1) / S);
+    return;
+  }
   gemm_tiled_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), 0, st>>>(
       a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
       (nkt + S - 1) / S);

@@ -26,6 +26,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st);
 int gemv_num_splits(int N, int K);
 int gemm_tiled_num_splits(int M, int N, int K);
 void set_gemv_variant(int v);
+void set_gemm_variant(int v);
 int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
 
 // ---- elementwise / normalisation / layout (elementwise.hip) ----

@@ -75,6 +75,13 @@ def set_gemv_variant(v: int) -> None:
     _lib.load().lcc_debug_set_gemv_variant(int(v))
 
 
+GEMM_DEFAULT_VARIANT = 1
+
+
+def set_gemm_variant(v: int) -> None:
+    _lib.load().lcc_debug_set_gemm_variant(int(v))
+
+
 def gemv_num_splits(N: int, K: int) -> int:
     return _lib.load().lcc_gemv_num_splits(N, K)
 

@@ -64,21 +64,32 @@ def _ref_linear(x, w, bias=None, epi=0, residual=None, with_atol=False):
                                    (17, 256, 512), (300, 4608, 3584)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("packed", [False, True])
-def test_gemm_tiled(dev, M, N, K, epi, packed):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
+    """variant 0: register-staged 2-stage kernel; 1: LDS-DMA (global_load_lds) 3-stage ring (default)."""
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
     res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
-    got = ops.linear(x, ops.pack_weight(w), b, epi, res, packed_shape=(N, K)) if packed else ops.linear(x, w, b, epi, res)
+    ops.set_gemm_variant(variant)
+    try:
+        got = ops.linear(x, ops.pack_weight(w), b, epi, res, packed_shape=(N, K)) if packed else ops.linear(x, w, b, epi, res)
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     ref, atol = _ref_linear(x, w, b, epi, res, with_atol=True)
     assert_bf16_close(got, ref, f"gemm_tiled[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
 @pytest.mark.parametrize("M,I,K", [(100, 512, 256), (386, 2432, 896)])
 @pytest.mark.parametrize("packed", [False, True])
-def test_gemm_tiled_swiglu(dev, M, I, K, packed):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
     from livecc_amd import ops
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
-    got = ops.linear(x, ops.pack_weight(w), None, ops.EPI_SWIGLU, packed_shape=(2 * I, K)) if packed else ops.linear(x, w, None, ops.EPI_SWIGLU)
+    ops.set_gemm_variant(variant)
+    try:
+        got = ops.linear(x, ops.pack_weight(w), None, ops.EPI_SWIGLU, packed_shape=(2 * I, K)) if packed else ops.linear(x, w, None, ops.EPI_SWIGLU)
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     ref, atol = _ref_linear(x, w, None, 4, with_atol=True)
     assert_bf16_close(got, ref, f"gemm_tiled_swiglu[{M}x{I}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
@@ -122,11 +133,16 @@ def test_gemv_skinny(dev, M, N, K, packed, variant):
 
 @pytest.mark.parametrize("M,N,K,S", [(100, 512, 1024, 2), (386, 3584, 3584, 4), (70, 256, 640, 3)])
 @pytest.mark.parametrize("packed", [False, True])
-def test_gemm_tiled_splitk_slabs(dev, M, N, K, S, packed):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_tiled_splitk_slabs(dev, M, N, K, S, packed, variant):
     """prefill split-K: fp32 slabs [S][M][N] whose sum is the product (reduced by add_rmsnorm in the engine)."""
     from livecc_amd import ops
     x, w = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2)
-    part = ops.linear_partial(x, ops.pack_weight(w) if packed else w, S, packed_shape=(N, K) if packed else None)
+    ops.set_gemm_variant(variant)
+    try:
+        part = ops.linear_partial(x, ops.pack_weight(w) if packed else w, S, packed_shape=(N, K) if packed else None)
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     ref = x.float() @ w.float().t()
     err = (part.sum(0) - ref).abs().max().item()
     assert err <= 2e-5 * float(ref.abs().max()) * math.sqrt(K / 256) + 1e-5, f"split-K slabs: {err}"

@@ -47,7 +47,51 @@ def time_gemv(M, N, K, packed, variant, mode, iters=40):
                 us_median=round(med, 2), us_min=round(ts[0], 2), TBps_median=round(gb / med * 1e3, 3), TBps_best=round(gb / ts[0] * 1e3, 3))
 
 
+def time_gemm(M, N, K, epi, variant, iters=20):
+    dev = torch.device("cuda:0")
+    nbuf = 3
+    ws = [ops.pack_weight((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(nbuf)]
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == ops.EPI_RESIDUAL else None
+    ops.set_gemm_variant(variant)
+    S = 0
+    if epi == "partial":
+        S = 4
+
+    def run(w):
+        if epi == "partial":
+            return ops.linear_partial(x, w, S, packed_shape=(N, K))
+        return ops.linear(x, w, None, epi, res, packed_shape=(N, K))
+
+    for w in ws:
+        run(w)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        run(ws[i % nbuf])
+    e1.record()
+    e1.synchronize()
+    ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    return dict(kernel="gemm_tiled", M=M, N=N, K=K, epi=str(epi), variant=variant, us=round(us, 1),
+                TFLOPs=round(2.0 * M * N * K / us / 1e6, 1))
+
+
+def main_gemm():
+    H, I = 3584, 18944
+    cases = [(386, 2 * I, H, ops.EPI_SWIGLU), (386, 4608, H, ops.EPI_NONE), (386, H, H, "partial"), (386, H, I, "partial"),
+             (3088, 2 * I, H, ops.EPI_SWIGLU), (3088, H, I, ops.EPI_RESIDUAL), (3088, 4608, H, ops.EPI_NONE),
+             (1456, 3840, 1280, ops.EPI_NONE), (1456, 5120, 1280, ops.EPI_QUICK_GELU), (1456, 1280, 5120, ops.EPI_RESIDUAL),
+             (11648, 5120, 1280, ops.EPI_QUICK_GELU), (11648, 1280, 5120, ops.EPI_RESIDUAL)]
+    for M, N, K, epi in cases:
+        for variant in (0, 1):
+            print(json.dumps(time_gemm(M, N, K, epi, variant)), flush=True)
+
+
 def main():
+    if "--gemm" in sys.argv:
+        return main_gemm()
     H, I, V, QKV = 3584, 18944, 152064, 4608
     cases = [("swiglu", 2 * I, H), ("partial", QKV, H), ("partial", H, H), ("partial", H, I), ("plain", V, H)]
     Ms = [1] if "--quick" in sys.argv else [1, 8]
