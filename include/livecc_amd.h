@@ -56,7 +56,7 @@ int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, 
                   void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream);
 /* tuning knob of the skinny kernel (0: 2 chunks single stage, 1: 1-chunk two-stage pipeline, 2: 2-chunk two-stage) */
 int lcc_debug_set_gemv_variant(int variant);
-/* tiled kernel: 0 = register-staged double-buffered LDS, 1 = LDS-DMA (global_load_lds) 3-stage ring (default) */
+/* tiled kernel: 0 = register-staged double-buffered LDS, 1 = LDS-DMA (global_load_lds) 3-stage ring, 2 = per tile shape (default) */
 int lcc_debug_set_gemm_variant(int variant);
 int lcc_gemv_num_splits(int N, int K);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */

@@ -118,6 +118,32 @@ LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (
     for (int n = 0; n < NQ; ++n) acc.o[dt][n] = mfma16(as_bf16x8(vf[dt]), pf[n], acc.o[dt][n]);
 }
 
+// key-tile loop [t0, t1) with a two-tile register ring: while tile t is multiplied the loads of tile t+1 are already in
+// flight and those of tile t+2 are issued right after tile t's operands are consumed.  All loads are unconditional
+// (tile index clamped to t1-1, so a re-load of the last tile may be issued and ignored): straight-line code, counted waits.
+template <int D, int NQ, class KRow, class VBlk>
+LCC_DEVICE void attn_loop(AttnAcc<D, NQ>& acc, KRow krow, VBlk vblk, int t0, int t1, const u32x4 (&qf)[NQ][(D + 31) / 32],
+                          int li, int g, const int (&key_limit)[NQ], float scale_log2e) {
+  if (t0 >= t1) return;
+  const int tl = t1 - 1;
+  KFrag<D> ka, kb;
+  u32x4 va[D / 16], vb[D / 16];
+  load_k<D>(ka, krow, t0 * 32, li, g);
+  load_v<D>(va, vblk(t0), li, g);
+  load_k<D>(kb, krow, min(t0 + 1, tl) * 32, li, g);
+  load_v<D>(vb, vblk(min(t0 + 1, tl)), li, g);
+  for (int t = t0; t < t1; t += 2) {
+    attn_tile<D, NQ>(acc, ka, va, qf, t * 32, g, key_limit, scale_log2e);
+    load_k<D>(ka, krow, min(t + 2, tl) * 32, li, g);
+    load_v<D>(va, vblk(min(t + 2, tl)), li, g);
+    if (t + 1 < t1) {
+      attn_tile<D, NQ>(acc, kb, vb, qf, (t + 1) * 32, g, key_limit, scale_log2e);
+      load_k<D>(kb, krow, min(t + 3, tl) * 32, li, g);
+      load_v<D>(vb, vblk(min(t + 3, tl)), li, g);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ViT attention: non-causal inside each temporal slice (segment).  grid = (ceil(n_tiles/4), heads),
 // 4 waves per block, one 32-query tile per wave.  qkv is the [P, 3*E] output of the qkv GEMM with q,k
@@ -157,16 +183,8 @@ __global__ __launch_bounds__(256) void attn_vit_kernel(
 
   AttnAcc<D, NQ> acc;
   acc.init();
-  KFrag<D> kf;
-  load_k<D>(kf, krow, 0, li, g);
-  const int ntile = (sl + 31) / 32;
-  for (int t = 0; t < ntile; ++t) {
-    u32x4 vf[D / 16];
-    load_v<D>(vf, vbase + (size_t)t * (D * 32), li, g);
-    KFrag<D> kcur = kf;
-    if (t + 1 < ntile) load_k<D>(kf, krow, (t + 1) * 32, li, g);
-    attn_tile<D, NQ>(acc, kcur, vf, qf, t * 32, g, key_limit, scale_log2e);
-  }
+  auto vblk = [&](int t) { return vbase + (size_t)t * (D * 32); };
+  attn_loop<D, NQ>(acc, krow, vblk, 0, (sl + 31) / 32, qf, li, g, key_limit, scale_log2e);
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float l = acc.l[n];
@@ -223,16 +241,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
 
   AttnAcc<D, NQ> acc;
   acc.init();
-  KFrag<D> kf;
-  load_k<D>(kf, krow, 0, li, g);
-  const int ntile = (kv_n + 31) / 32;
-  for (int t = 0; t < ntile; ++t) {
-    u32x4 vf[D / 16];
-    load_v<D>(vf, vbase + (size_t)t * (D * 32), li, g);
-    KFrag<D> kcur = kf;
-    if (t + 1 < ntile) load_k<D>(kf, krow, (t + 1) * 32, li, g);
-    attn_tile<D, NQ>(acc, kcur, vf, qf, t * 32, g, key_limit, scale_log2e);
-  }
+  auto vblk = [&](int t) { return vbase + (size_t)t * (D * 32); };
+  attn_loop<D, NQ>(acc, krow, vblk, 0, (kv_n + 31) / 32, qf, li, g, key_limit, scale_log2e);
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float l = acc.l[n];
@@ -287,17 +297,8 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
 
   AttnAcc<D, NQ> acc;
   acc.init();
-  if (t0 < t1) {
-    KFrag<D> kf;
-    load_k<D>(kf, krow, t0 * 32, li, g);
-    for (int t = t0; t < t1; ++t) {
-      u32x4 vf[D / 16];
-      load_v<D>(vf, vbase + (size_t)t * (D * 32), li, g);
-      KFrag<D> kcur = kf;
-      if (t + 1 < t1) load_k<D>(kf, krow, (t + 1) * 32, li, g);
-      attn_tile<D, NQ>(acc, kcur, vf, qf, t * 32, g, key_limit, scale_log2e);
-    }
-  }
+  auto vblk = [&](int t) { return vbase + (size_t)t * (D * 32); };
+  attn_loop<D, NQ>(acc, krow, vblk, t0, t1, qf, li, g, key_limit, scale_log2e);
   float l = acc.l[0];
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);

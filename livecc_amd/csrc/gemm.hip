@@ -315,14 +315,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
   tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
 }
 
-static int g_gemm_variant = 1;  // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel
+// 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel; 2 (default): measured best per tile shape --
+// 64-row tiles (72 KB ring, 2 blocks/CU) take the LDS-DMA kernel (1.5-1.6x), 128-row tiles keep the register-staged
+// kernel (64 KB, 2 blocks/CU; the 96 KB ring would leave 1 block/CU and measured 0.75x).
+static int g_gemm_variant = 2;
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 template <int BM, int EPI>
 static void launch_tiled(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 127) / 128;
   const int nkt = (a.K + 63) / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  if (g_gemm_variant == 1) {
+  if (g_gemm_variant == 1 || (g_gemm_variant == 2 && BM == 64)) {
     constexpr size_t lds = (size_t)3 * ((BM / 16) * 2 + 16) * 1024;   // 96 KB (BM 128) / 72 KB (BM 64)
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -341,9 +344,10 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI>
 static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
-  // small problems: 64-row tiles waste less of a ragged M and give >= ~2 blocks per CU sooner
+  // 128-row tiles only for large M with a grid that fills the chip; otherwise 64-row tiles (less waste on a ragged M such as
+  // 386 rows, more blocks, and the faster LDS-DMA kernel)
   const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (blocks128 >= 512) launch_tiled<128, EPI>(a, st);
+  if (a.M >= 1024 && blocks128 >= 512) launch_tiled<128, EPI>(a, st);
   else launch_tiled<64, EPI>(a, st);
 }
 

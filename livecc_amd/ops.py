@@ -75,7 +75,7 @@ def set_gemv_variant(v: int) -> None:
     _lib.load().lcc_debug_set_gemv_variant(int(v))
 
 
-GEMM_DEFAULT_VARIANT = 1
+GEMM_DEFAULT_VARIANT = 2
 
 
 def set_gemm_variant(v: int) -> None:

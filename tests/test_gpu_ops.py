@@ -64,7 +64,7 @@ def _ref_linear(x, w, bias=None, epi=0, residual=None, with_atol=False):
                                    (17, 256, 512), (300, 4608, 3584)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
     """variant 0: register-staged 2-stage kernel; 1: LDS-DMA (global_load_lds) 3-stage ring (default)."""
     from livecc_amd import ops
