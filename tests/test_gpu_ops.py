@@ -427,3 +427,31 @@ def test_sampler_matches_hf_processors(dev):
                 sc = ThresholdLogitsProcessor(thr_tok, thr, 0.0)(hist[b].view(1, -1), sc)
             assert int(tok[b]) == int(sc.argmax()), f"token mismatch pen={pen} thr={thr} stream {b}"
             assert torch.allclose(scores[b].cpu(), sc[0], rtol=1e-6, atol=1e-6), "processed scores"
+
+
+def test_liger_style_plugin_patches_hf_modules(dev):
+    """apply_livecc_amd_kernel_to_qwen2_vl() rebinds the HF module names like liger does (ref demo/infer.py:2-3)."""
+    import transformers.models.qwen2_vl.modeling_qwen2_vl as m
+    from livecc_amd.config import tiny
+    from livecc_amd.plugin import apply_livecc_amd_kernel_to_qwen2_vl
+    saved = (m.Qwen2VLRMSNorm, m.LayerNorm, m.Qwen2MLP)
+    try:
+        ref_norm = m.Qwen2VLRMSNorm(256, eps=1e-6).to(dev, torch.bfloat16)
+        ref_norm.weight.data.copy_(_rand((256,), dev, 1.0, 1))
+        ref_mlp = m.Qwen2MLP(tiny().to_hf().text_config).to(dev, torch.bfloat16)
+        apply_livecc_amd_kernel_to_qwen2_vl()
+        assert m.Qwen2VLRMSNorm is not saved[0] and m.LayerNorm is not saved[1] and m.Qwen2MLP is not saved[2]
+        new_norm = m.Qwen2VLRMSNorm(256, eps=1e-6).to(dev, torch.bfloat16)
+        new_norm.load_state_dict(ref_norm.state_dict())
+        x = _rand((3, 7, 256), dev, 2.0, 2)
+        assert_bf16_close(new_norm(x), ref_norm(x), "plugin_rmsnorm", 1.0, 5e-3)
+        new_mlp = m.Qwen2MLP(tiny().to_hf().text_config).to(dev, torch.bfloat16)
+        new_mlp.load_state_dict(ref_mlp.state_dict())
+        y_ref, y_new = ref_mlp(x), new_mlp(x)
+        assert (y_ref.float() - y_new.float()).abs().max() <= 0.02 * y_ref.float().abs().max() + 1e-3
+        ln = m.LayerNorm(160, eps=1e-6).to(dev, torch.bfloat16)
+        xv = _rand((10, 160), dev, 2.0, 3)
+        assert_bf16_close(ln(xv), torch.nn.functional.layer_norm(xv.float(), (160,), ln.weight.float(), ln.bias.float(), 1e-6).to(torch.bfloat16),
+                          "plugin_layernorm", 1.0, 5e-3)
+    finally:
+        m.Qwen2VLRMSNorm, m.LayerNorm, m.Qwen2MLP = saved
