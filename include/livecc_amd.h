@@ -58,6 +58,8 @@ int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, 
 int lcc_debug_set_gemv_variant(int variant);
 /* tiled kernel: 0 = register-staged double-buffered LDS, 1 = LDS-DMA (global_load_lds) 3-stage ring, 2 = per tile shape (default) */
 int lcc_debug_set_gemm_variant(int variant);
+/* attention: 0 = per-wave kernels (operands straight from L2), 1 = K/V tiles shared through an LDS-DMA ring (default) */
+int lcc_debug_set_attn_variant(int variant);
 int lcc_gemv_num_splits(int N, int K);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
 int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream);
@@ -79,10 +81,12 @@ int lcc_swiglu_bf16(const void* gate, const void* up, void* out, int64_t n, void
 int lcc_vit_rope_vt_bf16(void* qkv, const float* cos, const float* sin, const int32_t* seg_of_patch,
                          const int32_t* seg_start, const int32_t* seg_blk_start, void* vt, int P, int heads,
                          int total_blocks, void* stream);
-/* VisionAttention core (Q2VL:375-417): non-causal attention inside each temporal slice */
+/* VisionAttention core (Q2VL:375-417): non-causal attention inside each temporal slice (segment).  Work tables:
+ * 32-row query tiles (tile_seg/tile_q0) and 128-row groups (grp_seg/grp_q0; 4 tiles of ONE segment per block, K/V tiles
+ * shared through LDS).  n_groups == 0 selects the per-wave kernel. */
 int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, const int32_t* tile_seg, const int32_t* tile_q0,
                       const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
-                      int heads, int total_blocks, void* stream);
+                      int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, void* stream);
 
 /* M-RoPE tables (Q2VL:156-169) and apply + in-place KV append (Q2VL:180-222 + HF:cache_utils.py:127-146) */
 int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream);

@@ -76,6 +76,7 @@ def load():
         "lcc_gemm_bf16": (i32, [vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
         "lcc_debug_set_gemv_variant": (i32, [i32]),
         "lcc_debug_set_gemm_variant": (i32, [i32]),
+        "lcc_debug_set_attn_variant": (i32, [i32]),
         "lcc_gemv_num_splits": (i32, [i32, i32]),
         "lcc_debug_mfma_probe": (i32, [vp, vp, vp, vp]),
         "lcc_patchify_norm_u8": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp]),
@@ -85,7 +86,7 @@ def load():
         "lcc_add_rmsnorm_bf16": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, f32, vp]),
         "lcc_swiglu_bf16": (i32, [vp, vp, vp, i64, vp]),
         "lcc_vit_rope_vt_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-        "lcc_attn_vit_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+        "lcc_attn_vit_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
         "lcc_mrope_table": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "lcc_rope_kv_append_bf16": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, vp]),
         "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, vp]),

@@ -262,6 +262,146 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// v2: K/V tiles shared through LDS.  The per-wave kernels above re-read every K/V byte from L2 once per wave (7 heads x
+// 25 query tiles for a 386-row chunk against a 12k cache = 4.3 GB per layer: L2-bandwidth bound).  Here one block =
+// NWAVE waves that need the SAME keys: the G query heads of one KV group for the same query tile (prefill, MODE 1), or 4
+// consecutive query tiles of one head/segment (ViT, MODE 0).  A 32-key tile (K 2*KS + V^T D/16 one-KB fragment pieces)
+// is fetched ONCE per block by LDS-DMA (global_load_lds, per-lane source addresses put every piece in MFMA fragment order
+// so the reads are linear ds_read_b128) into a 4-stage ring: two tiles stay in flight while one is multiplied.
+//   iteration t:  s_waitcnt vmcnt(2*PW)  ->  s_barrier  ->  issue tile t+3  ->  QK^T / softmax / PV on tile t
+// ------------------------------------------------------------------------------------------------
+LCC_DEVICE void wait_two_tiles_in_flight(int pw) {   // pw = DMA instructions per wave per tile (wave-uniform)
+  switch (pw) {
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+__device__ unsigned int lcc_attn_zero_page[256];
+
+template <int D, int NQ, int MODE>
+__global__ __launch_bounds__(512) void attn_shared_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+    const int32_t* __restrict__ t0a, const int32_t* __restrict__ t1a, const int32_t* __restrict__ t2a,
+    const int32_t* __restrict__ t3a, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+    const int32_t* __restrict__ seg_blk_start, bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer,
+    int heads, int total_blocks, float scale_log2e) {
+  constexpr int KS = (D + 31) / 32, KP = 2 * KS, VP = D / 16, NP = KP + VP, NSTAGE = 4;
+  extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int pw = (NP + nwave - 1) / nwave;
+  const int grp = blockIdx.x;
+
+  // ---- what this block streams (K rows, V^T blocks, number of keys) and what this wave computes
+  const bf16_t* kbase; size_t kstride; const bf16_t* vbase; int nkeys;
+  const bf16_t* qrow0; size_t qstride; int nq_valid; bool active; bf16_t* orow0; size_t ostride;
+  int key_limit[NQ];
+  if (MODE == 0) {          // ViT: t0a = group segment, t1a = first query row of the group inside the segment
+    const int h = blockIdx.y, E = heads * D, ld = 3 * E;
+    const int sg = t0a[grp], q0 = t1a[grp] + wave * (NQ * 16);
+    const int s0 = seg_start[sg], sl = seg_len[sg];
+    kbase = q + (size_t)s0 * ld + E + h * D; kstride = ld;
+    vbase = vt + ((size_t)h * total_blocks + seg_blk_start[sg]) * (D * 32);
+    nkeys = sl;
+    active = q0 < sl;
+    nq_valid = max(0, min(NQ * 16, sl - q0));
+    qrow0 = q + (size_t)(s0 + min(q0, sl - 1)) * ld + h * D; qstride = ld;
+    orow0 = out + (size_t)(s0 + q0) * E + h * D; ostride = E;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) key_limit[n] = sl;
+  } else {                  // prefill: t0a = stream slot, t1a = first row in q, t2a = valid rows, t3a = cache index of row 0
+    const int hk = blockIdx.y, G = heads / lay.n_kv_heads, h = hk * G + wave;
+    const int strm = t0a[grp], q0 = t1a[grp], nq = t2a[grp], pos0 = t3a[grp];
+    const bf16_t* base = kv_base[strm] + (size_t)layer * lay.layer_stride();
+    kbase = base + (size_t)hk * lay.head_stride(); kstride = D;
+    vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
+    nkeys = pos0 + nq;
+    active = wave < G;
+    nq_valid = nq;
+    const int ldq = heads * D;
+    qrow0 = q + (size_t)q0 * ldq + min(h, heads - 1) * D; qstride = ldq;
+    orow0 = out + (size_t)q0 * ldq + min(h, heads - 1) * D; ostride = ldq;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) key_limit[n] = pos0 + min(n * 16 + li, nq - 1) + 1;
+  }
+  const int ntile = (nkeys + 31) / 32;
+
+  u32x4 qf[NQ][KS];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const int r = min(n * 16 + li, max(nq_valid - 1, 0));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      qf[n][ks] = (d0 < D) ? ld16(qrow0 + (size_t)r * qstride + d0) : (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn_zero_page) + lane * 8;
+  auto issue = [&](int t) {
+    const int tc = min(t, ntile - 1);
+    u32x4* sbase = alds + (t % NSTAGE) * (NP * 64);
+    for (int j = 0; j < pw; ++j) {
+      const int p = min(j * nwave + wave, NP - 1);   // surplus slots re-fetch the last piece (same bytes, same place)
+      const bf16_t* src;
+      if (p < KP) {
+        const int kt = p / KS, ks = p - kt * KS;
+        const int key = min(tc * 32 + (li >> 2) * 8 + kt * 4 + (li & 3), nkeys - 1);
+        const int d0 = ks * 32 + g * 8;
+        src = (d0 < D) ? kbase + (size_t)key * kstride + d0 : zp;
+      } else {
+        src = vbase + (size_t)tc * (D * 32) + ((p - KP) * 16 + li) * 32 + g * 8;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
+    }
+  };
+
+  AttnAcc<D, NQ> acc;
+  acc.init();
+  issue(0); issue(1); issue(2);
+  for (int t = 0; t < ntile; ++t) {
+    wait_two_tiles_in_flight(pw);
+    __builtin_amdgcn_s_barrier();
+    issue(t + 3);
+    if (active) {
+      const u32x4* s = alds + (t % NSTAGE) * (NP * 64);
+      KFrag<D> kf;
+      u32x4 vf[VP];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf.v[kt][ks] = s[(kt * KS + ks) * 64 + lane];
+#pragma unroll
+      for (int dt = 0; dt < VP; ++dt) vf[dt] = s[(KP + dt) * 64 + lane];
+      attn_tile<D, NQ>(acc, kf, vf, qf, t * 32, g, key_limit, scale_log2e);
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    float l = acc.l[n];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const int r = n * 16 + li;
+    if (r < nq_valid) {
+      bf16_t* op = orow0 + (size_t)r * ostride;
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) {
+        f32x4 o = acc.o[dt][n];
+        st8(op + dt * 16 + g * 4, (u32x2){pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv)});
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LLM decode attention: one new token per stream.  The G = Hq/Hkv query heads that share a KV head are the
 // query columns of one wave (G <= 16), so every K/V byte is read once per KV head.  grid = (nsplit, Hkv, B),
 // one wave per block; split s handles key tiles [s*per, (s+1)*per).  HBM-bound: L*512 bytes per KV head.
@@ -361,11 +501,27 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
+static int g_attn_variant = 1;  // 0: per-wave kernels (no LDS); 1: K/V tiles shared through LDS (default)
+void set_attn_variant(int v) { g_attn_variant = v; }
+
+template <class Kern>
+static void set_lds_attr(Kern k, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* tile_seg, const int32_t* tile_q0,
                   const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
-                  int heads, int total_blocks, hipStream_t st) {
+                  int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, hipStream_t st) {
   if (n_tiles <= 0) return 0;
+  if (g_attn_variant == 1 && n_groups > 0) {
+    constexpr size_t lds = (size_t)4 * (6 + 5) * 1024;
+    static bool once = false;
+    if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0>, lds); once = true; }
+    attn_shared_kernel<80, 2, 0><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
+        qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
+        heads, total_blocks, scale_l2e(80));
+    return 0;
+  }
   attn_vit_kernel<80, 2><<<dim3((n_tiles + 3) / 4, heads), dim3(256), 0, st>>>(
       qkv, vt, out, tile_seg, tile_q0, seg_start, seg_len, seg_blk_start, n_tiles, heads, total_blocks,
       scale_l2e(80));
@@ -377,6 +533,21 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
                       int layer, int n_tiles, int n_q_heads, int tile_rows, hipStream_t st) {
   if (n_tiles <= 0) return 0;
   if (lay.head_dim != 128 || (lay.lmax & 31) || (tile_rows != 16 && tile_rows != 32)) return LCC_ERR_SHAPE;
+  const int G = n_q_heads / lay.n_kv_heads;
+  if (g_attn_variant == 1 && G >= 2 && G <= 8) {
+    constexpr size_t lds = (size_t)4 * 16 * 1024;
+    static bool once = false;
+    if (!once) { set_lds_attr(attn_shared_kernel<128, 1, 1>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1>, lds); once = true; }
+    if (tile_rows == 32)
+      attn_shared_kernel<128, 2, 1><<<dim3(n_tiles, lay.n_kv_heads), dim3(G * 64), lds, st>>>(
+          q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0,
+          scale_l2e(128));
+    else
+      attn_shared_kernel<128, 1, 1><<<dim3(n_tiles, lay.n_kv_heads), dim3(G * 64), lds, st>>>(
+          q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0,
+          scale_l2e(128));
+    return 0;
+  }
   if (tile_rows == 32)
     attn_prefill_kernel<2><<<dim3((n_tiles + 3) / 4, n_q_heads), dim3(256), 0, st>>>(
         q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128));

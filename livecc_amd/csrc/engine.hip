@@ -215,7 +215,7 @@ extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
   const size_t S = e->lim.max_new_rows, P = e->lim.max_patches, B = e->lim.max_slots;
   const size_t llm = (7 * S + 4 * (S / 16 + B + 1) + 4 * B + 64) * 4;
-  const size_t vit = (P + 5 * (P / 16 + 64) + 64) * 4;
+  const size_t vit = (P + 7 * (P / 16 + 64) + 64) * 4;
   return align_up(std::max(llm, vit) + 4096, 4096) * META_RING;
 }
 
@@ -390,7 +390,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   hipStream_t st = (hipStream_t)stream;
   const int E = e->E, heads = e->c.vit_heads, MLP = e->c.vit_mlp, H = e->c.hidden_size, PD = e->c.patch_dim;
   // segment tables
-  std::vector<int32_t> seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0;
+  std::vector<int32_t> seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0, grp_seg, grp_q0;
   int P = 0, blocks = 0;
   for (int ci = 0; ci < n_clips; ++ci) {
     const lcc_clip& c = clips[ci];
@@ -401,12 +401,13 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
       const int sg = (int)seg_start.size();
       seg_start.push_back(P); seg_len.push_back(n); seg_blk.push_back(blocks);
       for (int q = 0; q < n; q += 32) { tile_seg.push_back(sg); tile_q0.push_back(q); }
+      for (int q = 0; q < n; q += 128) { grp_seg.push_back(sg); grp_q0.push_back(q); }
       seg_of_patch.insert(seg_of_patch.end(), n, sg);
       P += n; blocks += (n + 31) / 32;
     }
   }
   if (P > e->lim.max_patches) return fail(LCC_ERR_STATE, "%d patches > max_patches %d", P, e->lim.max_patches);
-  const int n_tiles = (int)tile_seg.size(), n_seg = (int)seg_start.size();
+  const int n_tiles = (int)tile_seg.size(), n_seg = (int)seg_start.size(), n_groups = (int)grp_seg.size();
 
   Carver cv; cv.base = e->ws;
   bf16_t* patches = cv.take<bf16_t>((size_t)P * PD);
@@ -420,10 +421,11 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small for %d patches", P);
 
   MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
-  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0;
+  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0, *d_grp_seg, *d_grp_q0;
   if (!mw.put(seg_start.data(), n_seg, &d_seg_start) || !mw.put(seg_len.data(), n_seg, &d_seg_len) ||
       !mw.put(seg_blk.data(), n_seg, &d_seg_blk) || !mw.put(seg_of_patch.data(), P, &d_seg_of_patch) ||
-      !mw.put(tile_seg.data(), n_tiles, &d_tile_seg) || !mw.put(tile_q0.data(), n_tiles, &d_tile_q0))
+      !mw.put(tile_seg.data(), n_tiles, &d_tile_seg) || !mw.put(tile_q0.data(), n_tiles, &d_tile_q0) ||
+      !mw.put(grp_seg.data(), n_groups, &d_grp_seg) || !mw.put(grp_q0.data(), n_groups, &d_grp_q0))
     return fail(LCC_ERR_STATE, "meta ring slot too small");
   LCC_TRY(meta_commit(&mw, st));
 
@@ -449,7 +451,8 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
     LCC_TRY(gemm_bf16(g, st));
     LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));
-    LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, st));
+    LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, d_grp_seg, d_grp_q0,
+                          n_groups, st));
     g = GemmArgs(); g.w_packed = 1; g.A = attn; g.lda = E; g.W = L.proj_w; g.ldw = E; g.bias = L.proj_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
     g.M = P; g.N = E; g.K = E; g.epilogue = LCC_EPI_RESIDUAL;
     LCC_TRY(gemm_bf16(g, st));
@@ -743,6 +746,7 @@ static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_hea
 
 extern "C" int lcc_debug_set_gemv_variant(int variant) { set_gemv_variant(variant); return 0; }
 extern "C" int lcc_debug_set_gemm_variant(int variant) { set_gemm_variant(variant); return 0; }
+extern "C" int lcc_debug_set_attn_variant(int variant) { set_attn_variant(variant); return 0; }
 extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual,
                              int ldr, void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {
   if (!A || !W || (!C && !partial)) return fail(LCC_ERR_ARG, "lcc_gemm_bf16: null pointer");
@@ -793,10 +797,11 @@ extern "C" int lcc_vit_rope_vt_bf16(void* qkv, const float* cos, const float* si
 }
 extern "C" int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, const int32_t* tile_seg, const int32_t* tile_q0,
                                  const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles, int heads,
-                                 int total_blocks, void* stream) {
+                                 int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, void* stream) {
   if (!qkv || !vt || !out || !tile_seg || !tile_q0 || !seg_start || !seg_len || !seg_blk_start) return fail(LCC_ERR_ARG, "null pointer");
+  if (n_groups > 0 && (!grp_seg || !grp_q0)) return fail(LCC_ERR_ARG, "null group table");
   OP_RET(attn_vit_bf16((const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, tile_seg, tile_q0, seg_start, seg_len, seg_blk_start, n_tiles,
-                       heads, total_blocks, (hipStream_t)stream), "lcc_attn_vit_bf16");
+                       heads, total_blocks, grp_seg, grp_q0, n_groups, (hipStream_t)stream), "lcc_attn_vit_bf16");
 }
 extern "C" int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream) {
   if (!pos3 || !inv_freq || !cos || !sin) return fail(LCC_ERR_ARG, "null pointer");

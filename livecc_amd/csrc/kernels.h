@@ -63,9 +63,11 @@ int embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t
 int gather_rows_bf16(const bf16_t* in, const int32_t* rows, bf16_t* out, int n, int dim, hipStream_t st);
 
 // ---- attention (attention.hip) ----
+void set_attn_variant(int v);
+// tile tables: 32-row query tiles (per-wave kernel); group tables: 128-row groups of one segment (LDS-shared kernel)
 int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* tile_seg, const int32_t* tile_q0,
                   const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
-                  int heads, int total_blocks, hipStream_t st);
+                  int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, hipStream_t st);
 int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0,
                       const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
                       int layer, int n_tiles, int n_q_heads, int tile_rows, hipStream_t st);

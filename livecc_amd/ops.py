@@ -76,6 +76,11 @@ def set_gemv_variant(v: int) -> None:
 
 
 GEMM_DEFAULT_VARIANT = 2
+ATTN_DEFAULT_VARIANT = 1
+
+
+def set_attn_variant(v: int) -> None:
+    _lib.load().lcc_debug_set_attn_variant(int(v))
 
 
 def set_gemm_variant(v: int) -> None:
@@ -149,7 +154,7 @@ def _i32(a, device) -> torch.Tensor:
 
 def vit_segments(grids: Sequence[Sequence[int]], device):
     """Segment / tile tables of the ViT attention for clips with grids (t,h,w): one segment per temporal slice."""
-    seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0 = [], [], [], [], [], []
+    seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0, grp_seg, grp_q0 = [], [], [], [], [], [], [], []
     P = blocks = 0
     for t, h, w in grids:
         n = h * w
@@ -158,10 +163,13 @@ def vit_segments(grids: Sequence[Sequence[int]], device):
             seg_start.append(P); seg_len.append(n); seg_blk.append(blocks)
             for q in range(0, n, 32):
                 tile_seg.append(sg); tile_q0.append(q)
+            for q in range(0, n, 128):
+                grp_seg.append(sg); grp_q0.append(q)
             seg_of_patch += [sg] * n
             P += n; blocks += (n + 31) // 32
     d = dict(seg_start=_i32(seg_start, device), seg_len=_i32(seg_len, device), seg_blk=_i32(seg_blk, device),
              seg_of_patch=_i32(seg_of_patch, device), tile_seg=_i32(tile_seg, device), tile_q0=_i32(tile_q0, device),
+             grp_seg=_i32(grp_seg, device), grp_q0=_i32(grp_q0, device), n_groups=len(grp_seg),
              P=P, blocks=blocks, n_tiles=len(tile_seg))
     return d
 
@@ -179,7 +187,8 @@ def vit_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, grids
                                         seg["blocks"], _st(qkv)), "lcc_vit_rope_vt_bf16")
     _lib.check(lib.lcc_attn_vit_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg["tile_seg"].data_ptr(),
                                      seg["tile_q0"].data_ptr(), seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(),
-                                     seg["seg_blk"].data_ptr(), seg["n_tiles"], heads, seg["blocks"], _st(qkv)),
+                                     seg["seg_blk"].data_ptr(), seg["n_tiles"], heads, seg["blocks"], seg["grp_seg"].data_ptr(),
+                                     seg["grp_q0"].data_ptr(), seg["n_groups"], _st(qkv)),
                "lcc_attn_vit_bf16")
     return out
 

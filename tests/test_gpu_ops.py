@@ -256,8 +256,16 @@ def _check_attn(got, ref, name, rel=0.02):
     assert (got - ref).abs().mean().item() <= 0.25 * rel * scale
 
 
+@pytest.fixture(params=[0, 1], ids=["attn_per_wave", "attn_lds_shared"])
+def attn_variant(request):
+    from livecc_amd import ops
+    ops.set_attn_variant(request.param)
+    yield request.param
+    ops.set_attn_variant(ops.ATTN_DEFAULT_VARIANT)
+
+
 @pytest.mark.parametrize("grids", [[(1, 4, 6)], [(3, 4, 6)], [(1, 10, 14), (2, 6, 8)], [(1, 28, 52)]])
-def test_vit_rope_attention(dev, grids):
+def test_vit_rope_attention(dev, grids, attn_variant):
     """VisionAttention core: fp32 2-D RoPE (one rounding) + per-temporal-slice non-causal attention, d = 80."""
     from livecc_amd import ops
     from livecc_amd.config import tiny
@@ -321,8 +329,8 @@ def _ref_attn_causal(q, k, v, past):
     return torch.einsum("hqk,khd->qhd", att.softmax(-1), vv)
 
 
-@pytest.mark.parametrize("Hq,Hkv", [(2, 1), (7, 1), (28, 4)])
-def test_rope_append_prefill_decode_attention(dev, Hq, Hkv):
+@pytest.mark.parametrize("Hq,Hkv", [(2, 1), (7, 1), (28, 4), (12, 2), (8, 1)])
+def test_rope_append_prefill_decode_attention(dev, Hq, Hkv, attn_variant):
     """M-RoPE apply + KV append (bit-level vs HF's bf16 op sequence), then prefill and decode attention over the cache."""
     from livecc_amd import ops
     D, L0, S1, S2 = 128, 0, 70, 45
@@ -378,7 +386,7 @@ def test_rope_append_prefill_decode_attention(dev, Hq, Hkv):
         _check_attn(got.view(1, Hq, D), ref, f"attn_decode[Hq{Hq},nsplit{nsplit}]")
 
 
-def test_attention_masks_garbage_beyond_length(dev):
+def test_attention_masks_garbage_beyond_length(dev, attn_variant):
     """Keys past the valid length (stale cache contents) must not leak into the result."""
     from livecc_amd import ops
     Hq, Hkv, D, S = 2, 1, 128, 40
