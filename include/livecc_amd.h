@@ -58,7 +58,7 @@ int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, 
 int lcc_debug_set_gemv_variant(int variant);
 /* tiled kernel: 0 = register-staged double-buffered LDS, 1 = LDS-DMA (global_load_lds) 3-stage ring, 2 = per tile shape (default) */
 int lcc_debug_set_gemm_variant(int variant);
-/* attention: 0 = per-wave kernels (operands straight from L2), 1 = K/V tiles shared through an LDS-DMA ring (default) */
+/* attention: 0 = per-wave kernels, operands straight from L2 (default), 1 = K/V tiles shared through an LDS-DMA ring */
 int lcc_debug_set_attn_variant(int variant);
 int lcc_gemv_num_splits(int N, int K);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
@@ -100,7 +100,9 @@ int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_partial, int 
  * consecutive new rows of one stream: slot, first row in q, valid rows, cache index of the first row. */
 int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0,
                           const int32_t* tile_nq, const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay,
-                          int layer, int n_tiles, int n_q_heads, int tile_rows, void* stream);
+                          int layer, int n_tiles, int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o,
+                          float* ws_ml, void* stream);  /* nsplit > 1: keys split over blockIdx.z, fp32 partials in ws_o
+                          [n_rows*Hq*nsplit*128] / ws_ml [n_rows*Hq*nsplit*2], merged by a combine kernel */
 /* decode: row b belongs to slot slots[b]; attends to kv_len[slot]+1 keys (its own K/V already appended) */
 int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
                          lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream);
@@ -112,7 +114,8 @@ int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const
 int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                       const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
                       int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
-                      int32_t* hist_col, float* scores_out, void* stream);
+                      int32_t* hist_col, float* scores_out, float* ws /* optional scratch B*256 floats: two-stage path */,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Model level -- what `model.generate(**inputs, past_key_values=...)` (ref:demo/infer.py:165-172) executes:

@@ -89,12 +89,12 @@ def load():
         "lcc_attn_vit_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
         "lcc_mrope_table": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "lcc_rope_kv_append_bf16": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, vp]),
-        "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, vp]),
+        "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
         "lcc_attn_decode_bf16": (i32, [vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, vp, vp, vp]),
         "lcc_embed_gather_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "lcc_seen_set": (i32, [vp, i32, vp, vp, i32, vp]),
         "lcc_sample_greedy": (i32, [vp, i32, i32, i32, vp, i32, vp, f32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp,
-                                    vp, vp]),
+                                    vp, vp, vp]),
         "lcc_engine_create": (vp, [C.POINTER(ModelConfig), C.POINTER(EngineLimits)]),
         "lcc_engine_destroy": (None, [vp]),
         "lcc_engine_workspace_bytes": (sz, [vp]),

@@ -141,7 +141,7 @@ size_t lcc_engine::llm_ws_bytes() const {
   t += align_up(std::max((size_t)MAX_SPLIT * 16 * std::max<size_t>(qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H) * 4);  // split-K slabs
   t += align_up(B * H * 2) * 2;              // last_h, last_xn
   t += align_up(B * V * 2);                  // logits
-  t += align_up(B * c.n_kv_heads * 64 * 16 * 128 * 4) + align_up(B * c.n_kv_heads * 64 * 16 * 2 * 4);  // decode attn ws
+  t += align_up(std::max<size_t>(B * c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * c.n_q_heads * 8) * 128 * 4) * 2;  // attention split partials (o, ml)
   return t + 4096;
 }
 size_t lcc_engine::vit_ws_bytes() const {
@@ -491,7 +491,8 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
   b->cos = cv.take<bf16_t>(S * 64); b->sin = cv.take<bf16_t>(S * 64);
   b->partial = cv.take<float>(std::max((size_t)MAX_SPLIT * 16 * std::max<size_t>(e->qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H));
   b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H); b->logits = cv.take<bf16_t>(B * V);
-  b->ws_o = cv.take<float>(B * e->c.n_kv_heads * 64 * 16 * 128); b->ws_ml = cv.take<float>(B * e->c.n_kv_heads * 64 * 16 * 2);
+  const size_t nslot = std::max<size_t>(B * e->c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * e->c.n_q_heads * 8);
+  b->ws_o = cv.take<float>(nslot * 128); b->ws_ml = cv.take<float>(nslot * 128);
   if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small");
   return 0;
 }
@@ -501,7 +502,7 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
 struct LayerCtx {
   int S; bool skinny;
   const int32_t *tok_stream, *tok_pos;          // prefill: explicit positions; decode: tok_pos == nullptr
-  const int32_t *tile_stream, *tile_q0, *tile_nq, *tile_pos0; int n_tiles, tile_rows;  // prefill attention tiles
+  const int32_t *tile_stream, *tile_q0, *tile_nq, *tile_pos0; int n_tiles, tile_rows, kv_split;  // prefill attention tiles
   const int32_t* slots; int B; int nsplit_attn;  // decode attention
 };
 int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream_t st) {
@@ -537,7 +538,7 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
                                b.ws_o, b.ws_ml, st));
     else
       LCC_TRY(attn_prefill_bf16(b.q, b.attn, cx.tile_stream, cx.tile_q0, cx.tile_nq, cx.tile_pos0, e->d_kv_base, e->lay, l,
-                                cx.n_tiles, e->c.n_q_heads, cx.tile_rows, st));
+                                cx.n_tiles, e->c.n_q_heads, cx.tile_rows, cx.kv_split, S, b.ws_o, b.ws_ml, st));
     // o_proj + residual + post-attention RMSNorm
     g = GemmArgs(); g.w_packed = 1; g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
     if (cx.skinny) {
@@ -591,7 +592,7 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   const float thr = sp ? sp->thr_base + sp->thr_step * (float)step_index : 0.f;
   LCC_TRY(sample_greedy(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr,
                         sp ? sp->eos_token : -1, sp ? sp->suppress_eos : 0, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
-                        e->d_hist_col, sp ? sp->scores_out : nullptr, st));
+                        e->d_hist_col, sp ? sp->scores_out : nullptr, b.ws_ml, st));
   return 0;
 }
 }  // namespace
@@ -656,6 +657,14 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
   LayerCtx cx{};
   cx.S = S; cx.skinny = S <= 16; cx.tok_stream = d_tok_stream; cx.tok_pos = d_tok_pos;
   cx.tile_stream = d_ts; cx.tile_q0 = d_tq; cx.tile_nq = d_tn; cx.tile_pos0 = d_tp; cx.n_tiles = n_tiles; cx.tile_rows = tile_rows;
+  {  // few query tiles against a long cache (a streaming chunk): also split the keys so that every SIMD gets 2-3 waves
+    int max_kv = 0;
+    for (int b = 0; b < n_streams; ++b) max_kv = std::max(max_kv, e->h_kv_len[slots[b]] + n_new[b]);
+    const long waves = (long)n_tiles * e->c.n_q_heads;
+    int ks = (int)std::min<long>(8, 3072 / std::max<long>(waves, 1));
+    ks = std::min(ks, (max_kv / 32) / 16);          // >= 16 key tiles per split
+    cx.kv_split = (S <= 1024 && ks >= 2) ? ks : 1;
+  }
   cx.slots = d_slots; cx.B = n_streams; cx.nsplit_attn = 1;
   LCC_TRY(run_layers(e, bf, cx, st));
 
@@ -817,10 +826,10 @@ extern "C" int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_pa
 }
 extern "C" int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                                      const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay, int layer, int n_tiles,
-                                     int n_q_heads, int tile_rows, void* stream) {
+                                     int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o, float* ws_ml, void* stream) {
   if (!q || !out || !tile_stream || !tile_q0 || !tile_nq || !tile_pos0 || !kv_base) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(attn_prefill_bf16((const bf16_t*)q, (bf16_t*)out, tile_stream, tile_q0, tile_nq, tile_pos0, (bf16_t* const*)kv_base, to_lay(lay),
-                           layer, n_tiles, n_q_heads, tile_rows, (hipStream_t)stream), "lcc_attn_prefill_bf16");
+                           layer, n_tiles, n_q_heads, tile_rows, nsplit, n_rows, ws_o, ws_ml, (hipStream_t)stream), "lcc_attn_prefill_bf16");
 }
 extern "C" int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
                                     lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream) {
@@ -841,9 +850,9 @@ extern "C" int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t*
 extern "C" int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream, const int32_t* stream_slot,
                                  float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token,
                                  int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
-                                 int32_t* hist_col, float* scores_out, void* stream) {
+                                 int32_t* hist_col, float* scores_out, float* ws, void* stream) {
   if (!logits || !seen || !stream_slot || !out_tokens || (history && !hist_col)) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(sample_greedy((const bf16_t*)logits, ld, B, V, seen, words_per_stream, stream_slot, repetition_penalty, thr_token, use_thr,
-                       thr_value, eos_token, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out, (hipStream_t)stream),
+                       thr_value, eos_token, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out, ws, (hipStream_t)stream),
          "lcc_sample_greedy");
 }

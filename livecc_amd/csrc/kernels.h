@@ -70,7 +70,8 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
                   int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, hipStream_t st);
 int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0,
                       const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
-                      int layer, int n_tiles, int n_q_heads, int tile_rows, hipStream_t st);
+                      int layer, int n_tiles, int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o, float* ws_ml,
+                      hipStream_t st);
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
                      KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
 
@@ -80,7 +81,7 @@ int seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int
 int sample_greedy(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                   const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
                   int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
-                  int32_t* hist_col, float* scores_out, hipStream_t st);
+                  int32_t* hist_col, float* scores_out, float* ws, hipStream_t st);
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st);
 
 }  // namespace lcc

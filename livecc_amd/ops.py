@@ -76,7 +76,7 @@ def set_gemv_variant(v: int) -> None:
 
 
 GEMM_DEFAULT_VARIANT = 2
-ATTN_DEFAULT_VARIANT = 1
+ATTN_DEFAULT_VARIANT = 0
 
 
 def set_attn_variant(v: int) -> None:
@@ -238,7 +238,7 @@ def rope_kv_append(qkv: Optional[torch.Tensor], cos, sin, tok_stream, tok_pos, k
 
 
 def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tuple[int, int, int]], n_q_heads: int,
-                 tile_rows: int = 32):
+                 tile_rows: int = 32, nsplit: int = 1):
     """segments: (slot, n_new, past_len) per stream, rows packed in that order."""
     ts, tq, tn, tp = [], [], [], []
     row = 0
@@ -249,9 +249,12 @@ def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tu
     dev = q.device
     out = torch.empty_like(q)
     a, b, c, d = _i32(ts, dev), _i32(tq, dev), _i32(tn, dev), _i32(tp, dev)
+    ws_o = torch.empty(q.shape[0] * n_q_heads * nsplit * 128, dtype=torch.float32, device=dev) if nsplit > 1 else None
+    ws_ml = torch.empty(q.shape[0] * n_q_heads * nsplit * 2, dtype=torch.float32, device=dev) if nsplit > 1 else None
     _lib.check(_lib.load().lcc_attn_prefill_bf16(_chk(q, torch.bfloat16, "q"), out.data_ptr(), a.data_ptr(), b.data_ptr(),
                                                  c.data_ptr(), d.data_ptr(), kv.ptrs.data_ptr(), kv.lay, layer, len(ts),
-                                                 n_q_heads, tile_rows, _st(q)), "lcc_attn_prefill_bf16")
+                                                 n_q_heads, tile_rows, nsplit, q.shape[0], ws_o.data_ptr() if ws_o is not None else None,
+                                                 ws_ml.data_ptr() if ws_ml is not None else None, _st(q)), "lcc_attn_prefill_bf16")
     return out
 
 
@@ -270,14 +273,15 @@ def attn_decode(q: torch.Tensor, kv: KvArena, layer: int, slots: torch.Tensor, k
 
 def sample_greedy(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor, repetition_penalty: float = 1.0,
                   thr_token: int = -1, thr_value: Optional[float] = None, eos_token: int = -1, suppress_eos: bool = False,
-                  want_scores: bool = False):
+                  want_scores: bool = False, two_stage: bool = False):
     B, V = logits.shape
     n_slots, words = seen.shape
     out = torch.zeros(n_slots, dtype=torch.int32, device=logits.device)
     scores = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_scores else None
+    ws = torch.empty(B * 256, dtype=torch.float32, device=logits.device) if two_stage else None
     _lib.check(_lib.load().lcc_sample_greedy(
         _chk(logits, torch.bfloat16, "logits"), V, B, V, _chk(seen, torch.int32, "seen"), words, _chk(slots, torch.int32, "slots"),
         repetition_penalty, thr_token, 1 if thr_value is not None else 0, float(thr_value or 0.0), eos_token,
         1 if suppress_eos else 0, None, out.data_ptr(), None, 0, None, scores.data_ptr() if scores is not None else None,
-        _st(logits)), "lcc_sample_greedy")
+        ws.data_ptr() if ws is not None else None, _st(logits)), "lcc_sample_greedy")
     return out, scores

@@ -359,9 +359,9 @@ def test_rope_append_prefill_decode_attention(dev, Hq, Hkv, attn_variant):
         assert torch.equal(kv.k_view(slot, layer)[:, :past + S].float(), K.transpose(0, 1)), "K cache append"
         assert torch.equal(kv.v_view(slot, layer)[:, :past + S].float(), V.transpose(0, 1)), "V cache append (blocked-transposed)"
         ref = _ref_attn_causal(q_ref, K, V, past)
-        for tr in (32, 16):
-            got = ops.attn_prefill(q_got, kv, layer, [(slot, S, past)], Hq, tile_rows=tr)
-            _check_attn(got.view(S, Hq, D), rb(ref), f"attn_prefill[Hq{Hq},turn{turn},rows{tr}]")
+        for tr, ns in ((32, 1), (16, 1), (16, 3), (32, 2)):
+            got = ops.attn_prefill(q_got, kv, layer, [(slot, S, past)], Hq, tile_rows=tr, nsplit=ns)
+            _check_attn(got.view(S, Hq, D), rb(ref), f"attn_prefill[Hq{Hq},turn{turn},rows{tr},split{ns}]")
         past += S
     # decode: one new token, appended at kv_len through the device counter path, several split counts
     qkv = _rand((1, qkv_dim), dev, 1.0, 99)
@@ -407,11 +407,12 @@ def test_attention_masks_garbage_beyond_length(dev, attn_variant):
 # ---------------------------------------------------------------------------------------------
 # sampler
 # ---------------------------------------------------------------------------------------------
-def test_sampler_matches_hf_processors(dev):
+@pytest.mark.parametrize("V,two_stage", [(2048, False), (16384, True), (152064, True)])
+def test_sampler_matches_hf_processors(dev, V, two_stage):
     from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
     from livecc_amd import ops
     from oracle.hf_oracle import ThresholdLogitsProcessor
-    V, B = 2048, 3
+    B = 3
     g = torch.Generator().manual_seed(0)
     logits = (torch.randn(B, V, generator=g) * 2).to(torch.bfloat16)
     hist = [torch.randint(0, V, (50,), generator=g) for _ in range(B)]
@@ -425,7 +426,7 @@ def test_sampler_matches_hf_processors(dev):
         thr_tok = int(logits[0].float().argmax())          # make the threshold token matter for stream 0
         eos = int(logits[1].float().argmax())              # and EOS suppression for stream 1
         tok, scores = ops.sample_greedy(logits.to(dev), seen.to(dev), slots.to(dev), pen, thr_tok if thr is not None else -1,
-                                        thr, eos if eos_sup else -1, eos_sup, want_scores=True)
+                                        thr, eos if eos_sup else -1, eos_sup, want_scores=True, two_stage=two_stage)
         for b in range(B):
             sc = logits[b:b + 1].float().clone()
             sc = RepetitionPenaltyLogitsProcessor(pen)(hist[b].view(1, -1), sc) if pen != 1.0 else sc
