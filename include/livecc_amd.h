@@ -58,7 +58,8 @@ int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, 
 int lcc_debug_set_gemv_variant(int variant);
 /* tiled kernel: 0 = register-staged double-buffered LDS, 1 = LDS-DMA (global_load_lds) 3-stage ring, 2 = per tile shape (default) */
 int lcc_debug_set_gemm_variant(int variant);
-/* attention: 0 = per-wave kernels, operands straight from L2 (default), 1 = K/V tiles shared through an LDS-DMA ring */
+/* attention: 0 = per-wave kernels (operands straight from L2); 1 (default) = prefill shares K/V tiles through an LDS-DMA ring,
+ * ViT per-wave; 2 = LDS-shared for both */
 int lcc_debug_set_attn_variant(int variant);
 int lcc_gemv_num_splits(int N, int K);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */

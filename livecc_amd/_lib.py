@@ -67,6 +67,17 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LccError(f"{LIB_PATH} not found: build the HIP extension first "
                        f"(python -c 'import __graft_entry__ as g; g.build()' or python -m livecc_amd.build)")
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so; if this library were loaded first it
+    # would pull /opt/rocm's copy and torch would then load a second runtime (kernels launched through one runtime on
+    # memory owned by the other fail with "no ROCm-capable device is detected").  Importing torch first makes the
+    # dynamic loader resolve our libamdhip64.so.N dependency to the copy that is already mapped.
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        try:
+            C.CDLL(tl, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32, i64, sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
     sig: Dict[str, tuple] = {

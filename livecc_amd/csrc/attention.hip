@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
     const int32_t* __restrict__ t0a, const int32_t* __restrict__ t1a, const int32_t* __restrict__ t2a,
     const int32_t* __restrict__ t3a, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_blk_start, bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer,
-    int heads, int total_blocks, float scale_log2e) {
+    int heads, int total_blocks, float scale_log2e, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
   constexpr int KS = (D + 31) / 32, KP = 2 * KS, VP = D / 16, NP = KP + VP, NSTAGE = 4;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
   const bf16_t* kbase; size_t kstride; const bf16_t* vbase; int nkeys;
   const bf16_t* qrow0; size_t qstride; int nq_valid; bool active; bf16_t* orow0; size_t ostride;
   int key_limit[NQ];
+  int part_row0 = 0, part_head = 0;   // (row, head) of this wave's first query row, for split partials
   if (MODE == 0) {          // ViT: t0a = group segment, t1a = first query row of the group inside the segment
     const int h = blockIdx.y, E = heads * D, ld = 3 * E;
     const int sg = t0a[grp], q0 = t1a[grp] + wave * (NQ * 16);
@@ -387,10 +388,15 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
     const int ldq = heads * D;
     qrow0 = q + (size_t)q0 * ldq + min(h, heads - 1) * D; qstride = ldq;
     orow0 = out + (size_t)q0 * ldq + min(h, heads - 1) * D; ostride = ldq;
+    part_row0 = q0; part_head = min(h, heads - 1);
 #pragma unroll
     for (int n = 0; n < NQ; ++n) key_limit[n] = pos0 + min(n * 16 + li, nq - 1) + 1;
   }
   const int ntile = (nkeys + 31) / 32;
+  // key split (blockIdx.z): this block handles key tiles [tb, te)
+  const int per = (ntile + nsplit - 1) / nsplit;
+  const int tb = (nsplit > 1) ? min(ntile, (int)blockIdx.z * per) : 0;
+  const int te = (nsplit > 1) ? min(ntile, tb + per) : ntile;
 
   u32x4 qf[NQ][KS];
 #pragma unroll
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn_zero_page) + lane * 8;
   auto issue = [&](int t) {
     const int tc = min(t, ntile - 1);
-    u32x4* sbase = alds + (t % NSTAGE) * (NP * 64);
+    u32x4* sbase = alds + ((t - tb) % NSTAGE) * (NP * 64);
     for (int j = 0; j < pw; ++j) {
       const int p = min(j * nwave + wave, NP - 1);   // surplus slots re-fetch the last piece (same bytes, same place)
       const bf16_t* src;
@@ -425,13 +431,13 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
 
   AttnAcc<D, NQ> acc;
   acc.init();
-  issue(0); issue(1); issue(2);
-  for (int t = 0; t < ntile; ++t) {
+  issue(tb); issue(tb + 1); issue(tb + 2);
+  for (int t = tb; t < te; ++t) {
     wait_two_tiles_in_flight(pw);
     __builtin_amdgcn_s_barrier();
     issue(t + 3);
     if (active) {
-      const u32x4* s = alds + (t % NSTAGE) * (NP * 64);
+      const u32x4* s = alds + ((t - tb) % NSTAGE) * (NP * 64);
       KFrag<D> kf;
       u32x4 vf[VP];
 #pragma unroll
@@ -444,6 +450,23 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
     }
   }
   if (!active) return;
+  if (MODE == 1 && nsplit > 1) {
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      float l = acc.l[n];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const int r = n * 16 + li;
+      if (r < nq_valid) {
+        const size_t slot = ((size_t)(part_row0 + r) * heads + part_head) * nsplit + blockIdx.z;
+        float* op = ws_o + slot * D;
+#pragma unroll
+        for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + g * 4) = acc.o[dt][n];
+        if (g == 0) { ws_ml[slot * 2] = acc.m[n]; ws_ml[slot * 2 + 1] = l; }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     float l = acc.l[n];
@@ -562,10 +585,9 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
-// 0 (default): per-wave kernels, operands straight from L2 -- measured equal or faster (prefill 268 vs 288 us, ViT 64 vs 75 us
-// at the LiveCC-7B streaming shapes: these kernels are bound by the per-wave dependent MFMA->softmax->MFMA chain, not by L2);
-// 1: K/V tiles shared through an LDS-DMA ring (kept selectable and tested: it removes the G-fold L2 re-reads).
-static int g_attn_variant = 0;
+// 0: per-wave kernels everywhere (operands straight from L2);  1 (default): prefill = LDS-shared kernel + key split, ViT =
+// per-wave kernel (measured 64 vs 75 us: one head per block has nothing to share but query tiles);  2: LDS-shared for both.
+static int g_attn_variant = 1;
 void set_attn_variant(int v) { g_attn_variant = v; }
 
 template <class Kern>
@@ -577,13 +599,13 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
                   const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
                   int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, hipStream_t st) {
   if (n_tiles <= 0) return 0;
-  if (g_attn_variant == 1 && n_groups > 0) {
+  if (g_attn_variant == 2 && n_groups > 0) {
     constexpr size_t lds = (size_t)4 * (6 + 5) * 1024;
     static bool once = false;
     if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0>, lds); once = true; }
     attn_shared_kernel<80, 2, 0><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
         qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
-        heads, total_blocks, scale_l2e(80));
+        heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
     return 0;
   }
   attn_vit_kernel<80, 2><<<dim3((n_tiles + 3) / 4, heads), dim3(256), 0, st>>>(
@@ -600,21 +622,25 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
   if (lay.head_dim != 128 || (lay.lmax & 31) || (tile_rows != 16 && tile_rows != 32)) return LCC_ERR_SHAPE;
   if (nsplit > 1 && (!ws_o || !ws_ml || nsplit > 16)) return LCC_ERR_ARG;
   const int G = n_q_heads / lay.n_kv_heads;
-  if (nsplit <= 1 && g_attn_variant == 1 && G >= 2 && G <= 8) {
+  const int S = nsplit > 1 ? nsplit : 1;
+  // Default for prefill: the LDS-shared kernel (the G heads of a KV group fetch every K/V tile once: G x less L2/TA traffic,
+  // which bounds the per-wave kernel at ~17 TB/s of 64-byte row segments) TOGETHER with the key split (which gives every SIMD
+  // 2-3 waves for the dependent MFMA->softmax->MFMA chain).  g_attn_variant 0 forces the per-wave kernel.
+  if (g_attn_variant != 0 && G >= 2 && G <= 8) {
     constexpr size_t lds = (size_t)4 * 16 * 1024;
     static bool once = false;
     if (!once) { set_lds_attr(attn_shared_kernel<128, 1, 1>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1>, lds); once = true; }
     if (tile_rows == 32)
-      attn_shared_kernel<128, 2, 1><<<dim3(n_tiles, lay.n_kv_heads), dim3(G * 64), lds, st>>>(
+      attn_shared_kernel<128, 2, 1><<<dim3(n_tiles, lay.n_kv_heads, S), dim3(G * 64), lds, st>>>(
           q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0,
-          scale_l2e(128));
+          scale_l2e(128), S, ws_o, ws_ml);
     else
-      attn_shared_kernel<128, 1, 1><<<dim3(n_tiles, lay.n_kv_heads), dim3(G * 64), lds, st>>>(
+      attn_shared_kernel<128, 1, 1><<<dim3(n_tiles, lay.n_kv_heads, S), dim3(G * 64), lds, st>>>(
           q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0,
-          scale_l2e(128));
+          scale_l2e(128), S, ws_o, ws_ml);
+    if (S > 1) attn_prefill_combine_kernel<<<dim3(n_q_heads, n_rows), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads, S);
     return 0;
   }
-  const int S = nsplit > 1 ? nsplit : 1;
   if (tile_rows == 32)
     attn_prefill_kernel<2><<<dim3((n_tiles + 3) / 4, n_q_heads, S), dim3(256), 0, st>>>(
         q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128), S, ws_o, ws_ml);
