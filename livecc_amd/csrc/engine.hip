@@ -677,13 +677,14 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
     LCC_TRY(rmsnorm_bf16(bf.last_h, e->final_norm, bf.last_xn, n_streams, e->c.hidden_size, e->c.rms_eps, st));
     xn_rows = bf.last_xn;
   }
-  // lengths: the new rows are now in the cache; the position of the next token continues the last row's (all 3 axes equal
-  // for the last text token): next_pos = max over axes of the last position + 1  (== kv_len + rope_delta)
+  // lengths: the new rows are now in the cache
   row = 0;
   for (int b = 0; b < n_streams; ++b) {
     const int s = slots[b];
-    int last = row + n_new[b] - 1;
-    int mx = std::max(pos3[last], std::max(pos3[S + last], pos3[2 * S + last]));
+    // HF: the next position is kv_len + rope_delta with rope_delta = max(position) + 1 - len (Q2VL:1014, 1349-1351), i.e.
+    // max over ALL rows and axes + 1 -- for a long one-shot video the maximum can sit on a video row, not on the last row
+    int mx = 0;
+    for (int i = row; i < row + n_new[b]; ++i) mx = std::max(mx, std::max(pos3[i], std::max(pos3[S + i], pos3[2 * S + i])));
     e->h_kv_len[s] += n_new[b];
     e->h_pos[s] = mx + 1;
     row += n_new[b];

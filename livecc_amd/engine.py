@@ -226,6 +226,13 @@ class Engine:
         _lib.check(self.lib.lcc_engine_profile_read(self.h, buf.ctypes.data, max_n, C.byref(n)), "lcc_engine_profile_read")
         return buf[:n.value]
 
+    def generated_count(self, slot: int) -> int:
+        """Blocking: number of tokens the slot has generated in the current generate call (stops growing after EOS)."""
+        buf = np.zeros(1, dtype=np.int32)
+        n = C.c_int()
+        _lib.check(self.lib.lcc_slot_read_tokens(self.h, slot, buf.ctypes.data, 0, C.byref(n), self._stream()), "lcc_slot_read_tokens")
+        return n.value
+
     def read_tokens(self, slot: int, max_n: int) -> List[int]:
         buf = np.zeros(max(max_n, 1), dtype=np.int32)
         n = C.c_int()

@@ -81,6 +81,31 @@ class LiveCCDemoInfer:
             yield (start, stop), self.decode([t for t in new_tokens if t != self.cfg.eos_token_id]), state
 
     @torch.inference_mode()
+    def video_qa(self, query_len: int, state: dict, clip: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
+                 repetition_penalty: float = 1.05, max_new_tokens: int = 512, force_length: bool = False):
+        """Multi-turn QA with KV reuse (ref demo/infer.py:182-242): the first turn prefills the WHOLE clip in one shot
+        (up to 480 frames / 24k visual tokens), later turns are text only.  Returns (generated ids, state)."""
+        turn = state.get("turn_index", 0)
+        past_ids = state.get("past_ids")
+        n_vid = 0
+        if past_ids is None and clip is not None:       # "only use once" (infer.py:213-214)
+            grid = protocol.grid_of(clip.shape[0], *(clip.shape[2:] if frames_layout == "TCHW" else clip.shape[1:3]), self.cfg)
+            n_vid = protocol.num_video_tokens(grid, self.cfg)
+        self.turn_builder.query_len = query_len
+        new_ids = self.turn_builder.turn_ids(turn, n_vid, with_query=True)
+        ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
+        out = self.model.generate(
+            input_ids=torch.from_numpy(ids).view(1, -1), frames=clip if n_vid else None, frames_layout=frames_layout,
+            past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=False,
+            repetition_penalty=repetition_penalty, max_new_tokens=max_new_tokens,
+            min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id)
+        seq = out.sequences[0].cpu().numpy()
+        state["past_key_values"] = out.past_key_values
+        state["past_ids"] = seq[:-1]
+        state["turn_index"] = turn + 1
+        return seq[len(ids):].tolist(), state
+
+    @torch.inference_mode()
     def live_cc_once_for_evaluation(self, clip: torch.Tensor, frames_layout: str = "TCHW", max_new_tokens: int = 32,
                                     repetition_penalty: float = 1.05, video_start: float = 0.0, force_length: bool = False):
         """Offline replay of a whole clip (ref infer.py:244-310): chunks 6,2,2,...; returns [[t0, t1, text], ...]."""

@@ -228,11 +228,20 @@ class LiveCCForConditionalGeneration:
         sp = Sampling(repetition_penalty=repetition_penalty, eos_token=eos, suppress_eos=force_length,
                       thr_token=thr[0] if thr else -1, thr_base=thr[1] if thr else None, thr_step=thr[2] if thr else 0.0)
         eng.prefill(slots, ids_new, pos3, vit, sp, scores_out=scores_buf, logits_out=logits_buf)
-        if max_new_tokens > 1:
-            for b0 in range(0, n, 16):   # decode batches of <= 16 streams (one MFMA column tile)
-                eng.decode(slots[b0:b0 + 16], max_new_tokens - 1, 1, sp,
-                           scores_out=scores_buf[b0:b0 + 16] if scores_buf is not None else None,
+        # decode: the device loop needs no host round trip per token (EOS freezes a slot on the device); long generations
+        # (video_qa: max_new_tokens=512, ref demo/infer.py:236) are cut into chunks of 32 steps so that the host can stop
+        # early once every stream has emitted EOS.
+        chunk = max_new_tokens - 1 if force_length else 32
+        for b0 in range(0, n, 16):   # decode batches of <= 16 streams (one MFMA column tile)
+            grp = slots[b0:b0 + 16]
+            step = 1
+            while step < max_new_tokens:
+                k = min(chunk, max_new_tokens - step)
+                eng.decode(grp, k, step, sp, scores_out=scores_buf[b0:b0 + 16] if scores_buf is not None else None,
                            logits_out=logits_buf if (logits_buf is not None and n <= 16) else None)
+                step += k
+                if step < max_new_tokens and all(eng.generated_count(s) < step for s in grp):
+                    break
         outs = []
         for b, st in enumerate(states):
             toks = eng.read_tokens(st.slot, max_new_tokens)

@@ -11,8 +11,8 @@ Everything here restates *orchestration* of the reference, citing the lines it f
                                                                            and ref livecc_utils/video_process_patch.py:88-124
 
 There are no tokenizer files offline, so turn ids are *synthesised* with the real structure
-(special ids at the real places, text ids drawn from a seeded generator).  When a tokenizer is
-available `TurnBuilder.from_tokenizer` produces the real ids instead.
+(special ids at the real places, text ids drawn from a seeded generator); with a checkpoint directory the HF
+processor/tokenizer produce the real ids and are passed to `generate()` unchanged.
 """
 from __future__ import annotations
 
@@ -181,7 +181,8 @@ class TurnBuilder:
             ids += [c.eos_token_id] + self._text(1)   # '<|im_end|>' + '\n'   (ref demo/infer.py:150)
         ids += self._text(3)                      # <|im_start|>user\n
         ids += self._text(10)                     # Time=a-bs
-        ids += [c.vision_start_token_id] + [c.video_token_id] * n_video_tokens + [c.vision_end_token_id]
+        if n_video_tokens > 0:
+            ids += [c.vision_start_token_id] + [c.video_token_id] * n_video_tokens + [c.vision_end_token_id]
         if with_query:
             ids += self._text(self.query_len)
         ids += [c.eos_token_id] + self._text(4)   # <|im_end|>\n<|im_start|>assistant\n

@@ -28,7 +28,7 @@ def _build(cfg, dev, seed=0, init_scale=1.0):
     hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=seed, init_scale=init_scale)
     hf32 = O.build_hf_model(cfg, dtype=torch.float32, seed=seed, init_scale=init_scale)
     native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=4, max_kv_len=4096,
-                                                          max_new_rows=2048, max_patches=8192, max_history=32)
+                                                          max_new_rows=2048, max_patches=8192, max_history=64)
     return hf16, hf32, native
 
 
@@ -211,3 +211,61 @@ def test_streaming_generate_matches_oracle_small(dev, name):
     builder = protocol.TurnBuilder(cfg, seed=77)
     turns = _replay_native(native, cfg, frames, builder, max_new_tokens=8, repetition_penalty=1.15, max_turns=2)
     _compare_stream(cfg, hf16, hf32, turns, frames, "stream_small", 1.15)
+
+
+def test_video_qa_one_shot_prefill_then_text_turns(dev, tiny_models):
+    """ref demo/infer.py:182-242 (video_qa): whole clip in ONE prefill (grid_t = 4 > max(h,w)/2 = 3, where the HF 5.15
+    text-offset rule differs from 4.5x -- SURVEY 8c-3), then a text-only turn on the carried KV; long generation runs in
+    32-step chunks with early exit on EOS."""
+    from livecc_amd import protocol
+    from oracle import hf_oracle as O
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=9, layout="TCHW"))
+    builder = protocol.TurnBuilder(cfg, seed=9, query_len=7)
+    grid = protocol.grid_of(8, 56, 84, cfg)
+    assert grid == (4, 4, 6)
+    t0 = builder.turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    t1 = builder.turn_ids(1, 0, with_query=True)
+    assert (t1 == cfg.video_token_id).sum() == 0
+    s16, s32 = O.OracleStream(hf16, cfg), O.OracleStream(hf32, cfg)
+    state, past = None, None
+    pv, g = O.patchify_normalize_ref(frames, cfg)
+    for ti, (new, n_tok) in enumerate([(t0, 40), (t1, 6)]):
+        ids = new if past is None else np.concatenate([past, new])
+        r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames if ti == 0 else None, past_key_values=state,
+                            repetition_penalty=1.05, max_new_tokens=n_tok, min_new_tokens=n_tok, output_logits=True)
+        state = r.past_key_values
+        seq = r.sequences[0].cpu().numpy()
+        toks = seq[len(ids):].tolist()
+        assert len(toks) == n_tok
+        past = seq[:-1]
+        r16 = s16.turn(new, pv if ti == 0 else None, g if ti == 0 else None, max_new_tokens=n_tok, repetition_penalty=1.05,
+                       teacher_tokens=toks)
+        r32 = s32.turn(new, pv if ti == 0 else None, g if ti == 0 else None, max_new_tokens=n_tok, repetition_penalty=1.05,
+                       teacher_tokens=toks)
+        for k in range(n_tok):
+            ln, l16, l32 = r.logits[k].float().cpu(), r16["logits"][k], r32["logits"][k]
+            scale = l32.abs().max().item()
+            assert (ln - l16).abs().max().item() <= 6e-2 * scale, f"turn {ti} step {k}"
+            assert (ln - l32).abs().max().item() <= 1.5 * (l16 - l32).abs().max().item() + (1e-3 + 2.0 ** -7) * scale
+    assert state.get_seq_length() == len(past)
+    state.release()
+
+
+def test_long_generation_stops_early_on_eos(dev, tiny_models):
+    """max_new_tokens = 60 (> the 32-step decode chunk): after EOS the stream is frozen on the device and the host loop exits."""
+    from livecc_amd import protocol
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(2, 56, 56, seed=4, layout="TCHW"))
+    ids = protocol.TurnBuilder(cfg, seed=4).turn_ids(0, protocol.num_video_tokens(protocol.grid_of(2, 56, 56, cfg), cfg))
+    r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, max_new_tokens=60, min_new_tokens=60)
+    toks = r.sequences[0, len(ids):].tolist()
+    r.past_key_values.release()
+    assert len(toks) == 60
+    eos = toks[40]
+    first = toks.index(eos)
+    r2 = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, max_new_tokens=60, eos_token_id=eos)
+    got = r2.sequences[0, len(ids):].tolist()
+    assert got == toks[:first + 1]
+    assert r2.past_key_values.get_seq_length() == len(ids) + first
+    r2.past_key_values.release()
