@@ -269,3 +269,27 @@ def test_long_generation_stops_early_on_eos(dev, tiny_models):
     assert got == toks[:first + 1]
     assert r2.past_key_values.get_seq_length() == len(ids) + first
     r2.past_key_values.release()
+
+
+def test_one_shot_long_clip_positions_follow_rope_delta(dev, tiny_models):
+    """grid_t (8) >> max(h,w)/2 (2): the largest M-RoPE position sits on a VIDEO row, so the decode positions must continue
+    from max(position)+1 = kv_len + rope_delta (HF Q2VL:1014,1349-1351), not from the last prompt row."""
+    from livecc_amd import protocol
+    from oracle import hf_oracle as O
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(16, 56, 56, seed=21, layout="TCHW"))
+    grid = protocol.grid_of(16, 56, 56, cfg)
+    assert grid == (8, 4, 4)
+    ids = protocol.TurnBuilder(cfg, seed=21).turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    pos, delta = protocol.rope_index_first_turn(ids, [grid], cfg)
+    assert pos.max() > pos[:, -1].max(), "test premise: the maximum position is not on the last row"
+    r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, repetition_penalty=1.05, max_new_tokens=6,
+                        min_new_tokens=6, output_logits=True)
+    toks = r.sequences[0, len(ids):].tolist()
+    assert native.engine.slot_length(r.past_key_values.slot) == (len(ids) + 5, len(ids) + 5 + delta)
+    r.past_key_values.release()
+    pv, g = O.patchify_normalize_ref(frames, cfg)
+    ro = O.OracleStream(hf16, cfg).turn(ids, pv, g, max_new_tokens=6, repetition_penalty=1.05, teacher_tokens=toks)
+    for k in range(6):
+        lo, ln = ro["logits"][k], r.logits[k].float().cpu()
+        assert (ln - lo).abs().max().item() <= 6e-2 * lo.abs().max().item(), f"step {k}"
