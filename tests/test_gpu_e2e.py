@@ -272,14 +272,14 @@ def test_long_generation_stops_early_on_eos(dev, tiny_models):
 
 
 def test_one_shot_long_clip_positions_follow_rope_delta(dev, tiny_models):
-    """grid_t (8) >> max(h,w)/2 (2): the largest M-RoPE position sits on a VIDEO row, so the decode positions must continue
+    """grid_t (16) >> max(h,w)/2 (2): the largest M-RoPE position sits on a VIDEO row, so the decode positions must continue
     from max(position)+1 = kv_len + rope_delta (HF Q2VL:1014,1349-1351), not from the last prompt row."""
     from livecc_amd import protocol
     from oracle import hf_oracle as O
     cfg, hf16, hf32, native = tiny_models
-    frames = torch.from_numpy(protocol.synth_frames(16, 56, 56, seed=21, layout="TCHW"))
-    grid = protocol.grid_of(16, 56, 56, cfg)
-    assert grid == (8, 4, 4)
+    frames = torch.from_numpy(protocol.synth_frames(32, 56, 56, seed=21, layout="TCHW"))
+    grid = protocol.grid_of(32, 56, 56, cfg)
+    assert grid == (16, 4, 4)
     ids = protocol.TurnBuilder(cfg, seed=21).turn_ids(0, protocol.num_video_tokens(grid, cfg))
     pos, delta = protocol.rope_index_first_turn(ids, [grid], cfg)
     assert pos.max() > pos[:, -1].max(), "test premise: the maximum position is not on the last row"
