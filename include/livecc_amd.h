@@ -61,6 +61,9 @@ int lcc_debug_set_gemm_variant(int variant);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 (default) = prefill shares K/V tiles through an LDS-DMA ring,
  * ViT per-wave; 2 = LDS-shared for both */
 int lcc_debug_set_attn_variant(int variant);
+/* 1 (default): on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add +
+ * RMSNorm) run as the TAIL of that GEMV in its last-arriving block (agent-scope release/acquire), 0: separate kernels */
+int lcc_debug_set_fused_tails(int on);
 int lcc_gemv_num_splits(int N, int K);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
 int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream);

@@ -116,6 +116,7 @@ struct lcc_engine {
 
   // device state (inside `state`)
   int32_t *d_kv_len = nullptr, *d_pos = nullptr, *d_hist_col = nullptr, *d_cur_tok = nullptr, *d_done = nullptr, *d_history = nullptr;
+  int32_t* d_counter = nullptr;   // arrival counter of the fused GEMV tails (zero between launches)
   uint32_t* d_seen = nullptr;
   bf16_t** d_kv_base = nullptr;
   // optional live timing of the dominant kernel (decode gate/up GEMV): hipEvent pairs on the launch stream
@@ -209,7 +210,7 @@ extern "C" int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, 
 extern "C" size_t lcc_engine_workspace_bytes(const lcc_engine* e) { return std::max(e->llm_ws_bytes(), e->vit_ws_bytes()); }
 extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
   const size_t B = e->lim.max_slots;
-  return align_up(B * 4) * 5 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096;
+  return align_up(B * 4) * 5 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096;
 }
 extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->lay.total() * 2; }
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
@@ -233,7 +234,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
   const size_t B = e->lim.max_slots;
   Carver cv; cv.base = e->state;
   e->d_kv_len = cv.take<int32_t>(B); e->d_pos = cv.take<int32_t>(B); e->d_hist_col = cv.take<int32_t>(B);
-  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_kv_base = cv.take<bf16_t*>(B);
+  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_kv_base = cv.take<bf16_t*>(B);
   e->d_history = cv.take<int32_t>(B * (size_t)e->lim.max_history);
   e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
   HIP_TRY(hipMemset(e->state, 0, state_bytes));
@@ -479,6 +480,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
 // LLM
 // ------------------------------------------------------------------------------------------------
 namespace {
+int g_fuse_tails = 1;   // 1: batch-1 decode runs rope/KV-append and residual+RMSNorm as tails of the producing GEMV
 struct LlmBuffers {
   bf16_t *h, *xn, *qkv, *q, *attn, *act, *cos, *sin, *last_h, *last_xn, *logits;
   float *partial, *ws_o, *ws_ml;
@@ -521,7 +523,14 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     GemmArgs g;
     // q/k/v projection (+bias) -> M-RoPE -> in-place KV append
     g = GemmArgs(); g.w_packed = 1; g.A = b.xn; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
-    if (cx.skinny) {
+    const bool fuse = cx.skinny && S <= 2 && g_fuse_tails;   // batch-1 decode: consumer ops run as GEMV tails
+    if (fuse) {
+      g.partial = b.partial; g.nsplit = sp_qkv;
+      g.tail.kind = 2; g.tail.counter = e->d_counter; g.tail.bias = L.qkv_b; g.tail.cs = b.cos; g.tail.sn = b.sin;
+      g.tail.tok_stream = cx.tok_stream; g.tail.tok_pos = cx.tok_pos; g.tail.kv_len = e->d_kv_len; g.tail.kv_base = e->d_kv_base;
+      g.tail.lay = e->lay; g.tail.layer = l; g.tail.q_out = b.q; g.tail.n_q_heads = e->c.n_q_heads;
+      LCC_TRY(gemm_bf16(g, st));
+    } else if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_qkv;
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(rope_kv_append_bf16(nullptr, b.partial, sp_qkv, L.qkv_b, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
@@ -541,7 +550,11 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
                                 cx.n_tiles, e->c.n_q_heads, cx.tile_rows, cx.kv_split, S, b.ws_o, b.ws_ml, st));
     // o_proj + residual + post-attention RMSNorm
     g = GemmArgs(); g.w_packed = 1; g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
-    if (cx.skinny) {
+    if (fuse) {
+      g.partial = b.partial; g.nsplit = sp_o;
+      g.tail.kind = 1; g.tail.counter = e->d_counter; g.tail.h = b.h; g.tail.norm_w = L.post_norm; g.tail.y = b.xn; g.tail.eps = eps;
+      LCC_TRY(gemm_bf16(g, st));
+    } else if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_o;
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, sp_o, L.post_norm, b.xn, S, H, eps, st));
@@ -562,7 +575,11 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     LCC_TRY(gemm_bf16(g, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
     g = GemmArgs(); g.w_packed = 1; g.A = b.act; g.lda = I; g.W = L.down_w; g.ldw = I; g.M = S; g.N = H; g.K = I;
-    if (cx.skinny) {
+    if (fuse) {
+      g.partial = b.partial; g.nsplit = sp_dn;
+      g.tail.kind = 1; g.tail.counter = e->d_counter; g.tail.h = b.h; g.tail.norm_w = next_norm; g.tail.y = b.xn; g.tail.eps = eps;
+      LCC_TRY(gemm_bf16(g, st));
+    } else if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_dn;
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(add_rmsnorm_bf16(b.h, nullptr, b.partial, sp_dn, next_norm, b.xn, S, H, eps, st));
@@ -743,6 +760,8 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   return check_launch("lcc_llm_decode");
 }
 
+extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
+
 // ------------------------------------------------------------------------------------------------
 // operator-level C-ABI wrappers
 // ------------------------------------------------------------------------------------------------
@@ -757,6 +776,7 @@ static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_hea
 extern "C" int lcc_debug_set_gemv_variant(int variant) { set_gemv_variant(variant); return 0; }
 extern "C" int lcc_debug_set_gemm_variant(int variant) { set_gemm_variant(variant); return 0; }
 extern "C" int lcc_debug_set_attn_variant(int variant) { set_attn_variant(variant); return 0; }
+extern "C" int lcc_debug_set_fused_tails(int on);
 extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual,
                              int ldr, void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {
   if (!A || !W || (!C && !partial)) return fail(LCC_ERR_ARG, "lcc_gemm_bf16: null pointer");

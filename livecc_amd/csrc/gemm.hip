@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "tail_ops.h"
 
 namespace lcc {
 
@@ -371,7 +372,7 @@ __device__ unsigned int lcc_zero_page_g[64];  // 256 zero bytes: x operand of ab
 template <int NTILE, int MODE, bool PACKED, int UNR, int PIPE>
 __global__ __launch_bounds__(256) void gemv_skinny_kernel(
     const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
-    const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int chunks_per_split) {
+    const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int chunks_per_split, GemvTail tail) {
   constexpr int NW = 4;
   __shared__ f32x4 red[NW - 1][NTILE][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
@@ -444,6 +445,50 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
     for (int t = 0; t < NTILE; ++t) red[wave - 1][t][lane] = acc[t];
   }
   __syncthreads();
+  if (MODE == 3) {
+    // split-K slabs + FUSED TAIL.  Publish/consume protocol (cdna_hip_programming.md G16, counter form): slab stores ->
+    // vmcnt(0) -> __syncthreads -> one lane: agent-scope release + vmcnt(0) + relaxed agent fetch_add (ticket).  The block that
+    // draws the last ticket: one lane agent-scope acquire -> __syncthreads -> plain loads of every slab.  Placement-independent.
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
+      if (li < M) {
+        float* o = (float*)out + ((size_t)split * M + li) * ldo;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+          const int n = n0 + t * 16 + g * 4;
+          if (n < N) *reinterpret_cast<f32x4*>(o + n) = acc[t];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    float* flag = reinterpret_cast<float*>(&red[0][0][0]);   // all LDS in ONE array
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(tail.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = (ticket == (int)(gridDim.x * gridDim.y) - 1) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (flag[0] == 0.f) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const int nsplit = gridDim.y;
+    if (tail.kind == 1) {
+      for (int m = 0; m < M; ++m)
+        tail_add_rmsnorm_row(tail.h + (size_t)m * N, (const float*)out, nsplit, (size_t)M * ldo, (size_t)m * ldo, tail.norm_w,
+                             tail.y + (size_t)m * N, N, tail.eps, flag + 8);
+    } else {
+      RopeTailArgs ra{tail.bias, tail.cs, tail.sn, tail.tok_stream, tail.tok_pos, tail.kv_len, tail.kv_base, tail.lay, tail.layer,
+                      tail.q_out, tail.n_q_heads};
+      tail_rope_kv_append((const float*)out, nsplit, M, ra);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(tail.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    return;
+  }
   if (wave > 0) return;
 #pragma unroll
   for (int t = 0; t < NTILE; ++t)
@@ -491,13 +536,13 @@ template <int NTILE, int MODE, bool PACKED>
 static void launch_gemv(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
   switch (g_gemv_variant) {
     case 1:
-      gemv_skinny_kernel<NTILE, MODE, PACKED, 1, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps);
+      gemv_skinny_kernel<NTILE, MODE, PACKED, 1, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps, a.tail);
       break;
     case 2:
-      gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps);
+      gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps, a.tail);
       break;
     default:
-      gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 0><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps);
+      gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 0><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps, a.tail);
   }
 }
 template <int NTILE, int MODE>
@@ -563,6 +608,12 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
     } else if (a.partial != nullptr) {
       const int S = a.nsplit > 0 ? a.nsplit : 1;
       if (S > nchunk) return LCC_ERR_SHAPE;
+      if (a.tail.kind != 0) {   // fused tail: last-arriving block reduces the slabs and runs the consumer (M <= 2, packed W)
+        if (a.M > 2 || !a.w_packed || a.tail.counter == nullptr || S > 8 || (a.tail.kind == 1 && (a.N > 8192 || (a.N & 7)))) return LCC_ERR_ARG;
+        gemv_skinny_kernel<1, 3, true, 1, 1><<<dim3((a.N + 15) / 16, S), dim3(256), 0, st>>>(
+            a.A, a.lda, a.W, a.ldw, nullptr, a.partial, a.N, a.M, a.N, a.K, (nchunk + S - 1) / S, a.tail);
+        return 0;
+      }
       launch_gemv_l<1, 0>(dim3((a.N + 15) / 16, S), a, a.partial, a.N, (nchunk + S - 1) / S, st);
     } else {
       launch_gemv_l<1, 1>(dim3((a.N + 15) / 16, 1), a, a.C, a.ldc, nchunk, st);

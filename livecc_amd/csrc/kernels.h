@@ -10,7 +10,27 @@ namespace lcc {
 typedef unsigned short bf16_t;
 
 
+// ---- per-stream KV arena layout ----
+struct KvLayout {  // per-stream KV arena: [layer][K|V][Hkv][Lmax][128]; V blocked-transposed [Lmax/32][128][32]
+  int n_layers, n_kv_heads, lmax, head_dim;
+  __host__ __device__ size_t head_stride() const { return (size_t)lmax * head_dim; }
+  __host__ __device__ size_t kv_stride() const { return (size_t)n_kv_heads * lmax * head_dim; }
+  __host__ __device__ size_t layer_stride() const { return (size_t)2 * n_kv_heads * lmax * head_dim; }
+  __host__ __device__ size_t total() const { return (size_t)n_layers * layer_stride(); }
+};
+
 // ---- GEMM (gemm.hip) ----
+// optional fused tail of a split-K skinny GEMV (M <= 2): the last-arriving block reduces the slabs and runs the consumer
+struct GemvTail {
+  int kind = 0;                 // 0 none; 1 residual add + RMSNorm; 2 bias + M-RoPE + KV append
+  int32_t* counter = nullptr;   // device word, zero before the launch (the tail resets it)
+  // kind 1
+  bf16_t* h = nullptr; const bf16_t* norm_w = nullptr; bf16_t* y = nullptr; float eps = 0.f;
+  // kind 2
+  const bf16_t* bias = nullptr; const bf16_t* cs = nullptr; const bf16_t* sn = nullptr;
+  const int32_t* tok_stream = nullptr; const int32_t* tok_pos = nullptr; const int32_t* kv_len = nullptr;
+  bf16_t* const* kv_base = nullptr; KvLayout lay = {0, 0, 0, 0}; int layer = 0; bf16_t* q_out = nullptr; int n_q_heads = 0;
+};
 struct GemmArgs {
   const bf16_t* A = nullptr; int lda = 0;       // [M,K]
   const bf16_t* W = nullptr; int ldw = 0;       // [N,K] row-major, or packed fragments (w_packed, ldw ignored)
@@ -21,6 +41,7 @@ struct GemmArgs {
   float* partial = nullptr; int nsplit = 0;     // fp32 split-K slabs [nsplit][M][N] instead of C (consumer reduces)
   int M = 0, N = 0, K = 0;
   int epilogue = 0;
+  GemvTail tail;
 };
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
 int gemv_num_splits(int N, int K);
@@ -47,13 +68,6 @@ int mrope_table_decode(const int32_t* slots, const int32_t* pos, const float* in
                        hipStream_t st);
 int swiglu_bf16(const bf16_t* g, const bf16_t* u, bf16_t* out, int64_t n, hipStream_t st);
 
-struct KvLayout {  // per-stream KV arena: [layer][K|V][Hkv][Lmax][128]; V blocked-transposed [Lmax/32][128][32]
-  int n_layers, n_kv_heads, lmax, head_dim;
-  __host__ __device__ size_t head_stride() const { return (size_t)lmax * head_dim; }
-  __host__ __device__ size_t kv_stride() const { return (size_t)n_kv_heads * lmax * head_dim; }
-  __host__ __device__ size_t layer_stride() const { return (size_t)2 * n_kv_heads * lmax * head_dim; }
-  __host__ __device__ size_t total() const { return (size_t)n_layers * layer_stride(); }
-};
 int rope_kv_append_bf16(const bf16_t* qkv_bf16, const float* qkv_partial, int nsplit, const bf16_t* bias,
                         const bf16_t* cos, const bf16_t* sin, const int32_t* tok_stream, const int32_t* tok_pos,
                         const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay, int layer, bf16_t* q_out, int S,

@@ -133,16 +133,33 @@ def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_pena
     assert n_exact >= 0.8 * n_steps, f"{name}: only {n_exact}/{n_steps} greedy tokens identical to the bf16 oracle"
 
 
-@pytest.mark.parametrize("use_pixel_values", [False, True])
-def test_streaming_generate_matches_oracle_tiny(dev, tiny_models, use_pixel_values):
-    from livecc_amd import protocol
+@pytest.mark.parametrize("use_pixel_values,fused_tails", [(False, 1), (True, 1), (False, 0)])
+def test_streaming_generate_matches_oracle_tiny(dev, tiny_models, use_pixel_values, fused_tails):
+    """fused_tails 1 (default): batch-1 decode runs rope/KV-append and residual+RMSNorm in the last-arriving block of the
+    producing split-K GEMV; 0: the same ops as separate kernels.  Both must give the same tokens."""
+    from livecc_amd import _lib, protocol
     cfg, hf16, hf32, native = tiny_models
+    _lib.load().lcc_debug_set_fused_tails(fused_tails)
+    try:
+        _run_stream_tiny(cfg, hf16, hf32, native, use_pixel_values, fused_tails)
+    finally:
+        _lib.load().lcc_debug_set_fused_tails(1)
+
+
+_TOKENS_SEEN = {}
+
+
+def _run_stream_tiny(cfg, hf16, hf32, native, use_pixel_values, fused_tails):
+    from livecc_amd import protocol
     frames = torch.from_numpy(protocol.synth_frames(10, 56, 84, seed=1234, layout="TCHW"))
     builder = protocol.TurnBuilder(cfg, seed=1234)
     turns = _replay_native(native, cfg, frames, builder, max_new_tokens=8, repetition_penalty=1.05, max_turns=3,
                            use_pixel_values=use_pixel_values)
     assert [t["grid"] for t in turns] == [(3, 4, 6), (1, 4, 6), (1, 4, 6)]
-    _compare_stream(cfg, hf16, hf32, turns, frames, f"stream_tiny[pv={use_pixel_values}]", 1.05)
+    _compare_stream(cfg, hf16, hf32, turns, frames, f"stream_tiny[pv={use_pixel_values},fused={fused_tails}]", 1.05)
+    toks = [t["new_tokens"] for t in turns]
+    prev = _TOKENS_SEEN.setdefault("tiny", toks)
+    assert toks == prev, "fused / unfused / pixel_values paths must generate identical tokens (bit-identical arithmetic)"
 
 
 def test_interleaved_streams_are_independent(dev, tiny_models):
