@@ -480,7 +480,9 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
 // LLM
 // ------------------------------------------------------------------------------------------------
 namespace {
-int g_fuse_tails = 1;   // 1: batch-1 decode runs rope/KV-append and residual+RMSNorm as tails of the producing GEMV
+int g_fuse_tails = 0;   // 1: batch-1 decode runs rope/KV-append and residual+RMSNorm as tails of the producing GEMV (last-arriving
+                        // block, ticket counter).  Measured on MI355X at 7B shapes: 184 tok/s fused vs 215 tok/s with separate
+                        // kernels (the slab write-through + ticket serialises the GEMV's tail), so it stays an opt-in variant.
 struct LlmBuffers {
   bf16_t *h, *xn, *qkv, *q, *attn, *act, *cos, *sin, *last_h, *last_xn, *logits;
   float *partial, *ws_o, *ws_ml;
@@ -698,10 +700,12 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
   row = 0;
   for (int b = 0; b < n_streams; ++b) {
     const int s = slots[b];
-    // HF: the next position is kv_len + rope_delta with rope_delta = max(position) + 1 - len (Q2VL:1014, 1349-1351), i.e.
-    // max over ALL rows and axes + 1 -- for a long one-shot video the maximum can sit on a video row, not on the last row
-    int mx = 0;
-    for (int i = row; i < row + n_new[b]; ++i) mx = std::max(mx, std::max(pos3[i], std::max(pos3[S + i], pos3[2 * S + i])));
+    // In-call decode positions continue from the LAST prompt row (+1 on every axis): HF generation/utils.py:975-985 extends
+    // position_ids[..., -1:] + 1.  The prompt always ends in text (assistant header), where the three axes are equal; under
+    // the transformers-4.5x text-offset rule that row also holds the maximum, i.e. this equals kv_len + rope_delta
+    // (Q2VL:1014).  The NEXT call's positions are past_len + i + rope_delta, computed by the host (protocol.positions_with_cache).
+    const int last = row + n_new[b] - 1;
+    const int mx = std::max(pos3[last], std::max(pos3[S + last], pos3[2 * S + last]));
     e->h_kv_len[s] += n_new[b];
     e->h_pos[s] = mx + 1;
     row += n_new[b];

@@ -446,9 +446,9 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   }
   __syncthreads();
   if (MODE == 3) {
-    // split-K slabs + FUSED TAIL.  Publish/consume protocol (cdna_hip_programming.md G16, counter form): slab stores ->
-    // vmcnt(0) -> __syncthreads -> one lane: agent-scope release + vmcnt(0) + relaxed agent fetch_add (ticket).  The block that
-    // draws the last ticket: one lane agent-scope acquire -> __syncthreads -> plain loads of every slab.  Placement-independent.
+    // split-K slabs + FUSED TAIL.  Publish/consume protocol (cdna_hip_programming.md G16 R1, counter form): write-through (sc1)
+    // slab stores -> vmcnt(0) -> __syncthreads -> one lane: relaxed agent fetch_add (ticket).  The block that draws the last
+    // ticket: one lane agent-scope acquire -> __syncthreads -> plain loads of every slab.  Placement-independent.
     if (wave == 0) {
 #pragma unroll
       for (int t = 0; t < NTILE; ++t)
@@ -459,16 +459,23 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
           const int n = n0 + t * 16 + g * 4;
-          if (n < N) *reinterpret_cast<f32x4*>(o + n) = acc[t];
+          if (n < N) {
+            // write-through (sc1) slab stores: relaxed agent-scope 8-byte atomic stores lower to `global_store_dwordx2 sc0 sc1`,
+            // so NO per-block release fence (buffer_wbl2) is needed -- measured: a release fence in each of the ~900 blocks
+            // made the whole kernel ~17 us slower
+            unsigned long long* p8 = reinterpret_cast<unsigned long long*>(o + n);
+            const unsigned long long lo = (unsigned long long)__float_as_uint(acc[t][0]) | ((unsigned long long)__float_as_uint(acc[t][1]) << 32);
+            const unsigned long long hi = (unsigned long long)__float_as_uint(acc[t][2]) | ((unsigned long long)__float_as_uint(acc[t][3]) << 32);
+            __hip_atomic_store(p8, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p8 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
     }
     __syncthreads();
     float* flag = reinterpret_cast<float*>(&red[0][0][0]);   // all LDS in ONE array
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(tail.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag[0] = (ticket == (int)(gridDim.x * gridDim.y) - 1) ? 1.f : 0.f;
     }
