@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--fused-tails", type=int, default=None, choices=[0, 1],
                     help="debug A/B: fuse add+rmsnorm / rope+append into the decode GEMV tails (default: library default)")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock budget of the CPU baseline leg, seconds")
@@ -154,6 +155,9 @@ def main():
     if args.fused_tails is not None:
         from livecc_amd import _lib
         _lib.load().lcc_debug_set_fused_tails(args.fused_tails)
+    if args.gemm_variant is not None:
+        from livecc_amd import ops
+        ops.set_gemm_variant(args.gemm_variant)
     model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
                                            max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
                                            max_history=max(16, args.max_new_tokens))

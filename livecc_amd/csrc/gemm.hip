@@ -30,21 +30,33 @@ template <int EPI, int MT, int NT>
 LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int ocbase, int li, int g,
                               const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
                               bf16_t* __restrict__ C, int ldc, int M, int N, float* __restrict__ partial) {
+  // Loads (bias: once per column group; residual: NT per row tile) are issued unconditionally from clamped addresses and
+  // back to back, so that they overlap instead of one L2 round trip per (row tile, column group); only the stores are
+  // predicated on the M / N edges.
+  u32x2 bv[NT];
+  if (EPI != EPI_PARTIAL && EPI != EPI_SWIGLU) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = (u32x2){0u, 0u};
+    if (bias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = ld8(bias + min(nbase + j * 16 + g * 4, N - 4));
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = mbase + i * 16 + li;
-    if (m >= M) continue;
+    const bool mok = m < M;
+    const int mc = min(m, M - 1);
     if (EPI == EPI_PARTIAL) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = nbase + j * 16 + g * 4;
-        if (n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j];
+        if (mok && n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j];
       }
     } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
       for (int j = 0; j < NT; j += 2) {
         const int n = nbase + j * 16 + g * 4;  // column in the interleaved [gate16|up16] space
-        if (n >= N) continue;
         const int oc = ocbase + (j / 2) * 16 + g * 4;
         float o[4];
 #pragma unroll
@@ -52,22 +64,22 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, 
           float gate = rbf(acc[i][j][r]), up = rbf(acc[i][j + 1][r]);
           o[r] = silu_bf16(gate) * up;
         }
-        st8(C + (size_t)m * ldc + oc, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
+        if (mok && n < N) st8(C + (size_t)m * ldc + oc, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
       }
     } else {
+      u32x2 rv[NT];
+      if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rv[j] = ld8(residual + (size_t)mc * ldr + min(nbase + j * 16 + g * 4, N - 4));
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = nbase + j * 16 + g * 4;
-        if (n >= N) continue;
         float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        if (bias != nullptr) {
-          u32x2 b = ld8(bias + n);
-          v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        v[0] = rbf(acc[i][j][0] + lo2f(bv[j].x));
+        v[1] = rbf(acc[i][j][1] + hi2f(bv[j].x));
+        v[2] = rbf(acc[i][j][2] + lo2f(bv[j].y));
+        v[3] = rbf(acc[i][j][3] + hi2f(bv[j].y));
         if (EPI == EPI_QUICK_GELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = quick_gelu_bf16(v[r]);
@@ -75,10 +87,9 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, 
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_erf_bf16(v[r]);
         } else if (EPI == EPI_RESIDUAL) {
-          u32x2 q = ld8(residual + (size_t)m * ldr + n);
-          v[0] += lo2f(q.x); v[1] += hi2f(q.x); v[2] += lo2f(q.y); v[3] += hi2f(q.y);
+          v[0] += lo2f(rv[j].x); v[1] += hi2f(rv[j].x); v[2] += lo2f(rv[j].y); v[3] += hi2f(rv[j].y);
         }
-        st8(C + (size_t)m * ldc + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+        if (mok && n < N) st8(C + (size_t)m * ldc + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
       }
     }
   }
@@ -316,17 +327,164 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
   tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
 }
 
+// ------------------------------------------------------------------------------------------------
+// tiled GEMM v3: 8 waves, BM x 256 x 64 block tile (BM = 256 or 128), LDS-DMA for both operands
+// ------------------------------------------------------------------------------------------------
+// The 64x128 / 128x128 tiles above move (1/BM + 1/BN) bytes per flop from L2 into LDS = 0.023 / 0.016 B/flop, i.e. 95 / 64
+// B/clk/CU at the MFMA peak -- above what the L2->CU path delivers, so they top out at 20-29 % of the bf16 peak.  A 256x256
+// tile needs 0.0078 B/flop (32 B/clk/CU).  8 waves = 2 (M) x 4 (N), wave tile (BM/2) x 64, 64 MFMAs per wave per k-tile.
+//   * W (packed fragment order in HBM): one DMA instruction copies one 1-KB (16 rows, 32 k) fragment sub-tile; the fragment
+//     read is the linear, conflict-free ds_read_b128 of slot `lane` (as in gemm_glds_kernel).
+//   * A (row-major activations): staged in FULL 128-byte lines -- one DMA instruction = 8 rows x 128 B -- into a [BM][8 x 16 B]
+//     image whose 16-byte chunks are XOR-swizzled with (row & 7).  LDS-DMA writes lane-linear, so the swizzle is applied to
+//     the per-lane SOURCE chunk and again on the fragment read (the same involution on both sides).  Full-line reads keep the
+//     texture-address path at one request per 128 B instead of the 16 rows x 64 B gather of a fragment-shaped load.
+//   * pipeline: BM = 256: two 64-KB stages (128 KB), vmcnt(0) + s_barrier per k-tile, the DMA of tile kt+1 runs under the
+//     MFMAs of tile kt.  BM = 128: three 48-KB stages, counted vmcnt so that one tile stays in flight across the barrier.
+// Requires packed W, K % 64 == 0 (every shape of the 7B/2B/72B models except the 1176-wide patch embedding).
+template <int BM, int EPI, int SCHED>
+__global__ __launch_bounds__(512) void gemm_big_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
+    float* __restrict__ partial, int kt_per_split) {
+  constexpr int BN = 256, BK = 64, NSTAGE = (BM == 256) ? 2 : 3;
+  constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
+  constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
+  constexpr int B_SUB = (BN / 16) * 2;            // 1-KB fragment sub-tiles of the W tile
+  constexpr int STAGE = A_UNITS + B_SUB * 64;     // 16-byte units per stage
+  constexpr int A_PER_WAVE = BM / 64;             // 8-row x 128-B pieces per wave (BM/8 pieces over 8 waves)
+  constexpr int B_PER_WAVE = B_SUB / 8;
+  constexpr int G = A_PER_WAVE + B_PER_WAVE;      // DMA instructions per wave per k-tile
+  extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
+
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;   // consecutive ids (one XCD) share the W panel
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 15, g = lane >> 4;
+  const int K32 = K >> 5, nfrag = N >> 4;
+  const bool wave_has_rows = m0 + wm * WM < M;
+
+  const bf16_t* asrc[A_PER_WAVE];
+  const bf16_t* bsrc[B_PER_WAVE];
+#pragma unroll
+  for (int q = 0; q < A_PER_WAVE; ++q) {
+    const int row = (wave * A_PER_WAVE + q) * 8 + (lane >> 3);
+    asrc[q] = A + (size_t)min(m0 + row, M - 1) * lda + (((lane & 7) ^ (lane >> 3)) << 3);
+  }
+#pragma unroll
+  for (int q = 0; q < B_PER_WAVE; ++q) {
+    const int st = wave * B_PER_WAVE + q;          // sub-tile: n-fragment row st >> 1, 32-k block st & 1
+    const int fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
+    bsrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+  }
+
+  auto issue = [&](int kt, int stage) {
+    u32x4* sbase = dsmem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < B_PER_WAVE; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * 1024),
+                                       (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (wave * B_PER_WAVE + q) * 64), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt_all = K / BK;
+  const int kt0 = (EPI == EPI_PARTIAL) ? blockIdx.y * kt_per_split : 0;
+  const int nkt = (EPI == EPI_PARTIAL) ? min(nkt_all, kt0 + kt_per_split) : nkt_all;
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (kt0 + p < nkt) issue(kt0 + p, p);
+
+  // fragment read offsets (16-byte units within a stage)
+  int aoff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (wm * WM + li) * 8 + ((kk * 4 + g) ^ (li & 7));
+  const int boff = A_UNITS + (wn * NT * 2) * 64 + lane;
+
+  for (int kt = kt0; kt < nkt; ++kt) {
+    // this wave's pieces of tile kt have landed; NSTAGE-2 later tiles may stay in flight across the barrier
+    if (NSTAGE == 3 && kt + 1 < nkt) {
+      if (G == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
+    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt0) % NSTAGE);
+    const u32x4* s = dsmem + ((kt - kt0) % NSTAGE) * STAGE;
+    // ragged last row tile (e.g. M = 386 = 3 x 128 + 2): a wave whose WM rows are all past M skips the multiply and only keeps
+    // feeding the DMA ring and the barriers (wave-uniform branch around the whole k-tile body; a finer per-16-row predicate
+    // made hipcc if-convert the accumulators and spill)
+    if (!wave_has_rows) {
+    } else if (SCHED == 0) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 fa[MT], fb[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = as_bf16x8(s[aoff[kk] + i * 128]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+      }
+    } else {
+      // explicit software pipeline of the fragment reads: the 8 W fragments of the k-tile are read up front, the activation
+      // fragments stream through a 3-register ring two steps (8 MFMAs = 128 cycles) ahead of their use; the issue order is
+      // pinned with sched_group_barrier (DS read = 0x100, MFMA = 0x008) so that hipcc does not fall back to read-wait-use.
+      bf16x8 fb[2][NT], fa[3];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[kk][j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+      fa[0] = as_bf16x8(s[aoff[0]]);
+      fa[1] = as_bf16x8(s[aoff[0] + 128]);
+#pragma unroll
+      for (int t = 0; t < 2 * MT; ++t) {
+        if (t + 2 < 2 * MT) fa[(t + 2) % 3] = as_bf16x8(s[aoff[(t + 2) / MT] + ((t + 2) % MT) * 128]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[t % MT][j] = mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2, 0);
+#pragma unroll
+      for (int t = 0; t < 2 * MT; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+      }
+    }
+  }
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
+}
+
 // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel; 2 (default): measured best per tile shape --
 // 64-row tiles (72 KB ring, 2 blocks/CU) take the LDS-DMA kernel (1.5-1.6x), 128-row tiles keep the register-staged
 // kernel (64 KB, 2 blocks/CU; the 96 KB ring would leave 1 block/CU and measured 0.75x).
 static int g_gemm_variant = 2;
-void set_gemm_variant(int v) { g_gemm_variant = v; }
+static int g_gemm_sched = 1;   // fragment-read schedule of gemm_big_kernel: 0 compiler order, 1 pinned software pipeline
+void set_gemm_variant(int v) { g_gemm_variant = v; g_gemm_sched = (v == 5 || v == 6) ? 0 : 1; }
 
 template <int BM, int EPI>
 static void launch_tiled(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 127) / 128;
   const int nkt = (a.K + 63) / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  if (g_gemm_variant == 1 || (g_gemm_variant == 2 && BM == 64)) {
+  if (g_gemm_variant == 1 || ((g_gemm_variant == 2 || g_gemm_variant == 7) && BM == 64)) {   // 7: auto without the 8-wave kernel
     constexpr size_t lds = (size_t)3 * ((BM / 16) * 2 + 16) * 1024;   // 96 KB (BM 128) / 72 KB (BM 64)
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -343,8 +501,57 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
       (nkt + S - 1) / S);
 }
 
+template <int BM, int EPI, int SCHED>
+static void launch_big_s(const GemmArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
+  const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
+  constexpr size_t lds = (size_t)(BM == 256 ? 2 : 3) * (BM * 8 + 2048) * 16;   // 128 KB (BM 256) / 144 KB (BM 128)
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  gemm_big_kernel<BM, EPI, SCHED><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S);
+}
+template <int BM, int EPI>
+static void launch_big(const GemmArgs& a, hipStream_t st) {
+  if (g_gemm_sched) launch_big_s<BM, EPI, 1>(a, st);
+  else launch_big_s<BM, EPI, 0>(a, st);
+}
+static bool big_eligible(const GemmArgs& a) { return a.w_packed && (a.K % 64) == 0 && a.M > 16; }
+
+// 0 = not the 8-wave kernel, else its BM.  Variants 3 / 4 (5 / 6) force BM 256 / 128 wherever the kernel is eligible.
+// Auto (2): estimated relative throughput = row utilisation x wave quantisation x measured tile efficiency.  The 8-wave
+// kernels run one block per CU (256 slots), the 4-wave 64-row kernel two (512 slots).  Measured on MI355X (7B shapes):
+// 256x256 tiles ~1.05-1.1 PF, 128x256 ~0.9 PF, 64x128 ~0.55 PF when the grid fills the chip; with few blocks (qkv at
+// M = 386: 72 blocks of 128x256) the small tile wins.
+static float tile_score(int M, int N, int S, int BM, int BN, int slots, float eff, bool ragged_skip) {
+  const long tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN, blocks = tm * tn * S;
+  const int half = BM / 2, mh = (M + half - 1) / half * half;   // the 8-wave kernel skips an all-padding half tile (~25 % cost)
+  const float rows = ragged_skip ? (float)mh + 0.25f * (float)(tm * BM - mh) : (float)(tm * BM);
+  const float util = (float)M / rows;
+  const float quant = (float)blocks / (float)((blocks + slots - 1) / slots * slots);
+  return util * quant * eff;
+}
+static int big_tile_rows(const GemmArgs& a, int S) {
+  if (!big_eligible(a)) return 0;
+  if (g_gemm_variant == 3 || g_gemm_variant == 5) return 256;
+  if (g_gemm_variant == 4 || g_gemm_variant == 6) return 128;
+  if (g_gemm_variant != 2) return 0;
+  const float s256 = tile_score(a.M, a.N, S, 256, 256, 256, 1.0f, true);
+  const float s128 = tile_score(a.M, a.N, S, 128, 256, 256, 0.85f, true);
+  const float s64 = tile_score(a.M, a.N, S, 64, 128, 512, 0.55f, false);
+  if (s256 >= s128 && s256 >= s64) return 256;
+  if (s128 >= s64) return 128;
+  return 0;
+}
+
 template <int EPI>
 static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
+  const int big = big_tile_rows(a, 1);
+  if (big == 256) return launch_big<256, EPI>(a, st);
+  if (big == 128) return launch_big<128, EPI>(a, st);
   // 128-row tiles only for large M with a grid that fills the chip; otherwise 64-row tiles (less waste on a ragged M such as
   // 386 rows, more blocks, and the faster LDS-DMA kernel)
   const long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -629,7 +836,10 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   }
   if (a.partial != nullptr) {   // split-K slabs on the tiled path (prefill GEMMs with few output tiles)
     if (a.epilogue != EPI_NONE || a.nsplit < 1 || a.nsplit > 8 || a.nsplit > (a.K + 63) / 64) return LCC_ERR_ARG;
-    launch_tiled<64, EPI_PARTIAL>(a, st);
+    const int big = big_tile_rows(a, a.nsplit);
+    if (big == 256) launch_big<256, EPI_PARTIAL>(a, st);
+    else if (big == 128) launch_big<128, EPI_PARTIAL>(a, st);
+    else launch_tiled<64, EPI_PARTIAL>(a, st);
     return 0;
   }
   switch (a.epilogue) {

@@ -87,3 +87,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every gfx950 kernel of the library must fit its register budget: a scratch spill is a silent 3-5x slowdown
+    (tools/check_resources.py compiles with -Rpass-analysis=kernel-resource-usage; no GPU needed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "check_resources.py")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-500:]
+    assert p.stdout.count("vgpr=") > 50
