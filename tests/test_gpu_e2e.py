@@ -92,9 +92,10 @@ def _replay_native(native, cfg, frames, builder, max_new_tokens, repetition_pena
     return out
 
 
-def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_penalty, streaming_eos=None):
+def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_penalty, streaming_eos=None, min_exact_frac=0.8):
+    """hf32 may be None (large configs: only the bf16 oracle = the reference's own dtype is run)."""
     from oracle import hf_oracle as O
-    s16, s32 = O.OracleStream(hf16, cfg), O.OracleStream(hf32, cfg)
+    s16, s32 = O.OracleStream(hf16, cfg), (O.OracleStream(hf32, cfg) if hf32 is not None else None)
     n_steps = n_exact = n_checked = 0
     worst = dict(dl=0.0, ratio=0.0)
     for ti, nt in enumerate(native_turns):
@@ -104,18 +105,20 @@ def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_pena
         r16 = s16.turn(nt["turn_ids"], pv, grid, max_new_tokens=len(toks), repetition_penalty=repetition_penalty,
                        teacher_tokens=toks)
         r32 = s32.turn(nt["turn_ids"], pv, grid, max_new_tokens=len(toks), repetition_penalty=repetition_penalty,
-                       teacher_tokens=toks)
+                       teacher_tokens=toks) if s32 is not None else None
         assert r16["new_tokens"] == toks, "teacher forcing failed"
         for k in range(len(toks)):
-            ln, l16, l32 = nt["logits"][k], r16["logits"][k], r32["logits"][k]
+            ln, l16 = nt["logits"][k], r16["logits"][k]
+            l32 = r32["logits"][k] if r32 is not None else l16
             scale = l32.abs().max().item()
             d16 = (ln - l16).abs().max().item()
-            en, eo = (ln - l32).abs().max().item(), (l16 - l32).abs().max().item()
             worst["dl"] = max(worst["dl"], d16 / scale)
-            worst["ratio"] = max(worst["ratio"], en / (eo + 1e-3 * scale))
             assert d16 <= 6e-2 * scale, f"{name} turn {ti} step {k}: |native - bf16 oracle| = {d16:.4g} (scale {scale:.3g})"
-            assert en <= 1.5 * eo + 1e-3 * scale + 2.0 ** -7 * scale, (
-                f"{name} turn {ti} step {k}: native error vs fp32 {en:.4g} > 1.5 x bf16-oracle error {eo:.4g}")
+            if r32 is not None:
+                en, eo = (ln - l32).abs().max().item(), (l16 - l32).abs().max().item()
+                worst["ratio"] = max(worst["ratio"], en / (eo + 1e-3 * scale))
+                assert en <= 1.5 * eo + 1e-3 * scale + 2.0 ** -7 * scale, (
+                    f"{name} turn {ti} step {k}: native error vs fp32 {en:.4g} > 1.5 x bf16-oracle error {eo:.4g}")
             # margin-aware greedy exactness on the processed scores of the bf16 oracle (same history)
             sc_f = r16["scores"][k]          # processed scores before teacher forcing = the oracle's own preference
             ranked = torch.where(torch.isfinite(sc_f), sc_f, torch.full_like(sc_f, -1e30))
@@ -130,7 +133,7 @@ def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_pena
                                         f"with margin {margin:.4g} > 2 x logit error {d16:.4g}")
     record(name, dict(steps=n_steps, exact=n_exact, margin_checked=n_checked, worst_rel_dlogit=worst["dl"],
                       worst_err_ratio=worst["ratio"]))
-    assert n_exact >= 0.8 * n_steps, f"{name}: only {n_exact}/{n_steps} greedy tokens identical to the bf16 oracle"
+    assert n_exact >= min_exact_frac * n_steps, f"{name}: only {n_exact}/{n_steps} greedy tokens identical to the bf16 oracle"
 
 
 @pytest.mark.parametrize("use_pixel_values,fused_tails", [(False, 0), (True, 0), (False, 1)])
@@ -312,3 +315,25 @@ def test_one_shot_long_clip_decode_positions_follow_last_row(dev, tiny_models):
     for k in range(6):
         lo, ln = ro["logits"][k], r.logits[k].float().cpu()
         assert (ln - lo).abs().max().item() <= 6e-2 * lo.abs().max().item(), f"step {k}"
+
+
+@pytest.mark.skipif(__import__("os").environ.get("LCC_SKIP_SLOW") == "1", reason="LCC_SKIP_SLOW=1")
+def test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference(dev):
+    """BASELINE.json configs[0]: Qwen2-VL-2B (real shapes: 28 layers, hidden 1536, 12/2 heads, tied 151936-row lm_head, full
+    32-block ViT), one 8-frame 392x728 clip = chunks 6 + 2, greedy, repetition_penalty 1.05, 16 tokens per turn -- the native
+    path against the reference's CPU path (HF bf16 on the host cores, teacher-forced along the native tokens).  Only the bf16
+    oracle is run at this size (the fp32 twin would double the host time); with random weights and a 152k vocabulary many
+    top-1/top-2 margins are below one bf16 ulp, so free-running identity is required for half of the steps and the
+    margin-aware rule for all of them."""
+    from livecc_amd import protocol
+    from livecc_amd.config import qwen2vl_2b
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O
+    cfg = qwen2vl_2b()
+    hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=0, init_scale=1.0)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=4096, max_new_rows=2048,
+                                                          max_patches=8192, max_history=64)
+    frames = torch.from_numpy(protocol.synth_frames(8, 392, 728, seed=1234, layout="TCHW"))
+    turns = _replay_native(native, cfg, frames, protocol.TurnBuilder(cfg, seed=1234), 16, 1.05, max_turns=2)
+    assert [len(t["new_tokens"]) for t in turns] == [16, 16]
+    _compare_stream(cfg, hf16, None, turns, frames, "baseline_config0_qwen2vl_2b", 1.05, min_exact_frac=0.5)

@@ -89,9 +89,46 @@ def main_gemm():
             print(json.dumps(time_gemm(M, N, K, epi, variant)), flush=True)
 
 
+def main_mall():
+    """Does a decode GEMV run faster when its weights were just read by ANOTHER kernel (Infinity Cache / MALL warm)?
+    cold = rotating > 600 MB of weights; warm = each buffer is touched by a plain read kernel right before its GEMV (the GEMV
+    alone is timed).  Decides whether it pays to prefetch the next GEMV's weights under the latency-bound small kernels."""
+    dev = torch.device("cuda:0")
+    H, I, QKV = 3584, 18944, 4608
+    for name, mode, N, K in [("qkv", "partial", QKV, H), ("o", "partial", H, H), ("down", "partial", H, I), ("gate_up", "swiglu", 2 * I, H)]:
+        nbuf = max(2, int(700e6 // (N * K * 2)) + 1)
+        ws = [ops.pack_weight((torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(nbuf)]
+        x = torch.randn(1, K, device=dev).to(torch.bfloat16)
+        S = ops.gemv_num_splits(N, K)
+
+        def run(w):
+            if mode == "swiglu":
+                return ops.linear(x, w, None, ops.EPI_SWIGLU, packed_shape=(N, K))
+            return ops.linear_partial(x, w, S, packed_shape=(N, K))
+
+        for frac in (0.0, 1.0, 0.5, 0.25):
+            ts = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(30):
+                w = ws[i % nbuf]
+                if frac > 0:
+                    flat = w.view(-1).view(torch.int32)
+                    flat[: int(flat.numel() * frac)].sum()      # a plain (temporal) read of the leading part of the weights
+                e0.record()
+                run(w)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            ts.sort()
+            print(json.dumps(dict(kernel="gemv_mall", shape=name, N=N, K=K, MB=round(N * K * 2 / 1e6, 1), warm_fraction=frac,
+                                  us_median=round(ts[len(ts) // 2], 2), us_min=round(ts[0], 2))), flush=True)
+
+
 def main():
     if "--gemm" in sys.argv:
         return main_gemm()
+    if "--mall" in sys.argv:
+        return main_mall()
     H, I, V, QKV = 3584, 18944, 152064, 4608
     cases = [("swiglu", 2 * I, H), ("partial", QKV, H), ("partial", H, H), ("partial", H, I), ("plain", V, H)]
     Ms = [1] if "--quick" in sys.argv else [1, 8]
