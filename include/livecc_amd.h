@@ -110,6 +110,25 @@ int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, 
 /* decode: row b belongs to slot slots[b]; attends to kv_len[slot]+1 keys (its own K/V already appended) */
 int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slots, const int32_t* kv_len, void* const* kv_base,
                          lcc_kv_layout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, void* stream);
+/* fused decode step of one layer: [q/k/v bias + M-RoPE (Q2VL:180-222) + Cache.update (cache_utils.py:127-146)] + attention
+ * (Q2VL:537-556) + split merge in ONE launch.  qkv_partial = the fp32 split-K slabs [nsplit_qkv][B][(Hq+2Hkv)*128] of the
+ * q/k/v Linear (lcc_gemm_bf16 with `partial`); cos/sin = lcc_mrope_table rows of the B new tokens; the new K/V go to cache
+ * index kv_len[slots[b]] (kv_len itself is not advanced).  counters: Hkv*B int32, zero before the first call (left at zero).
+ * ws_o [B*Hkv*nsplit*16*128] / ws_ml [B*Hkv*nsplit*16*2] floats (used when nsplit > 1).  Same result as
+ * lcc_rope_kv_append_bf16 + lcc_attn_decode_bf16 up to the fp32 merge order. */
+int lcc_attn_decode_fused_bf16(const float* qkv_partial, int nsplit_qkv, const void* bias, const void* cos, const void* sin,
+                               const int32_t* slots, const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer,
+                               void* out, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, int32_t* counters,
+                               void* stream);
+/* bench only: `iters` back-to-back launches of one layer's decode attention chain from C++; variant 0 = rope_kv_append +
+ * attn_decode + combine, 1 = fused + combine launch, 2 = fused with in-launch merge; *out_us = average microseconds per chain */
+int lcc_debug_bench_attn_decode(int variant, int iters, const float* qkv_partial, int nsplit_qkv, const void* bias, const void* cos,
+                                const void* sin, const int32_t* slots, const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay,
+                                int layer, void* q_scratch, void* out, int B, int n_q_heads, int nsplit_sep, int nsplit_fused,
+                                float* ws_o, float* ws_ml, int32_t* counters, float* out_us, void* stream);
+int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode uses the fused kernel for batches of >= 16 (stream,
+                                          KV head) pairs; bit 2: for every batch; bit 1: key splits merged in the same launch by the
+                                          last-arriving block instead of a combine launch (default off) */
 
 int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
                           const void* vit_rows, void* out, int S, int dim, void* stream);             /* Q2VL:1159-1176 */

@@ -103,6 +103,10 @@ def load():
         "lcc_rope_kv_append_bf16": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, vp]),
         "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
         "lcc_attn_decode_bf16": (i32, [vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, vp, vp, vp]),
+        "lcc_attn_decode_fused_bf16": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp, vp, vp, vp]),
+        "lcc_debug_set_fused_attn": (i32, [i32]),
+        "lcc_debug_bench_attn_decode": (i32, [i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp,
+                                            C.POINTER(f32), vp]),
         "lcc_embed_gather_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "lcc_seen_set": (i32, [vp, i32, vp, vp, i32, vp]),
         "lcc_sample_greedy": (i32, [vp, i32, i32, i32, vp, i32, vp, f32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp,

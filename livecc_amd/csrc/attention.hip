@@ -121,10 +121,12 @@ LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (
 // key-tile loop [t0, t1) with a two-tile register ring: while tile t is multiplied the loads of tile t+1 are already in
 // flight and those of tile t+2 are issued right after tile t's operands are consumed.  All loads are unconditional
 // (tile index clamped to t1-1, so a re-load of the last tile may be issued and ignored): straight-line code, counted waits.
-template <int D, int NQ, class KRow, class VBlk>
+struct NoHook { LCC_DEVICE void operator()() const {} };
+// `after_first_loads` runs once the first two tiles' loads have been issued (e.g. to build the q fragments while they fly)
+template <int D, int NQ, class KRow, class VBlk, class Hook = NoHook>
 LCC_DEVICE void attn_loop(AttnAcc<D, NQ>& acc, KRow krow, VBlk vblk, int t0, int t1, const u32x4 (&qf)[NQ][(D + 31) / 32],
-                          int li, int g, const int (&key_limit)[NQ], float scale_log2e) {
-  if (t0 >= t1) return;
+                          int li, int g, const int (&key_limit)[NQ], float scale_log2e, Hook after_first_loads = Hook()) {
+  if (t0 >= t1) { after_first_loads(); return; }
   const int tl = t1 - 1;
   KFrag<D> ka, kb;
   u32x4 va[D / 16], vb[D / 16];
@@ -132,6 +134,7 @@ LCC_DEVICE void attn_loop(AttnAcc<D, NQ>& acc, KRow krow, VBlk vblk, int t0, int
   load_v<D>(va, vblk(t0), li, g);
   load_k<D>(kb, krow, min(t0 + 1, tl) * 32, li, g);
   load_v<D>(vb, vblk(min(t0 + 1, tl)), li, g);
+  after_first_loads();
   for (int t = t0; t < t1; t += 2) {
     attn_tile<D, NQ>(acc, ka, va, qf, t * 32, g, key_limit, scale_log2e);
     load_k<D>(ka, krow, min(t + 2, tl) * 32, li, g);
@@ -582,6 +585,251 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// LLM decode attention, FUSED form: [bias + M-RoPE + KV append]  ->  attention  ->  [split merge]  in ONE launch.
+// Replaces the rope_kv_append -> attn_decode -> attn_decode_combine chain of the batch decode step (three latency-bound
+// launches, ~18 us per layer at 7B) by one kernel:
+//   * prologue: every wave rebuilds the roped q fragments of its KV head's G query heads straight from the fp32 split-K slabs
+//     of the qkv GEMV (+ bias, HF rounding points of Q2VL:180-222), so q never goes through HBM as bf16;
+//   * the block that owns the last key tile appends the new token's roped K row and (blocked-transposed) V column to the
+//     cache first (plain stores -> vmcnt(0) -> __syncthreads: same-CU visibility; no other block reads that tile);
+//   * 4 waves per block share the block's key range; their (o, m, l) are merged through LDS;
+//   * nsplit > 1: the block partial is published with write-through (sc1) stores, one relaxed agent-scope ticket per block;
+//     the block that draws the last ticket of its (stream, KV head) acquires once and merges the nsplit partials
+//     (placement-independent protocol of cdna_hip_programming.md G16; the counter is left at zero for the next launch).
+// grid = (nsplit, Hkv, B), 256 threads.  G = Hq / Hkv <= 16.
+// ------------------------------------------------------------------------------------------------
+template <int NS>
+LCC_DEVICE void qkv8_from_slabs(const float* __restrict__ part, size_t slab_stride, size_t off, const bf16_t* __restrict__ bias,
+                                int col, float (&v)[8]) {
+  f32x4 pa[NS], pb[NS];
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) {
+    const float* pp = part + (size_t)sp * slab_stride + off + col;
+    pa[sp] = *reinterpret_cast<const f32x4*>(pp);
+    pb[sp] = *reinterpret_cast<const f32x4*>(pp + 4);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += pa[sp][e]; v[4 + e] += pb[sp][e]; }
+  const u32x4 bq = ld16(bias + col);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = rbf(v[2 * e] + lo2f(bq[e])); v[2 * e + 1] = rbf(v[2 * e + 1] + hi2f(bq[e])); }
+}
+
+// rotate one (x[c0..c0+8), x[c0+64..c0+72)) pair of a head with the token's cos/sin row (64 bf16 each)
+LCC_DEVICE void rope_pair8(const float (&x1)[8], const float (&x2)[8], const bf16_t* __restrict__ cs, const bf16_t* __restrict__ sn,
+                           int c0, u32x4& lo, u32x4& hi) {
+  const u32x4 cq = ld16(cs + c0), sq = ld16(sn + c0);
+  float o1[8], o2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float c = (e & 1) ? hi2f(cq[e >> 1]) : lo2f(cq[e >> 1]);
+    const float sv = (e & 1) ? hi2f(sq[e >> 1]) : lo2f(sq[e >> 1]);
+    o1[e] = rbf(x1[e] * c) + rbf(-x2[e] * sv);
+    o2[e] = rbf(x2[e] * c) + rbf(x1[e] * sv);
+  }
+  lo = (u32x4){pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])};
+  hi = (u32x4){pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])};
+}
+
+LCC_DEVICE void store_sc1_f32x4(float* p, f32x4 v) {   // write-through (sc1) 16 bytes as two 8-byte agent-scope atomic stores
+  unsigned long long* p8 = reinterpret_cast<unsigned long long*>(p);
+  const unsigned long long lo = (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32);
+  const unsigned long long hi = (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32);
+  __hip_atomic_store(p8, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p8 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NS, int TAIL>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(
+    const float* __restrict__ qkv_part, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ cs_tab,
+    const bf16_t* __restrict__ sn_tab, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
+    bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int B, int n_q_heads, int nsplit,
+    float* __restrict__ ws_o, float* __restrict__ ws_ml, int32_t* __restrict__ counters, bf16_t* __restrict__ out,
+    float scale_log2e) {
+  constexpr int D = 128, KS = 4, NQ = 1, NW = 4;
+  // LDS: per wave, per query column (16): 128 o values + m + l (row stride 528 B keeps the 16-byte o accesses aligned);
+  // the first 512 bytes double as the staging area of the new token's K row / V column and later as the merge flag
+  __shared__ __attribute__((aligned(16))) float sm[NW][16][D + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int hkv = lay.n_kv_heads, G = n_q_heads / hkv;
+  const int ld = (n_q_heads + 2 * hkv) * D;
+  const size_t slab_stride = (size_t)B * ld, row_off = (size_t)b * ld;
+  const int slot_id = slots[b];
+  const int nrow = kv_len[slot_id];        // cached keys; the new token's K/V take cache index nrow
+  const int ntile = (nrow + 31) / 32;      // tiles of CACHED keys, split over the blocks; the new key is a register tile
+  const int per = (ntile + nsplit - 1) / nsplit;
+  const int t0 = split * per, t1 = min(ntile, t0 + per);
+  const bf16_t* cs = cs_tab + (size_t)b * 64;
+  const bf16_t* sn = sn_tab + (size_t)b * 64;
+  bf16_t* base = kv_base[slot_id] + (size_t)layer * lay.layer_stride();
+  bf16_t* knew = reinterpret_cast<bf16_t*>(&sm[0][0][0]);   // [128] roped K row of the new token
+  bf16_t* vnew = knew + D;                                   // [128] V row of the new token
+
+  // ---- split 0 appends the new token's K/V (stores are fire-and-forget: nobody reads them in this launch) and stages them
+  //      in LDS for its own wave 0, which scores the new key from registers ----
+  if (split == 0) {
+    const int t = threadIdx.x;
+    if (t < 8) {            // K: 8 (c0, c0+64) pairs
+      const int c0 = t * 8;
+      float x1[8], x2[8];
+      qkv8_from_slabs<NS>(qkv_part, slab_stride, row_off, bias, (n_q_heads + hk) * D + c0, x1);
+      qkv8_from_slabs<NS>(qkv_part, slab_stride, row_off, bias, (n_q_heads + hk) * D + c0 + 64, x2);
+      u32x4 lo, hi;
+      rope_pair8(x1, x2, cs, sn, c0, lo, hi);
+      bf16_t* dst = base + (size_t)hk * lay.head_stride() + (size_t)nrow * D;
+      st16(dst + c0, lo);
+      st16(dst + c0 + 64, hi);
+      st16(knew + c0, lo);
+      st16(knew + c0 + 64, hi);
+    } else if (t >= 64 && t < 80) {   // V: 16 chunks of 8 d
+      const int c0 = (t - 64) * 8;
+      float x[8];
+      qkv8_from_slabs<NS>(qkv_part, slab_stride, row_off, bias, (n_q_heads + hkv + hk) * D + c0, x);
+      bf16_t* dst = base + lay.kv_stride() + (size_t)hk * lay.head_stride() + ((size_t)(nrow >> 5) * D + c0) * 32 + (nrow & 31);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const bf16_t h = f2bf(x[e]); dst[e * 32] = h; vnew[c0 + e] = h; }
+    }
+  }
+
+  // ---- attention over this wave's share of the block's cached key tiles; the roped q fragments of the KV head's query heads
+  //      (lane li -> head hk*G + min(li, G-1)) are rebuilt from the slabs while the first K/V tiles are in flight ----
+  u32x4 qf[NQ][KS];
+  auto build_q = [&]() {
+    const int hq = hk * G + min(li, G - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c0 = ks * 32 + g * 8;
+      float x1[8], x2[8];
+      qkv8_from_slabs<NS>(qkv_part, slab_stride, row_off, bias, hq * D + c0, x1);
+      qkv8_from_slabs<NS>(qkv_part, slab_stride, row_off, bias, hq * D + c0 + 64, x2);
+      rope_pair8(x1, x2, cs, sn, c0, qf[0][ks], qf[0][ks + 2]);
+    }
+  };
+  const int nt = max(t1 - t0, 0), pw = (nt + NW - 1) / NW;
+  const int w0 = t0 + wave * pw, w1 = min(t1, w0 + pw);
+  const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
+  const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
+  auto krow = [&](int key) { return kbase + (size_t)max(min(key, nrow - 1), 0) * D; };
+  auto vblk = [&](int t) { return vbase + (size_t)t * (D * 32); };
+  int key_limit[NQ] = {nrow};
+  AttnAcc<D, NQ> acc;
+  acc.init();
+  attn_loop<D, NQ>(acc, krow, vblk, w0, w1, qf, li, g, key_limit, scale_log2e, build_q);
+
+  if (split == 0) {
+    __syncthreads();          // knew / vnew staged (block-uniform branch)
+    if (wave == 0) {
+      // the new key as a one-key register tile: A-operand row 0 of the K fragment, column 0 of the V^T fragment
+      KFrag<D> kf;
+      u32x4 vf[D / 16];
+      const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf.v[0][ks] = (li == 0) ? *reinterpret_cast<const u32x4*>(knew + ks * 32 + g * 8) : z;
+        kf.v[1][ks] = z;
+      }
+#pragma unroll
+      for (int dt = 0; dt < D / 16; ++dt) vf[dt] = (g == 0) ? (u32x4){(unsigned)vnew[dt * 16 + li], 0u, 0u, 0u} : z;
+      const int one[NQ] = {1};
+      attn_tile<D, NQ>(acc, kf, vf, qf, 0, g, one, scale_log2e);
+    }
+    __syncthreads();          // staging area is reused by the merge below
+  }
+  float l = acc.l[0];
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4*>(&sm[wave][li][dt * 16 + g * 4]) = acc.o[dt][0];
+  if (g == 0) { sm[wave][li][D] = acc.m[0]; sm[wave][li][D + 1] = l; }
+  __syncthreads();
+
+  // ---- merge the 4 waves: item = (query head j, 4 consecutive d) ----
+  const bool single = nsplit == 1;
+  for (int item = threadIdx.x; item < G * 32; item += 256) {
+    const int j = item >> 5, d4 = (item & 31) * 4;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j][D]);
+    float den = 0.f;
+    f32x4 num = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float m = sm[w][j][D];
+      const float wt = (m == -INFINITY) ? 0.f : exp2f(m - M);
+      den += wt * sm[w][j][D + 1];
+      num += *reinterpret_cast<const f32x4*>(&sm[w][j][d4]) * wt;
+    }
+    const size_t slot = (((size_t)b * hkv + hk) * nsplit + split) * 16 + j;
+    if (single) {
+      const float inv = 1.f / den;
+      st8(out + ((size_t)b * n_q_heads + hk * G + j) * D + d4, (u32x2){pack2(num[0] * inv, num[1] * inv), pack2(num[2] * inv, num[3] * inv)});
+    } else if (TAIL == 1) {     // plain partials, merged by attn_decode_combine_kernel (next launch)
+      *reinterpret_cast<f32x4*>(ws_o + slot * D + d4) = num;
+      if ((item & 31) == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = den; }
+    } else {
+      store_sc1_f32x4(ws_o + slot * D + d4, num);
+      if ((item & 31) == 0) {
+        unsigned long long ml = (unsigned long long)__float_as_uint(M) | ((unsigned long long)__float_as_uint(den) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(ws_ml + slot * 2), ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (single || TAIL == 1) return;
+
+  // ---- publish / last-arriver merge ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                    // also: everyone is done reading sm
+  float* flag = &sm[0][0][0];
+  if (threadIdx.x == 0) {
+    int32_t* cnt = counters + b * hkv + hk;
+    const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == nsplit - 1;
+    if (last) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    flag[0] = last ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (flag[0] == 0.f) return;
+  for (int item = threadIdx.x; item < G * 32; item += 256) {
+    const int j = item >> 5, d4 = (item & 31) * 4;
+    const size_t slot0 = (((size_t)b * hkv + hk) * nsplit) * 16 + j;
+    float M = -INFINITY, den = 0.f;
+    f32x4 num = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nsplit; s0 += 4) {
+      float m4[4], l4[4];
+      f32x4 o4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {      // 4 partials in flight
+        const size_t slot = slot0 + (size_t)min(s0 + u, nsplit - 1) * 16;
+        m4[u] = ws_ml[slot * 2];
+        l4[u] = ws_ml[slot * 2 + 1];
+        o4[u] = *reinterpret_cast<const f32x4*>(ws_o + slot * D + d4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (s0 + u < nsplit) {
+          const float Mn = fmaxf(M, m4[u]);
+          const float a = (M == -INFINITY) ? 0.f : exp2f(M - Mn);
+          const float wt = (m4[u] == -INFINITY) ? 0.f : exp2f(m4[u] - Mn);
+          num = num * a + o4[u] * wt;
+          den = den * a + wt * l4[u];
+          M = Mn;
+        }
+      }
+    }
+    const float inv = 1.f / den;
+    st8(out + ((size_t)b * n_q_heads + hk * G + j) * D + d4, (u32x2){pack2(num[0] * inv, num[1] * inv), pack2(num[2] * inv, num[3] * inv)});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
@@ -659,6 +907,37 @@ int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const i
       q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128));
   attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(256), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
                                                                        lay.n_kv_heads, nsplit);
+  return 0;
+}
+
+// 0: the last-arriving block of each (stream, KV head) merges the key splits in the same launch (ticket + acquire);
+// 1: plain partials + attn_decode_combine_kernel as a second launch
+static int g_attn_fused_tail = 1;
+void set_attn_fused_tail(int v) { g_attn_fused_tail = v; }
+
+int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias, const bf16_t* cs, const bf16_t* sn,
+                           const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay, int layer, int B,
+                           int n_q_heads, int nsplit, float* ws_o, float* ws_ml, int32_t* counters, bf16_t* out, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads % lay.n_kv_heads || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
+  if (nsplit < 1 || nsplit > 64 || ns_qkv < 1 || ns_qkv > 8) return LCC_ERR_ARG;
+  const dim3 grid(nsplit, lay.n_kv_heads, B), blk(256);
+  const int tail = g_attn_fused_tail;
+#define LCC_ADF(NS)                                                                                                              \
+  case NS:                                                                                                                       \
+    if (tail == 0)                                                                                                               \
+      attn_decode_fused_kernel<NS, 0><<<grid, blk, 0, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,       \
+                                                            n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));      \
+    else                                                                                                                         \
+      attn_decode_fused_kernel<NS, 1><<<grid, blk, 0, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,       \
+                                                            n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));      \
+    break;
+  switch (ns_qkv) {
+    LCC_ADF(1) LCC_ADF(2) LCC_ADF(3) LCC_ADF(4) LCC_ADF(5) LCC_ADF(6) LCC_ADF(7) LCC_ADF(8)
+  }
+#undef LCC_ADF
+  if (tail != 0 && nsplit > 1)
+    attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(256), 0, st>>>(ws_o, ws_ml, out, n_q_heads, lay.n_kv_heads, nsplit);
   return 0;
 }
 

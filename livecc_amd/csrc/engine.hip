@@ -117,6 +117,7 @@ struct lcc_engine {
   // device state (inside `state`)
   int32_t *d_kv_len = nullptr, *d_pos = nullptr, *d_hist_col = nullptr, *d_cur_tok = nullptr, *d_done = nullptr, *d_history = nullptr;
   int32_t* d_counter = nullptr;   // arrival counter of the fused GEMV tails (zero between launches)
+  int32_t* d_attn_cnt = nullptr;  // [16 streams x Hkv] arrival counters of the fused decode attention (zero between launches)
   uint32_t* d_seen = nullptr;
   bf16_t** d_kv_base = nullptr;
   // optional live timing of the dominant kernel (decode gate/up GEMV): hipEvent pairs on the launch stream
@@ -210,7 +211,7 @@ extern "C" int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, 
 extern "C" size_t lcc_engine_workspace_bytes(const lcc_engine* e) { return std::max(e->llm_ws_bytes(), e->vit_ws_bytes()); }
 extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
   const size_t B = e->lim.max_slots;
-  return align_up(B * 4) * 5 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096;
+  return align_up(B * 4) * 5 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096 + 1024;
 }
 extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->lay.total() * 2; }
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
@@ -234,7 +235,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
   const size_t B = e->lim.max_slots;
   Carver cv; cv.base = e->state;
   e->d_kv_len = cv.take<int32_t>(B); e->d_pos = cv.take<int32_t>(B); e->d_hist_col = cv.take<int32_t>(B);
-  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_kv_base = cv.take<bf16_t*>(B);
+  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_attn_cnt = cv.take<int32_t>(256); e->d_kv_base = cv.take<bf16_t*>(B);
   e->d_history = cv.take<int32_t>(B * (size_t)e->lim.max_history);
   e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
   HIP_TRY(hipMemset(e->state, 0, state_bytes));
@@ -480,6 +481,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
 // LLM
 // ------------------------------------------------------------------------------------------------
 namespace {
+int g_fused_attn = 1;   // decode: 0 three kernels; 1 rope/KV-append + attention fused for multi-stream batches; 2 for every batch
 int g_fuse_tails = 0;   // 1: batch-1 decode runs rope/KV-append and residual+RMSNorm as tails of the producing GEMV (last-arriving
                         // block, ticket counter).  Measured on MI355X at 7B shapes: 184 tok/s fused vs 215 tok/s with separate
                         // kernels (the slab write-through + ticket serialises the GEMV's tail), so it stays an opt-in variant.
@@ -507,7 +509,7 @@ struct LayerCtx {
   int S; bool skinny;
   const int32_t *tok_stream, *tok_pos;          // prefill: explicit positions; decode: tok_pos == nullptr
   const int32_t *tile_stream, *tile_q0, *tile_nq, *tile_pos0; int n_tiles, tile_rows, kv_split;  // prefill attention tiles
-  const int32_t* slots; int B; int nsplit_attn;  // decode attention
+  const int32_t* slots; int B; int nsplit_attn; int nsplit_attn_fused;  // decode attention
 };
 int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream_t st) {
   const int H = e->c.hidden_size, I = e->c.intermediate_size, S = cx.S;
@@ -526,6 +528,12 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     // q/k/v projection (+bias) -> M-RoPE -> in-place KV append
     g = GemmArgs(); g.w_packed = 1; g.A = b.xn; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
     const bool fuse = cx.skinny && S <= 2 && g_fuse_tails;   // batch-1 decode: consumer ops run as GEMV tails
+    // batch decode: bias + M-RoPE + KV append + attention + split merge in one launch (attention.hip)
+    // Measured on MI355X (tools/bench_kernels.py --attn, 7B heads): one stream 14.2 vs 14.3 us per layer (no gain: the chain is a
+    // sequence of dependent memory round trips either way), 8 streams 24.6 vs 29.2 us (6k keys), 37.9 vs 41.9 us (12k keys) --
+    // so the fused kernel serves batches with >= 16 (stream, KV head) pairs; g_fused_attn = 2 forces it for every batch.
+    const bool fused_attn = !fuse && cx.skinny && cx.tok_pos == nullptr && cx.B * e->c.n_kv_heads <= 256 &&
+                            (g_fused_attn == 2 || (g_fused_attn == 1 && cx.B * e->c.n_kv_heads >= 16));
     if (fuse) {
       g.partial = b.partial; g.nsplit = sp_qkv;
       g.tail.kind = 2; g.tail.counter = e->d_counter; g.tail.bias = L.qkv_b; g.tail.cs = b.cos; g.tail.sn = b.sin;
@@ -535,8 +543,9 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     } else if (cx.skinny) {
       g.partial = b.partial; g.nsplit = sp_qkv;
       LCC_TRY(gemm_bf16(g, st));
-      LCC_TRY(rope_kv_append_bf16(nullptr, b.partial, sp_qkv, L.qkv_b, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
-                                  e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
+      if (!fused_attn)
+        LCC_TRY(rope_kv_append_bf16(nullptr, b.partial, sp_qkv, L.qkv_b, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
+                                    e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
     } else {
       g.bias = L.qkv_b; g.C = b.qkv; g.ldc = e->qkvd;
       LCC_TRY(gemm_bf16(g, st));
@@ -544,7 +553,10 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
                                   e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
     }
     // attention
-    if (cx.tok_pos == nullptr)
+    if (fused_attn)
+      LCC_TRY(attn_decode_fused_bf16(b.partial, sp_qkv, L.qkv_b, b.cos, b.sin, cx.slots, e->d_kv_len, e->d_kv_base, e->lay, l, cx.B,
+                                     e->c.n_q_heads, cx.nsplit_attn_fused, b.ws_o, b.ws_ml, e->d_attn_cnt, b.attn, st));
+    else if (cx.tok_pos == nullptr)
       LCC_TRY(attn_decode_bf16(b.q, b.attn, cx.slots, e->d_kv_len, e->d_kv_base, e->lay, l, cx.B, e->c.n_q_heads, cx.nsplit_attn,
                                b.ws_o, b.ws_ml, st));
     else
@@ -751,6 +763,8 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   LayerCtx cx{};
   cx.S = n_streams; cx.skinny = true; cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
   cx.nsplit_attn = nsplit;
+  // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
+  cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
   for (int step = 0; step < n_steps; ++step) {
     // the token sampled by the previous step (d_cur_tok[slot]) is embedded, appended at kv_len[slot], position pos[slot]
     LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
@@ -765,6 +779,13 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
 }
 
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
+// bit 0: engine uses the fused decode attention for batches of >= 16 (stream, KV head) pairs (default); bit 2: for every batch;
+// bit 1: its key splits are merged in-launch (ticket) instead of by a combine launch
+extern "C" int lcc_debug_set_fused_attn(int mode) {
+  g_fused_attn = (mode & 4) ? 2 : (mode & 1);
+  set_attn_fused_tail((mode & 2) ? 0 : 1);
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // operator-level C-ABI wrappers
@@ -861,6 +882,54 @@ extern "C" int lcc_attn_decode_bf16(const void* q, void* out, const int32_t* slo
   if (!q || !out || !slots || !kv_len || !kv_base || !ws_o || !ws_ml || nsplit < 1) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(attn_decode_bf16((const bf16_t*)q, (bf16_t*)out, slots, kv_len, (bf16_t* const*)kv_base, to_lay(lay), layer, B, n_q_heads, nsplit,
                           ws_o, ws_ml, (hipStream_t)stream), "lcc_attn_decode_bf16");
+}
+extern "C" int lcc_attn_decode_fused_bf16(const float* qkv_partial, int nsplit_qkv, const void* bias, const void* cos, const void* sin,
+                                          const int32_t* slots, const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer,
+                                          void* out, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, int32_t* counters,
+                                          void* stream) {
+  if (!qkv_partial || !bias || !cos || !sin || !slots || !kv_len || !kv_base || !out || !counters) return fail(LCC_ERR_ARG, "null pointer");
+  if (nsplit > 1 && (!ws_o || !ws_ml)) return fail(LCC_ERR_ARG, "nsplit > 1 needs the partial workspaces");
+  OP_RET(attn_decode_fused_bf16(qkv_partial, nsplit_qkv, (const bf16_t*)bias, (const bf16_t*)cos, (const bf16_t*)sin, slots, kv_len,
+                                (bf16_t* const*)kv_base, to_lay(lay), layer, B, n_q_heads, nsplit, ws_o, ws_ml, counters, (bf16_t*)out,
+                                (hipStream_t)stream), "lcc_attn_decode_fused_bf16");
+}
+// micro-benchmark of the decode attention chain of one layer, launched back to back `iters` times from C++ (a Python loop cannot
+// issue 5-us kernels fast enough).  variant 0: rope_kv_append + attn_decode + combine (three launches, nsplit_sep key splits);
+// 1: fused kernel + combine launch; 2: fused kernel with the in-launch merge.  Returns the average microseconds per chain.
+extern "C" int lcc_debug_bench_attn_decode(int variant, int iters, const float* qkv_partial, int nsplit_qkv, const void* bias,
+                                           const void* cos, const void* sin, const int32_t* slots, const int32_t* kv_len,
+                                           void* const* kv_base, lcc_kv_layout lay, int layer, void* q_scratch, void* out, int B,
+                                           int n_q_heads, int nsplit_sep, int nsplit_fused, float* ws_o, float* ws_ml,
+                                           int32_t* counters, float* out_us, void* stream) {
+  if (!qkv_partial || !bias || !cos || !sin || !slots || !kv_len || !kv_base || !q_scratch || !out || !ws_o || !ws_ml || !counters || !out_us)
+    return fail(LCC_ERR_ARG, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  const KvLayout L = to_lay(lay);
+  set_attn_fused_tail(variant == 2 ? 0 : 1);
+  int rc = 0;
+  for (int it = -3; it < iters && rc == 0; ++it) {
+    if (it == 0) HIP_TRY(hipEventRecord(e0, st));
+    if (variant == 0) {
+      rc = rope_kv_append_bf16(nullptr, qkv_partial, nsplit_qkv, (const bf16_t*)bias, (const bf16_t*)cos, (const bf16_t*)sin, slots, nullptr,
+                               kv_len, (bf16_t* const*)kv_base, L, layer, (bf16_t*)q_scratch, B, n_q_heads, st);
+      if (rc == 0) rc = attn_decode_bf16((const bf16_t*)q_scratch, (bf16_t*)out, slots, kv_len, (bf16_t* const*)kv_base, L, layer, B, n_q_heads,
+                                         nsplit_sep, ws_o, ws_ml, st);
+    } else {
+      rc = attn_decode_fused_bf16(qkv_partial, nsplit_qkv, (const bf16_t*)bias, (const bf16_t*)cos, (const bf16_t*)sin, slots, kv_len,
+                                  (bf16_t* const*)kv_base, L, layer, B, n_q_heads, nsplit_fused, ws_o, ws_ml, counters, (bf16_t*)out, st);
+    }
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *out_us = ms * 1000.f / (float)std::max(1, iters);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  set_attn_fused_tail(1);
+  if (rc != 0) return fail(rc, "lcc_debug_bench_attn_decode: invalid arguments (%d)", rc);
+  return check_launch("lcc_debug_bench_attn_decode");
 }
 extern "C" int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
                                      const void* vit_rows, void* out, int S, int dim, void* stream) {

@@ -88,6 +88,11 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
                       hipStream_t st);
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
                      KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
+void set_attn_fused_tail(int v);
+// fused decode attention: bias + M-RoPE + KV append + attention + split merge in one launch (reads the qkv GEMV's fp32 slabs)
+int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias, const bf16_t* cs, const bf16_t* sn,
+                           const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay, int layer, int B,
+                           int n_q_heads, int nsplit, float* ws_o, float* ws_ml, int32_t* counters, bf16_t* out, hipStream_t st);
 
 // ---- sampler (sampler.hip) ----
 int seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, int indirect,

@@ -271,6 +271,24 @@ def attn_decode(q: torch.Tensor, kv: KvArena, layer: int, slots: torch.Tensor, k
     return out
 
 
+def attn_decode_fused(qkv_partial: torch.Tensor, bias: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, kv: KvArena, layer: int,
+                      slots: torch.Tensor, kv_len: torch.Tensor, n_q_heads: int, nsplit: int, counters: Optional[torch.Tensor] = None):
+    """qkv_partial: fp32 [NS, B, (Hq+2Hkv)*128] split-K slabs of the q/k/v Linear.  Appends the new K/V at kv_len[slot] and returns
+    the attention output [B, Hq*128] (one launch)."""
+    NS, B, _ = qkv_partial.shape
+    out = torch.empty(B, n_q_heads * 128, dtype=torch.bfloat16, device=qkv_partial.device)
+    ws_o = torch.empty(B * kv.n_kv_heads * nsplit * 16 * 128, dtype=torch.float32, device=out.device)
+    ws_ml = torch.empty(B * kv.n_kv_heads * nsplit * 16 * 2, dtype=torch.float32, device=out.device)
+    if counters is None:
+        counters = torch.zeros(B * kv.n_kv_heads, dtype=torch.int32, device=out.device)
+    _lib.check(_lib.load().lcc_attn_decode_fused_bf16(
+        _chk(qkv_partial, torch.float32, "qkv_partial"), NS, _chk(bias, torch.bfloat16, "bias"), _chk(cos, torch.bfloat16, "cos"),
+        _chk(sin, torch.bfloat16, "sin"), _chk(slots, torch.int32, "slots"), _chk(kv_len, torch.int32, "kv_len"), kv.ptrs.data_ptr(),
+        kv.lay, layer, out.data_ptr(), B, n_q_heads, nsplit, ws_o.data_ptr(), ws_ml.data_ptr(), counters.data_ptr(), _st(out)),
+        "lcc_attn_decode_fused_bf16")
+    return out, counters
+
+
 def sample_greedy(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor, repetition_penalty: float = 1.0,
                   thr_token: int = -1, thr_value: Optional[float] = None, eos_token: int = -1, suppress_eos: bool = False,
                   want_scores: bool = False, two_stage: bool = False):

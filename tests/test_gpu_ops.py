@@ -394,6 +394,56 @@ def test_rope_append_prefill_decode_attention(dev, Hq, Hkv, attn_variant):
         _check_attn(got.view(1, Hq, D), ref, f"attn_decode[Hq{Hq},nsplit{nsplit}]")
 
 
+@pytest.mark.parametrize("Hq,Hkv", [(7, 1), (28, 4), (12, 2), (8, 1), (2, 1)])
+@pytest.mark.parametrize("NS", [1, 3, 4])
+def test_attn_decode_fused_matches_separate_kernels(dev, Hq, Hkv, NS):
+    """The fused decode kernel (bias + M-RoPE + KV append + attention + split merge in one launch) against the three separate
+    kernels on the same slabs and the same caches: identical K/V appends (bit-exact), attention output within the fp32
+    merge-order noise (<= 1 bf16 ulp), for ragged stream lengths (1 key ... several tiles, tile-boundary cases), every split
+    count, and with the arrival counters reused across consecutive launches."""
+    from livecc_amd import ops
+    D, Lmax = 128, 1024
+    lens = [0, 31, 32, 33, 500, 991]          # cached keys per stream before the new token
+    B = len(lens)
+    qkv_dim = (Hq + 2 * Hkv) * D
+    kv_a = ops.KvArena(B + 1, 2, Hkv, Lmax, dev)
+    g = torch.Generator().manual_seed(5)
+    kv_a.buf.copy_((torch.randn(kv_a.buf.shape, generator=g) * 0.7).to(torch.bfloat16))
+    kv_b = ops.KvArena(B + 1, 2, Hkv, Lmax, dev)
+    kv_b.buf.copy_(kv_a.buf)
+    layer = 1
+    slots = torch.tensor([3, 0, 5, 1, 6, 2], dtype=torch.int32, device=dev)          # batch row -> slot (a permutation)
+    kv_len = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    kv_len[slots.long()] = torch.tensor(lens, dtype=torch.int32, device=dev)
+    part = (torch.randn(NS, B, qkv_dim, generator=g) * 0.6).to(dev)
+    bias = _rand((qkv_dim,), dev, 0.2, 98)
+    pos3 = torch.tensor([[l + 2 for l in lens]] * 3, dtype=torch.int32)
+    _, _, inv = _hf_mrope_ref(pos3)
+    c, s_ = ops.mrope_table(pos3.to(dev), inv.to(dev), [16, 24, 24])
+    q_ref = ops.rope_kv_append(None, c, s_, slots, None, kv_a, layer, Hq, partial=part, bias=bias, kv_len=kv_len)
+    ref = ops.attn_decode(q_ref, kv_a, layer, slots, kv_len, Hq, 4).float()
+    counters = None
+    for nsplit in (1, 2, 3, 8, 16):
+        kv_b.buf.copy_(kv_a.buf)     # (already holds the appended rows of the reference; the fused kernel rewrites them)
+        got, counters = ops.attn_decode_fused(part, bias, c, s_, kv_b, layer, slots, kv_len, Hq, nsplit, counters)
+        assert int(counters.abs().sum()) == 0, "arrival counters must be left at zero"
+        assert torch.equal(kv_b.buf, kv_a.buf), f"fused KV append differs (nsplit {nsplit})"
+        _check_attn(got.view(B, Hq, D), ref.view(B, Hq, D), f"attn_decode_fused[Hq{Hq},NS{NS},nsplit{nsplit}]")
+    # the append itself: start from caches WITHOUT the new rows
+    kv_c = ops.KvArena(B + 1, 2, Hkv, Lmax, dev)
+    kv_c.buf.copy_(kv_a.buf)
+    for b in range(B):
+        sl, n = int(slots[b]), lens[b]
+        kv_c.k_view(sl, layer)[:, n] = 7.0
+        o = (layer * 2 + 1) * Hkv * Lmax * 128
+        raw = kv_c.buf[sl, o:o + Hkv * Lmax * 128].view(Hkv, Lmax // 32, 128, 32)
+        raw[:, n // 32, :, n % 32] = 7.0
+    assert not torch.equal(kv_c.buf, kv_a.buf)
+    got, _ = ops.attn_decode_fused(part, bias, c, s_, kv_c, layer, slots, kv_len, Hq, 4)
+    assert torch.equal(kv_c.buf, kv_a.buf), "fused kernel must append exactly the rows rope_kv_append appends"
+    _check_attn(got.view(B, Hq, D), ref.view(B, Hq, D), f"attn_decode_fused_append[Hq{Hq},NS{NS}]")
+
+
 def test_attention_masks_garbage_beyond_length(dev, attn_variant):
     """Keys past the valid length (stale cache contents) must not leak into the result."""
     from livecc_amd import ops

@@ -124,9 +124,49 @@ def main_mall():
                                   us_median=round(ts[len(ts) // 2], 2), us_min=round(ts[0], 2))), flush=True)
 
 
+def main_attn():
+    """One layer's decode attention chain at 7B head counts (28 q / 4 kv heads), B streams with L cached keys each."""
+    import ctypes
+    from livecc_amd import _lib
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    Hq, Hkv, D, NS = 28, 4, 128, 4
+    for B, L in [(1, 1200), (1, 6000), (1, 12000), (8, 6000), (8, 12000), (1, 32000)]:
+        Lmax = (L + 64 + 31) // 32 * 32
+        kv = ops.KvArena(B, 1, Hkv, Lmax, dev)
+        kv.buf.copy_((torch.randn(kv.buf.shape, device=dev) * 0.7).to(torch.bfloat16))
+        qd = (Hq + 2 * Hkv) * D
+        part = torch.randn(NS, B, qd, device=dev) * 0.5
+        bias = (torch.randn(qd, device=dev) * 0.1).to(torch.bfloat16)
+        cos = torch.rand(B, 64, device=dev).to(torch.bfloat16)
+        sin = torch.rand(B, 64, device=dev).to(torch.bfloat16)
+        slots = torch.arange(B, dtype=torch.int32, device=dev)
+        kv_len = torch.full((B,), L, dtype=torch.int32, device=dev)
+        ntile = (L + 1 + 31) // 32
+        ns_sep = max(1, min(64, (ntile + 3) // 4))
+        q = torch.empty(B, Hq * D, dtype=torch.bfloat16, device=dev)
+        out = torch.empty_like(q)
+        ws_o = torch.empty(B * Hkv * 64 * 16 * 128, dtype=torch.float32, device=dev)
+        ws_ml = torch.empty(B * Hkv * 64 * 16 * 2, dtype=torch.float32, device=dev)
+        cnt = torch.zeros(256, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for variant, ns_f in [(0, 0), (1, 8), (1, 16), (1, 32), (2, 8), (2, 16)]:
+            ns_fused = max(1, min(ns_f, (ntile + 3) // 4)) if ns_f else 1
+            us = ctypes.c_float(0)
+            rc = lib.lcc_debug_bench_attn_decode(variant, 300, part.data_ptr(), NS, bias.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                                 slots.data_ptr(), kv_len.data_ptr(), kv.ptrs.data_ptr(), kv.lay, 0, q.data_ptr(),
+                                                 out.data_ptr(), B, Hq, ns_sep, ns_fused, ws_o.data_ptr(), ws_ml.data_ptr(),
+                                                 cnt.data_ptr(), ctypes.byref(us), st)
+            _lib.check(rc, "lcc_debug_bench_attn_decode")
+            print(json.dumps(dict(kernel="attn_decode_chain", B=B, L=L, variant=["3 kernels", "fused+combine", "fused in-launch merge"][variant],
+                                  nsplit=ns_sep if variant == 0 else ns_fused, us_per_layer=round(us.value, 2))), flush=True)
+
+
 def main():
     if "--gemm" in sys.argv:
         return main_gemm()
+    if "--attn" in sys.argv:
+        return main_attn()
     if "--mall" in sys.argv:
         return main_mall()
     H, I, V, QKV = 3584, 18944, 152064, 4608
