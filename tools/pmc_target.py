@@ -12,6 +12,16 @@ from livecc_amd import ops  # noqa: E402
 
 H, I = 3584, 18944
 dev = torch.device("cuda:0")
+if "--gemm" in sys.argv:
+    # the LLM prefill gate/up GEMM (SwiGLU epilogue) with 8 streams (M = 3088) and one stream (M = 386): MFMA-utilisation passes
+    ws = [ops.pack_weight((torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(2)]
+    for M in (3088, 386):
+        x = torch.randn(M, H, device=dev).to(torch.bfloat16)
+        for i in range(6):
+            ops.linear(x, ws[i % 2], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
+    torch.cuda.synchronize()
+    print("ok")
+    sys.exit(0)
 ws = [(torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
 x = torch.randn(1, H, device=dev).to(torch.bfloat16)
 for i in range(12):

@@ -25,4 +25,15 @@ d = dict(kernel="gemv_skinny_kernel<2,2,packed> M=1 N=37888 K=3584", algorithmic
          fetch_size_kib_raw=fetch, write_size_kib_raw=write,
          gemv_gate_up_hbm_bytes_per_launch=(fetch * 1024 * 2 + (write or 0) * 1024) if fetch else None,
          note="FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024 (uncalibrated)", passes=res)
+# MFMA-utilisation passes of the 8-wave GEMM (best effort: raw per-dispatch counters and the kernel duration of the same dispatch)
+gemm = {}
+for f in glob.glob(os.path.join(out, "pmc_gemm_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "gemm_big_kernel" not in r.get("Kernel_Name", ""):
+            continue
+        key = "M3088" if "<256" in r["Kernel_Name"] else "M386"
+        gemm.setdefault(key, {}).setdefault(r.get("Counter_Name"), []).append(float(r["Counter_Value"]))
+d["gemm_big_kernel_counters_mean_per_dispatch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in gemm.items()}
+d["gemm_note"] = ("MfmaUtil = rocprofv3 derived metric reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum)/(reduce(GRBM_GUI_ACTIVE,max)*SIMD_NUM)*100 (gfx94x formula); "
+                  "the raw SQ_* / GRBM_* values are per-dispatch means of the CSV rows as rocprofv3 writes them")
 print(json.dumps(d, indent=1))
