@@ -65,6 +65,13 @@ int lcc_debug_set_attn_variant(int variant);
  * RMSNorm) run as the TAIL of that GEMV in its last-arriving block (agent-scope release/acquire), 0: separate kernels */
 int lcc_debug_set_fused_tails(int on);
 int lcc_gemv_num_splits(int N, int K);
+/* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
+ * [N/16][K/64][4 g][16 rows][16 k] (lane (g,row) owns 16 consecutive k), wscale = fp32 [N] per-output-row scale:
+ * y[m][n] = epilogue(wscale[n] * sum_k x[m][k] * q[n][k] (+ bias[n])).  M <= 16: weight-streaming GEMV (e4m3 -> bf16 exactly
+ * in registers, bf16 MFMA, fp32 accumulate).  M > 16: exact dequantisation into dq_scratch (N*K bf16, caller-provided), then
+ * the bf16 GEMM with the scale in its epilogue.  K % 64 == 0, N % 16 == 0.  partial / nsplit as in lcc_gemm_bf16. */
+int lcc_gemm_w8_bf16(const void* A, int lda, const void* W8, const float* wscale, const void* bias, const void* residual, int ldr,
+                     void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* dq_scratch, void* stream);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
 int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream);
 
@@ -152,6 +159,8 @@ typedef struct {
   float rms_eps;
   int mrope_sec_t, mrope_sec_h, mrope_sec_w;
   int vit_depth, vit_embed, vit_heads, vit_mlp, patch_dim, merge;
+  int llm_fp8;   /* 1: the LLM Linear weights (q/k/v, o, gate/up, down, lm_head) are fp8 e4m3 (PACKED8 order) + fp32 row scales
+                    set as "<name>.scale"; the workspace then includes a bf16 dequantisation scratch for prefill */
 } lcc_model_config;
 
 typedef struct {

@@ -29,7 +29,7 @@ class ModelConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("vocab_size", "hidden_size", "intermediate_size", "n_layers", "n_q_heads",
                                        "n_kv_heads", "head_dim")] + [("rms_eps", C.c_float)] + \
                [(n, C.c_int) for n in ("mrope_sec_t", "mrope_sec_h", "mrope_sec_w", "vit_depth", "vit_embed",
-                                       "vit_heads", "vit_mlp", "patch_dim", "merge")]
+                                       "vit_heads", "vit_mlp", "patch_dim", "merge", "llm_fp8")]
 
 
 class EngineLimits(C.Structure):
@@ -102,6 +102,7 @@ def load():
         "lcc_mrope_table": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "lcc_rope_kv_append_bf16": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, vp]),
         "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "lcc_gemm_w8_bf16": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
         "lcc_attn_decode_bf16": (i32, [vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, vp, vp, vp]),
         "lcc_attn_decode_fused_bf16": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp, vp, vp, vp]),
         "lcc_debug_set_fused_attn": (i32, [i32]),

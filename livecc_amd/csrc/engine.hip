@@ -73,7 +73,10 @@ namespace {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct VitLayerW { const bf16_t *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
-struct LlmLayerW { const bf16_t *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gate_up_w, *down_w; };
+struct LlmLayerW {
+  const bf16_t *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gate_up_w, *down_w;
+  const float *qkv_s, *o_s, *gate_up_s, *down_s;   // fp8 weights: per-output-row scales (nullptr for bf16 weights)
+};
 
 struct Carver {  // bump allocator over a caller-provided region
   char* base = nullptr;
@@ -104,6 +107,7 @@ struct lcc_engine {
   const bf16_t *patch_embed = nullptr, *mg_ln_w = nullptr, *mg_ln_b = nullptr, *mg_fc1_w = nullptr, *mg_fc1_b = nullptr,
                *mg_fc2_w = nullptr, *mg_fc2_b = nullptr, *embed = nullptr, *final_norm = nullptr, *lm_head = nullptr;
   const float* inv_freq = nullptr;
+  const float* lm_head_s = nullptr;
   bool weights_resolved = false;
 
   // buffers
@@ -144,6 +148,7 @@ size_t lcc_engine::llm_ws_bytes() const {
   t += align_up(B * H * 2) * 2;              // last_h, last_xn
   t += align_up(B * V * 2);                  // logits
   t += align_up(std::max<size_t>(B * c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * c.n_q_heads * 8) * 128 * 4) * 2;  // attention split partials (o, ml)
+  if (c.llm_fp8) t += align_up(std::max<size_t>((size_t)qkvd * H, 2 * I * H) * 2);   // bf16 dequantisation scratch of the largest LLM weight
   return t + 4096;
 }
 size_t lcc_engine::vit_ws_bytes() const {
@@ -284,8 +289,14 @@ static int resolve_weights(lcc_engine* e, std::string* missing) {
     LlmLayerW& L = e->llm[i];
     L.in_norm = get(p + "in_norm"); L.qkv_w = get(p + "qkv_w"); L.qkv_b = get(p + "qkv_b"); L.o_w = get(p + "o_w");
     L.post_norm = get(p + "post_norm"); L.gate_up_w = get(p + "gate_up_w"); L.down_w = get(p + "down_w");
+    L.qkv_s = L.o_s = L.gate_up_s = L.down_s = nullptr;
+    if (e->c.llm_fp8) {
+      L.qkv_s = (const float*)get(p + "qkv_w.scale"); L.o_s = (const float*)get(p + "o_w.scale");
+      L.gate_up_s = (const float*)get(p + "gate_up_w.scale"); L.down_s = (const float*)get(p + "down_w.scale");
+    }
   }
   e->final_norm = get("final_norm"); e->lm_head = get("lm_head");
+  e->lm_head_s = e->c.llm_fp8 ? (const float*)get("lm_head.scale") : nullptr;
   e->inv_freq = (const float*)get("inv_freq");
   if (missing && !missing->empty()) return LCC_ERR_STATE;
   e->weights_resolved = true;
@@ -486,7 +497,7 @@ int g_fuse_tails = 0;   // 1: batch-1 decode runs rope/KV-append and residual+RM
                         // block, ticket counter).  Measured on MI355X at 7B shapes: 184 tok/s fused vs 215 tok/s with separate
                         // kernels (the slab write-through + ticket serialises the GEMV's tail), so it stays an opt-in variant.
 struct LlmBuffers {
-  bf16_t *h, *xn, *qkv, *q, *attn, *act, *cos, *sin, *last_h, *last_xn, *logits;
+  bf16_t *h, *xn, *qkv, *q, *attn, *act, *cos, *sin, *last_h, *last_xn, *logits, *dq;
   float *partial, *ws_o, *ws_ml;
 };
 int carve_llm(lcc_engine* e, LlmBuffers* b) {
@@ -499,6 +510,7 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
   b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H); b->logits = cv.take<bf16_t>(B * V);
   const size_t nslot = std::max<size_t>(B * e->c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * e->c.n_q_heads * 8);
   b->ws_o = cv.take<float>(nslot * 128); b->ws_ml = cv.take<float>(nslot * 128);
+  b->dq = e->c.llm_fp8 ? cv.take<bf16_t>(std::max<size_t>((size_t)e->qkvd * H, 2 * I * H)) : nullptr;
   if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small");
   return 0;
 }
@@ -520,14 +532,19 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
   // prefill with few output tiles (N = hidden): split-K slabs, reduced by the fused residual-add + RMSNorm kernel
   const int tp_o = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, e->qd);
   const int tp_dn = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, I);
+  // fp8 weights: the same GemmArgs with the byte pointer, the row scales and the dequantisation scratch of the tiled path
+  auto set_w = [&](GemmArgs& g, const bf16_t* w, const float* scale) {
+    g.w_packed = 1; g.W = w;
+    if (scale != nullptr) { g.w_fp8 = 1; g.wscale = scale; g.dq_scratch = b.dq; }
+  };
   LCC_TRY(rmsnorm_bf16(b.h, e->llm[0].in_norm, b.xn, S, H, eps, st));
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     const bf16_t* next_norm = (l + 1 < e->c.n_layers) ? e->llm[l + 1].in_norm : e->final_norm;
     GemmArgs g;
     // q/k/v projection (+bias) -> M-RoPE -> in-place KV append
-    g = GemmArgs(); g.w_packed = 1; g.A = b.xn; g.lda = H; g.W = L.qkv_w; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
-    const bool fuse = cx.skinny && S <= 2 && g_fuse_tails;   // batch-1 decode: consumer ops run as GEMV tails
+    g = GemmArgs(); set_w(g, L.qkv_w, L.qkv_s); g.A = b.xn; g.lda = H; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
+    const bool fuse = cx.skinny && S <= 2 && g_fuse_tails && !e->c.llm_fp8;   // batch-1 decode: consumer ops run as GEMV tails
     // batch decode: bias + M-RoPE + KV append + attention + split merge in one launch (attention.hip)
     // Measured on MI355X (tools/bench_kernels.py --attn, 7B heads): one stream 14.2 vs 14.3 us per layer (no gain: the chain is a
     // sequence of dependent memory round trips either way), 8 streams 24.6 vs 29.2 us (6k keys), 37.9 vs 41.9 us (12k keys) --
@@ -563,7 +580,7 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       LCC_TRY(attn_prefill_bf16(b.q, b.attn, cx.tile_stream, cx.tile_q0, cx.tile_nq, cx.tile_pos0, e->d_kv_base, e->lay, l,
                                 cx.n_tiles, e->c.n_q_heads, cx.tile_rows, cx.kv_split, S, b.ws_o, b.ws_ml, st));
     // o_proj + residual + post-attention RMSNorm
-    g = GemmArgs(); g.w_packed = 1; g.A = b.attn; g.lda = e->qd; g.W = L.o_w; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
+    g = GemmArgs(); set_w(g, L.o_w, L.o_s); g.A = b.attn; g.lda = e->qd; g.ldw = e->qd; g.M = S; g.N = H; g.K = e->qd;
     if (fuse) {
       g.partial = b.partial; g.nsplit = sp_o;
       g.tail.kind = 1; g.tail.counter = e->d_counter; g.tail.h = b.h; g.tail.norm_w = L.post_norm; g.tail.y = b.xn; g.tail.eps = eps;
@@ -582,13 +599,13 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       LCC_TRY(rmsnorm_bf16(b.h, L.post_norm, b.xn, S, H, eps, st));
     }
     // SwiGLU MLP
-    g = GemmArgs(); g.w_packed = 1; g.A = b.xn; g.lda = H; g.W = L.gate_up_w; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
+    g = GemmArgs(); set_w(g, L.gate_up_w, L.gate_up_s); g.A = b.xn; g.lda = H; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
     g.epilogue = LCC_EPI_SWIGLU;
     const bool prof = e->prof_on && cx.skinny && cx.tok_pos == nullptr && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
     if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
     LCC_TRY(gemm_bf16(g, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
-    g = GemmArgs(); g.w_packed = 1; g.A = b.act; g.lda = I; g.W = L.down_w; g.ldw = I; g.M = S; g.N = H; g.K = I;
+    g = GemmArgs(); set_w(g, L.down_w, L.down_s); g.A = b.act; g.lda = I; g.ldw = I; g.M = S; g.N = H; g.K = I;
     if (fuse) {
       g.partial = b.partial; g.nsplit = sp_dn;
       g.tail.kind = 1; g.tail.counter = e->d_counter; g.tail.h = b.h; g.tail.norm_w = next_norm; g.tail.y = b.xn; g.tail.eps = eps;
@@ -616,6 +633,7 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   bf16_t* logits = b.logits;
   if (sp && sp->logits_out) logits = (bf16_t*)sp->logits_out + (size_t)step_index * B * V;
   GemmArgs g; g.w_packed = 1; g.A = xn_rows; g.lda = H; g.W = e->lm_head; g.ldw = H; g.C = logits; g.ldc = V; g.M = B; g.N = V; g.K = H;
+  if (e->lm_head_s != nullptr) { g.w_fp8 = 1; g.wscale = e->lm_head_s; }
   LCC_TRY(gemm_bf16(g, st));
   const float pen = sp ? sp->repetition_penalty : 1.0f;
   const int thr_tok = sp ? sp->thr_token : -1;
@@ -813,6 +831,17 @@ extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int
   OP_RET(gemm_bf16(g, (hipStream_t)stream), "lcc_gemm_bf16");
 }
 extern "C" int lcc_gemv_num_splits(int N, int K) { return gemv_num_splits(N, K); }
+extern "C" int lcc_gemm_w8_bf16(const void* A, int lda, const void* W8, const float* wscale, const void* bias, const void* residual,
+                                int ldr, void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit,
+                                void* dq_scratch, void* stream) {
+  if (!A || !W8 || !wscale || (!C && !partial)) return fail(LCC_ERR_ARG, "lcc_gemm_w8_bf16: null pointer");
+  if (M > 16 && !dq_scratch) return fail(LCC_ERR_ARG, "lcc_gemm_w8_bf16: M > 16 needs dq_scratch (N*K bf16)");
+  GemmArgs g; g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W8; g.ldw = K; g.w_packed = 1; g.bias = (const bf16_t*)bias;
+  g.residual = (const bf16_t*)residual; g.ldr = ldr; g.C = (bf16_t*)C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epilogue = epilogue;
+  g.partial = partial; g.nsplit = nsplit; g.w_fp8 = 1; g.wscale = wscale; g.dq_scratch = (bf16_t*)dq_scratch;
+  if (partial && C == nullptr) g.C = (bf16_t*)partial;
+  OP_RET(gemm_bf16(g, (hipStream_t)stream), "lcc_gemm_w8_bf16");
+}
 extern "C" int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream) {
   if (!A || !B || !D) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(mfma_probe((const bf16_t*)A, (const bf16_t*)B, D, (hipStream_t)stream), "lcc_debug_mfma_probe");

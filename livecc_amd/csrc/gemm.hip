@@ -29,7 +29,16 @@ __device__ unsigned int lcc_zero_page[256];  // 1 KB of zeros: operand source of
 template <int EPI, int MT, int NT>
 LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int ocbase, int li, int g,
                               const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
-                              bf16_t* __restrict__ C, int ldc, int M, int N, float* __restrict__ partial) {
+                              bf16_t* __restrict__ C, int ldc, int M, int N, float* __restrict__ partial,
+                              const float* __restrict__ wscale) {
+  // per-output-row dequantisation scale of fp8 weights (1.0 for bf16 weights: x * 1.0 is exact)
+  f32x4 sc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) sc[j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+  if (wscale != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) sc[j] = *reinterpret_cast<const f32x4*>(wscale + min(nbase + j * 16 + g * 4, N - 4));
+  }
   // Loads (bias: once per column group; residual: NT per row tile) are issued unconditionally from clamped addresses and
   // back to back, so that they overlap instead of one L2 round trip per (row tile, column group); only the stores are
   // predicated on the M / N edges.
@@ -51,7 +60,7 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, 
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = nbase + j * 16 + g * 4;
-        if (mok && n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j];
+        if (mok && n < N) *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * M + m) * N + n) = acc[i][j] * sc[j];
       }
     } else if (EPI == EPI_SWIGLU) {
 #pragma unroll
@@ -61,7 +70,7 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, 
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float gate = rbf(acc[i][j][r]), up = rbf(acc[i][j + 1][r]);
+          float gate = rbf(acc[i][j][r] * sc[j][r]), up = rbf(acc[i][j + 1][r] * sc[j + 1][r]);
           o[r] = silu_bf16(gate) * up;
         }
         if (mok && n < N) st8(C + (size_t)m * ldc + oc, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
@@ -76,10 +85,10 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, 
       for (int j = 0; j < NT; ++j) {
         const int n = nbase + j * 16 + g * 4;
         float v[4];
-        v[0] = rbf(acc[i][j][0] + lo2f(bv[j].x));
-        v[1] = rbf(acc[i][j][1] + hi2f(bv[j].x));
-        v[2] = rbf(acc[i][j][2] + lo2f(bv[j].y));
-        v[3] = rbf(acc[i][j][3] + hi2f(bv[j].y));
+        v[0] = rbf(acc[i][j][0] * sc[j][0] + lo2f(bv[j].x));
+        v[1] = rbf(acc[i][j][1] * sc[j][1] + hi2f(bv[j].x));
+        v[2] = rbf(acc[i][j][2] * sc[j][2] + lo2f(bv[j].y));
+        v[3] = rbf(acc[i][j][3] * sc[j][3] + hi2f(bv[j].y));
         if (EPI == EPI_QUICK_GELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = quick_gelu_bf16(v[r]);
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, int w_packed,
-    float* __restrict__ partial, int kt_per_split) {
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale) {
   constexpr int BN = 128, BK = 64;
   constexpr int WM = BM / 2;       // wave tile rows (of A)
   constexpr int MT = WM / 16;      // 16-row MFMA tiles per wave in M
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(
     __syncthreads();
   }
 
-  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n, int w_packed,
-    float* __restrict__ partial, int kt_per_split) {
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale) {
   constexpr int BN = 128, BK = 64, NSTAGE = 3;
   constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
   constexpr int A_SUB = (BM / 16) * 2;          // 1-KB sub-tiles of the A tile (row tiles x 2 k-blocks)
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
     }
   }
-  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
-    float* __restrict__ partial, int kt_per_split) {
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale) {
   constexpr int BN = 256, BK = 64, NSTAGE = (BM == 256) ? 2 : 3;
   constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
   constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       }
     }
   }
-  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial);
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
 // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel; 2 (default): measured best per tile shape --
@@ -493,12 +502,12 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
     }
     gemm_glds_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), lds, st>>>(
         a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
-        (nkt + S - 1) / S);
+        (nkt + S - 1) / S, a.wscale);
     return;
   }
   gemm_tiled_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), 0, st>>>(
       a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
-      (nkt + S - 1) / S);
+      (nkt + S - 1) / S, a.wscale);
 }
 
 template <int BM, int EPI, int SCHED>
@@ -512,7 +521,7 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
     attr_set = true;
   }
   gemm_big_kernel<BM, EPI, SCHED><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
-      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S);
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale);
 }
 template <int BM, int EPI>
 static void launch_big(const GemmArgs& a, hipStream_t st) {
@@ -765,6 +774,139 @@ static void launch_gemv_l(dim3 grid, const GemmArgs& a, void* out, int ldo, int 
   else launch_gemv<NTILE, MODE, false>(grid, a, out, ldo, cps, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 weights (OCP e4m3, per-output-row fp32 scale): decode GEMV + exact dequantisation for the tiled GEMMs
+// ------------------------------------------------------------------------------------------------
+// PACKED8 layout [N/16][K/64][4 g][16 rows][16 k] bytes: lane (g, row) of a 16-row x 64-k fragment owns the 16 consecutive
+// k = kb*64 + g*16 .. +15 of its row, i.e. ONE 16-byte load per lane per fragment and 1 KB contiguous per wave load -- the same
+// linear HBM stream as the bf16 packed layout at half the bytes.  The 16 bytes feed TWO 16x16x32 MFMAs (bytes 0-7, 8-15): the
+// k -> MFMA-slot assignment is arbitrary as long as the activation fragment uses the same one (x[kb*64 + g*16 + 0..7] and
+// + 8..15).  e4m3 -> bf16 is exact (v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32), products accumulate in fp32, and the row scale is
+// applied once to the fp32 sum -- so the result is the bf16 GEMV of the exactly dequantised integers times the scale.
+LCC_DEVICE bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
+  const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
+  const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
+  return as_bf16x8((u32x4){pack2(a0[0], a0[1]), pack2(a1[0], a1[1]), pack2(b0[0], b0[1]), pack2(b1[0], b1[1])});
+}
+
+template <int NTILE, int MODE>   // MODE 0 fp32 split-K slabs, 1 bf16 + bias, 2 SwiGLU (tile 0 = 16 gate rows, tile 1 = their up rows)
+__global__ __launch_bounds__(256) void gemv_w8_kernel(
+    const bf16_t* __restrict__ X, int ldx, const uint8_t* __restrict__ W, const float* __restrict__ wscale,
+    const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int chunks_per_split) {
+  constexpr int NW = 4, UNR = 2;
+  __shared__ f32x4 red[NW - 1][NTILE][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * (NTILE * 16);
+  const int split = blockIdx.y;
+  const int nchunk = K >> 6;
+  const int cb = split * chunks_per_split, ce = min(nchunk, cb + chunks_per_split);
+  const int nfrag = N >> 4;
+
+  const bf16_t* xp = X + (size_t)min(li, M - 1) * ldx + g * 16;
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_g) + g * 16;
+  const uint8_t* wp[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) wp[t] = W + (size_t)min((n0 >> 4) + t, nfrag - 1) * nchunk * 1024 + lane * 16;
+
+  f32x4 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_stage = [&](int c0, u32x4 (&wv)[UNR][NTILE], u32x4 (&xv)[UNR][2]) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int cc = c0 + u * NW;
+      const bool ok = cc < ce;                          // wave-uniform
+      const int ccl = min(cc, nchunk - 1);
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) wv[u][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)ccl * 1024));
+      const bf16_t* xs = ok ? xp + ccl * 64 : zp;       // an absent chunk is cancelled by a zero activation fragment
+      xv[u][0] = ld16(xs);
+      xv[u][1] = ld16(xs + 8);
+    }
+  };
+  auto mma_stage = [&](const u32x4 (&wv)[UNR][NTILE], const u32x4 (&xv)[UNR][2]) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) {
+        acc[t] = mfma16(fp8x8_to_bf16x8(wv[u][t][0], wv[u][t][1]), as_bf16x8(xv[u][0]), acc[t]);
+        acc[t] = mfma16(fp8x8_to_bf16x8(wv[u][t][2], wv[u][t][3]), as_bf16x8(xv[u][1]), acc[t]);
+      }
+  };
+  constexpr int STEP = UNR * NW;
+  {
+    u32x4 wa[UNR][NTILE], xa[UNR][2], wb[UNR][NTILE], xb[UNR][2];
+    int c = cb + wave;
+    load_stage(c, wa, xa);
+    for (; c < ce; c += 2 * STEP) {
+      load_stage(c + STEP, wb, xb);
+      mma_stage(wa, xa);
+      load_stage(c + 2 * STEP, wa, xa);
+      mma_stage(wb, xb);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) red[wave - 1][t][lane] = acc[t];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
+    acc[t] *= *reinterpret_cast<const f32x4*>(wscale + min(n0 + t * 16 + g * 4, N - 4));
+  }
+  if (li >= M) return;
+  if (MODE == 0) {
+    float* o = (float*)out + ((size_t)split * M + li) * ldo;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const int n = n0 + t * 16 + g * 4;
+      if (n < N) *reinterpret_cast<f32x4*>(o + n) = acc[t];
+    }
+  } else if (MODE == 1) {
+    bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const int n = n0 + t * 16 + g * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+      if (bias != nullptr) {
+        u32x2 b = ld8(bias + n);
+        v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+      }
+      st8(o + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+    }
+  } else {
+    static_assert(MODE != 2 || NTILE == 2, "swiglu needs the gate and up tile in one block");
+    bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
+    const int oc = n0 / 2 + g * 4;
+    if (n0 < N) {
+      float r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = silu_bf16(rbf(acc[0][q])) * rbf(acc[NTILE - 1][q]);
+      st8(o + oc, (u32x2){pack2(r[0], r[1]), pack2(r[2], r[3])});
+    }
+  }
+}
+
+// PACKED8 fp8 -> bf16 packed fragments (exact; no scale): thread = one 16-byte piece (row, 16 k) of a 16 x 64 fragment ->
+// the two 16-byte pieces (g' = 2*(g&1), 2*(g&1)+1) of the bf16 fragment of 32-k block 2*kb + (g >> 1)
+__global__ __launch_bounds__(256) void dequant_w8_kernel(const uint8_t* __restrict__ W8, bf16_t* __restrict__ out, size_t n_pieces) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pieces) return;
+  const size_t frag = i >> 6;                    // (row tile, 64-k block)
+  const int lane = (int)(i & 63), g = lane >> 4, row = lane & 15;
+  const u32x4 q = ld16(W8 + i * 16);
+  const bf16x8 lo = fp8x8_to_bf16x8(q[0], q[1]), hi = fp8x8_to_bf16x8(q[2], q[3]);
+  // bf16 packed: [row tile][32-k block][4 g'][16 rows][8 k]; 32-k block index = 2*kb64 + (g >> 1); frag already = rt*nchunk + kb64
+  bf16_t* dst = out + (frag * 2 + (size_t)(g >> 1)) * 512 + ((g & 1) * 2 * 16 + row) * 8;
+  st16(dst, as_u32x4(lo));
+  st16(dst + 16 * 8, as_u32x4(hi));
+}
+
 // layout probe (tests/test_gpu_ops.py::test_mfma_layout_probe): D[16x16] = A[16x32] * B[32x16] with the fragment maps of
 // common.h, one wave.  Verifies the operand/result lane maps every kernel in this library relies on.
 __global__ __launch_bounds__(64) void mfma_probe_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
@@ -807,8 +949,38 @@ int gemm_tiled_num_splits(int M, int N, int K) {
   return std::max(1, std::min(4, s));
 }
 
+static int gemm_w8(const GemmArgs& a, hipStream_t st) {
+  if ((a.K & 63) || (a.N & 15) || (a.lda & 7) || a.wscale == nullptr) return LCC_ERR_SHAPE;
+  if ((((uintptr_t)a.A | (uintptr_t)a.W) & 15) != 0 || ((uintptr_t)a.wscale & 15) != 0) return LCC_ERR_ALIGN;
+  if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
+  const uint8_t* W8 = reinterpret_cast<const uint8_t*>(a.W);
+  const bool skinny = a.M <= 16 && a.epilogue != EPI_QUICK_GELU && a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
+  if (skinny) {
+    const int nchunk = a.K / 64;
+    if (a.epilogue == EPI_SWIGLU) {
+      gemv_w8_kernel<2, 2><<<dim3((a.N + 31) / 32, 1), dim3(256), 0, st>>>(a.A, a.lda, W8, a.wscale, nullptr, a.C, a.ldc, a.M, a.N, a.K, nchunk);
+    } else if (a.partial != nullptr) {
+      const int S = a.nsplit > 0 ? a.nsplit : 1;
+      if (S > nchunk || a.tail.kind != 0) return LCC_ERR_ARG;
+      gemv_w8_kernel<1, 0><<<dim3((a.N + 15) / 16, S), dim3(256), 0, st>>>(a.A, a.lda, W8, a.wscale, nullptr, a.partial, a.N, a.M, a.N, a.K,
+                                                                             (nchunk + S - 1) / S);
+    } else {
+      gemv_w8_kernel<1, 1><<<dim3((a.N + 15) / 16, 1), dim3(256), 0, st>>>(a.A, a.lda, W8, a.wscale, a.bias, a.C, a.ldc, a.M, a.N, a.K, nchunk);
+    }
+    return 0;
+  }
+  // M > 16: exact dequantisation into the bf16 packed order, then the bf16 GEMM with the row scale in its epilogue
+  if (a.dq_scratch == nullptr) return LCC_ERR_ARG;
+  const size_t pieces = (size_t)a.N * a.K / 16;
+  dequant_w8_kernel<<<dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st>>>(W8, a.dq_scratch, pieces);
+  GemmArgs b = a;
+  b.w_fp8 = 0; b.W = a.dq_scratch; b.w_packed = 1; b.ldw = a.K;
+  return gemm_bf16(b, st);
+}
+
 int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0;
+  if (a.w_fp8) return gemm_w8(a, st);
   if ((a.K & 7) || (a.N & 15) || (a.lda & 7) || (!a.w_packed && (a.ldw & 7)) || (a.ldc & 3)) return LCC_ERR_SHAPE;
   if ((((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) != 0) return LCC_ERR_ALIGN;
   if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;

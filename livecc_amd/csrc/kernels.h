@@ -42,6 +42,10 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;
   int epilogue = 0;
   GemvTail tail;
+  // fp8 (OCP e4m3) weights: W points at bytes in the PACKED8 order [N/16][K/64][4 g][16 rows][16 k], wscale = fp32 [N]
+  // (y[n] = wscale[n] * sum_k x[k] q[n][k]); M > 16 needs dq_scratch = N*K bf16 (exact dequantisation into the bf16 packed
+  // order, then the bf16 GEMM with the scale in its epilogue)
+  int w_fp8 = 0; const float* wscale = nullptr; bf16_t* dq_scratch = nullptr;
 };
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
 int gemv_num_splits(int N, int K);

@@ -85,7 +85,8 @@ class Engine:
         mc = _lib.ModelConfig(cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers,
                               cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps,
                               cfg.mrope_section[0], cfg.mrope_section[1], cfg.mrope_section[2], cfg.vit_depth,
-                              cfg.vit_embed_dim, cfg.vit_num_heads, cfg.vit_mlp_dim, cfg.patch_dim, cfg.spatial_merge_size)
+                              cfg.vit_embed_dim, cfg.vit_num_heads, cfg.vit_mlp_dim, cfg.patch_dim, cfg.spatial_merge_size,
+                              1 if getattr(weights, "llm_fp8", False) else 0)
         lim = _lib.EngineLimits(max_slots, max_kv_len, max_new_rows, max_patches, max_history)
         self.h = self.lib.lcc_engine_create(C.byref(mc), C.byref(lim))
         if not self.h:

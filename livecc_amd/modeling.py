@@ -103,16 +103,17 @@ class LiveCCForConditionalGeneration:
         if "cuda" not in str(device):
             raise RuntimeError("livecc_amd has no CPU path; use device_map='cuda[:i]' (the oracle under oracle/ is the CPU path)")
         cfg = get_config(model_path)
-        arena = _arena_from_pretrained(model_path, cfg, device)
+        arena = _arena_from_pretrained(model_path, cfg, device, llm_fp8=bool(kw.pop("llm_fp8", False)))
         return cls(cfg, arena, device, **kw)
 
     @classmethod
-    def from_config(cls, cfg: LiveCCConfig, device="cuda", seed: int = 0, **kw):
-        return cls(cfg, WeightArena(cfg, device).fill_random(seed), device, **kw)
+    def from_config(cls, cfg: LiveCCConfig, device="cuda", seed: int = 0, llm_fp8: bool = False, **kw):
+        """llm_fp8: quantise the LLM Linear weights to OCP e4m3 with per-output-row scales (the 72B single-GPU weight path)."""
+        return cls(cfg, WeightArena(cfg, device, llm_fp8=llm_fp8).fill_random(seed), device, **kw)
 
     @classmethod
-    def from_hf_model(cls, hf_model, cfg: LiveCCConfig, device="cuda", **kw):
-        return cls(cfg, _arena_from_hf(hf_model, cfg, device), device, **kw)
+    def from_hf_model(cls, hf_model, cfg: LiveCCConfig, device="cuda", llm_fp8: bool = False, **kw):
+        return cls(cfg, _arena_from_hf(hf_model, cfg, device, llm_fp8=llm_fp8), device, **kw)
 
     def eval(self):
         return self

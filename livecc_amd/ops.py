@@ -68,6 +68,34 @@ def linear_partial(x: torch.Tensor, w: torch.Tensor, nsplit: int, packed_shape: 
     return out
 
 
+def quantize_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[N,K] -> (PACKED8 uint8 [N,K], fp32 row scales [N]) for linear_w8."""
+    from .weights import pack_weight_fp8, quantize_fp8_rows
+    q, scale = quantize_fp8_rows(w)
+    return pack_weight_fp8(q), scale.contiguous()
+
+
+def linear_w8(x: torch.Tensor, w8: torch.Tensor, scale: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE,
+              residual: Optional[torch.Tensor] = None, nsplit: int = 0) -> torch.Tensor:
+    """nn.Linear with fp8 e4m3 weights (PACKED8 bytes + fp32 row scales).  nsplit > 0: fp32 split-K slabs [nsplit, M, N]."""
+    M, K = x.shape
+    N = w8.shape[0]
+    assert w8.dtype == torch.uint8 and w8.shape[1] == K and scale.dtype == torch.float32 and scale.numel() == N
+    dq = torch.empty(N * K, dtype=torch.bfloat16, device=x.device) if M > 16 else None
+    lib = _lib.load()
+    if nsplit > 0:
+        out = torch.empty(nsplit, M, N, dtype=torch.float32, device=x.device)
+        _lib.check(lib.lcc_gemm_w8_bf16(_chk(x, torch.bfloat16, "x"), K, w8.data_ptr(), scale.data_ptr(), None, None, 0, None, N, M, N, K,
+                                        EPI_NONE, out.data_ptr(), nsplit, dq.data_ptr() if dq is not None else None, _st(x)),
+                   "lcc_gemm_w8_bf16(partial)")
+        return out
+    out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.lcc_gemm_w8_bf16(_chk(x, torch.bfloat16, "x"), K, w8.data_ptr(), scale.data_ptr(), _chk(bias, torch.bfloat16, "bias"),
+                                    _chk(residual, torch.bfloat16, "residual"), N, out.data_ptr(), out.shape[1], M, N, K, epilogue,
+                                    None, 0, dq.data_ptr() if dq is not None else None, _st(x)), "lcc_gemm_w8_bf16")
+    return out
+
+
 GEMV_DEFAULT_VARIANT = 1
 
 

@@ -57,6 +57,42 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     return w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
 
 
+FP8_MAX = 448.0   # largest finite OCP e4m3 value
+
+
+def quantize_fp8_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[N,K] float -> (q uint8 [N,K] = OCP e4m3 bit patterns, scale fp32 [N]) with w ~= q * scale[:, None]; per-output-row
+    absmax scaling (the row's largest weight maps to +-448), round-to-nearest-even (torch.float8_e4m3fn)."""
+    wf = w.float()
+    scale = (wf.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-12)
+    q = (wf / scale[:, None]).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def dequantize_fp8_rows(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q_u8.view(torch.float8_e4m3fn).float() * scale[:, None].float()
+
+
+def pack_weight_fp8(q_u8: torch.Tensor) -> torch.Tensor:
+    """PACKED8 order of include/livecc_amd.h: [N/16][K/64][4 g][16 rows][16 k] bytes."""
+    N, K = q_u8.shape
+    assert N % 16 == 0 and K % 64 == 0, (N, K)
+    return q_u8.view(N // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
+def unpack_weight_fp8(p_u8: torch.Tensor) -> torch.Tensor:
+    N, K = p_u8.shape
+    return p_u8.reshape(N // 16, K // 64, 4, 16, 16).permute(0, 3, 1, 2, 4).reshape(N, K)
+
+
+def fp8_weight_names(cfg: LiveCCConfig) -> List[str]:
+    """The LLM Linear weights stored as fp8 when the arena is built with llm_fp8=True (ViT, embeddings, norms stay bf16)."""
+    out = []
+    for i in range(cfg.num_hidden_layers):
+        out += [f"llm.{i}.qkv_w", f"llm.{i}.o_w", f"llm.{i}.gate_up_w", f"llm.{i}.down_w"]
+    return out + ["lm_head"]
+
+
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     """[I,H],[I,H] -> [2I,H] with rows [16 gate | 16 up | 16 gate | ...]."""
     I, H = gate.shape
@@ -65,33 +101,50 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
 
 
 class WeightArena:
-    def __init__(self, cfg: LiveCCConfig, device):
-        self.cfg, self.device = cfg, torch.device(device)
+    def __init__(self, cfg: LiveCCConfig, device, llm_fp8: bool = False):
+        """llm_fp8: the LLM Linear weights + lm_head are stored as OCP e4m3 bytes (PACKED8 order) followed by their fp32 row
+        scales (`<name>.scale`) -- 1 byte per parameter instead of 2 (72B: 73 GB instead of 147 GB; BASELINE configs[4])."""
+        self.cfg, self.device, self.llm_fp8 = cfg, torch.device(device), bool(llm_fp8)
         self.shapes = weight_shapes(cfg)
-        offs, total = {}, 0
+        self.fp8 = set(fp8_weight_names(cfg)) if llm_fp8 else set()
+        offs, total = {}, 0          # offsets / sizes in bf16 (2-byte) units
         for name, shp in self.shapes:
             n = 1
             for s in shp:
                 n *= s
-            offs[name] = (total, n, shp)
-            total += (n + 127) // 128 * 128          # keep every weight 256-byte aligned
+            units = n // 2 if name in self.fp8 else n
+            offs[name] = (total, units, shp)
+            total += (units + 127) // 128 * 128          # keep every weight 256-byte aligned
+            if name in self.fp8:
+                offs[name + ".scale"] = (total, 2 * shp[0], (shp[0],))
+                total += (2 * shp[0] + 127) // 128 * 128
         self.offsets, self.numel = offs, total
         self.flat = torch.empty(total, dtype=torch.bfloat16, device=self.device)
         hd = cfg.head_dim
         # HF Qwen2VLRotaryEmbedding.compute_default_rope_parameters (modeling_qwen2_vl.py:129-146), fp32 on CPU
         self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(self.device)
 
+    def is_fp8(self, name: str) -> bool:
+        return name in self.fp8
+
     def view(self, name: str) -> torch.Tensor:
-        """Storage view [N,K]-shaped; for packed weights the bytes are in fragment order (use `logical` to read values)."""
+        """Storage view [N,K]-shaped; for packed weights the bytes are in fragment order (use `logical` to read values).
+        fp8 weights: uint8 [N,K] in the PACKED8 order; `<name>.scale`: fp32 [N]."""
         o, n, shp = self.offsets[name]
+        if name.endswith(".scale"):
+            return self.flat[o:o + n].view(torch.float32)
+        if name in self.fp8:
+            return self.flat[o:o + n].view(torch.uint8).view(*shp)
         return self.flat[o:o + n].view(*shp)
 
     def is_packed(self, name: str) -> bool:
         return len(self.offsets[name][2]) == 2 and name not in ROW_MAJOR
 
     def logical(self, name: str) -> torch.Tensor:
-        """Row-major [N,K] values of a (possibly packed) weight (tests / export)."""
+        """Row-major [N,K] values of a (possibly packed / fp8) weight (tests / export); fp8 weights come back dequantised (fp32)."""
         v = self.view(name)
+        if name in self.fp8:
+            return dequantize_fp8_rows(unpack_weight_fp8(v), self.view(name + ".scale"))
         if not self.is_packed(name):
             return v
         N, K = v.shape
@@ -100,11 +153,21 @@ class WeightArena:
     def store(self, name: str, t: torch.Tensor) -> None:
         v = self.view(name)
         assert tuple(t.shape) == tuple(v.shape), f"{name}: {tuple(t.shape)} vs {tuple(v.shape)}"
+        if name in self.fp8:
+            q, scale = quantize_fp8_rows(t.to(self.device))
+            v.copy_(pack_weight_fp8(q))
+            self.view(name + ".scale").copy_(scale)
+            return
         t = t.to(self.device, dtype=torch.bfloat16)
         v.copy_(pack_weight(t) if self.is_packed(name) else t)
 
     def names(self) -> List[str]:
-        return [s[0] for s in self.shapes]
+        out = []
+        for s in self.shapes:
+            out.append(s[0])
+            if s[0] in self.fp8:
+                out.append(s[0] + ".scale")
+        return out
 
     def nbytes(self) -> int:
         return self.flat.numel() * 2
@@ -117,7 +180,17 @@ class WeightArena:
         g = torch.Generator(device=self.device).manual_seed(seed)
         for name, shp in self.shapes:
             v = self.view(name)
-            if len(shp) >= 2:   # i.i.d. values: the packed order of a random matrix is a random matrix
+            if name in self.fp8:   # quantised in row blocks so that the fp32 staging stays below ~1 GB at 72B shapes
+                N, K = shp
+                rows = max(16, (1 << 27) // K // 16 * 16)
+                sc = self.view(name + ".scale")
+                pv = v.view(N // 16, K // 64, 4, 16, 16)
+                for r0 in range(0, N, rows):
+                    r1 = min(N, r0 + rows)
+                    q, s_ = quantize_fp8_rows(torch.randn((r1 - r0, K), generator=g, device=self.device, dtype=torch.float32).mul_(std))
+                    pv[r0 // 16:r1 // 16].copy_(pack_weight_fp8(q).view((r1 - r0) // 16, K // 64, 4, 16, 16))
+                    sc[r0:r1].copy_(s_)
+            elif len(shp) >= 2:   # i.i.d. values: the packed order of a random matrix is a random matrix
                 v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(std))
             elif name.endswith("_b"):
                 v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(0.05))
@@ -166,12 +239,12 @@ def _normalise_hf_key(k: str) -> str:
     return k
 
 
-def from_hf_model(hf_model, cfg: LiveCCConfig, device) -> WeightArena:
+def from_hf_model(hf_model, cfg: LiveCCConfig, device, llm_fp8: bool = False) -> WeightArena:
     sd = {_normalise_hf_key(k): v for k, v in hf_model.state_dict().items()}
-    return WeightArena(cfg, device).load_state_dict(lambda n: sd[n])
+    return WeightArena(cfg, device, llm_fp8=llm_fp8).load_state_dict(lambda n: sd[n])
 
 
-def from_pretrained(path: str, cfg: LiveCCConfig, device) -> WeightArena:
+def from_pretrained(path: str, cfg: LiveCCConfig, device, llm_fp8: bool = False) -> WeightArena:
     """safetensors checkpoint directory -> arena (what `from_pretrained` does at ref demo/infer.py:43-47)."""
     import glob
     import os
@@ -191,4 +264,4 @@ def from_pretrained(path: str, cfg: LiveCCConfig, device) -> WeightArena:
         f, k = index[name]
         return handles[f].get_tensor(k)
 
-    return WeightArena(cfg, device).load_state_dict(get)
+    return WeightArena(cfg, device, llm_fp8=llm_fp8).load_state_dict(get)

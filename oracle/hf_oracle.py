@@ -119,6 +119,22 @@ def build_hf_model(cfg: LiveCCConfig, dtype=torch.bfloat16, seed: int = 0, init_
     return model
 
 
+def fake_quantize_llm_fp8(model) -> None:
+    """Replace every LLM Linear weight (q/k/v/o, gate/up/down, lm_head) by its OCP-e4m3 per-output-row quantisation
+    q * scale (the values the native fp8 weight path computes with), rounded to the model's dtype.  On an fp32 model the
+    products q*scale are exact up to one fp32 rounding = the truth for the fp8 path; on a bf16 model they carry bf16's
+    2^-9 weight rounding = what the reference's dtype would do with the dequantised checkpoint.  TEST INFRASTRUCTURE."""
+    from livecc_amd.weights import dequantize_fp8_rows, quantize_fp8_rows
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() != 2 or "visual" in n or "embed_tokens" in n:
+                continue
+            if not any(k in n for k in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj", "lm_head")):
+                continue
+            q, sc = quantize_fp8_rows(p.float())
+            p.copy_(dequantize_fp8_rows(q, sc).to(p.dtype))
+
+
 def round_weights_to_bf16(model) -> None:
     with torch.no_grad():
         for p in model.parameters():

@@ -342,3 +342,27 @@ def test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference(dev):
     turns = _replay_native(native, cfg, frames, protocol.TurnBuilder(cfg, seed=1234), 16, 1.05, max_turns=2)
     assert [len(t["new_tokens"]) for t in turns] == [16, 16]
     _compare_stream(cfg, hf16, None, turns, frames, "baseline_config0_qwen2vl_2b", 1.05, min_exact_frac=0.5)
+
+
+def test_streaming_generate_fp8_llm_weights_matches_oracle(dev):
+    """The fp8 weight path (BASELINE configs[4]'s mechanism, here at tiny shapes): LLM Linear weights as OCP e4m3 + fp32 row
+    scales.  Both oracles run on the SAME quantised values (`fake_quantize_llm_fp8`): fp32 = exact q*scale (truth), bf16 = what
+    the reference's dtype makes of the dequantised checkpoint; the native arena quantises the bf16 oracle's weights back to
+    the identical integers (tests/test_weights_dist.py shows the round trip is exact)."""
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O
+    cfg = tiny()
+    hf32 = O.build_hf_model(cfg, dtype=torch.float32, seed=3, init_scale=2.0)
+    O.fake_quantize_llm_fp8(hf32)
+    hf16 = O.build_hf_model(cfg, dtype=torch.float32, seed=3, init_scale=2.0)
+    O.fake_quantize_llm_fp8(hf16)
+    hf16.to(torch.bfloat16)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf32, cfg, dev, llm_fp8=True, max_streams=2, max_kv_len=2048,
+                                                          max_new_rows=1024, max_patches=4096, max_history=32)
+    assert native.weights.llm_fp8 and native.weights.view("llm.0.qkv_w").dtype == torch.uint8
+    frames = torch.from_numpy(protocol.synth_frames(10, 56, 84, seed=77, layout="TCHW"))
+    turns = _replay_native(native, cfg, frames, protocol.TurnBuilder(cfg, seed=77), max_new_tokens=8, repetition_penalty=1.05,
+                           max_turns=3)
+    _compare_stream(cfg, hf16, hf32, turns, frames, "stream_tiny_fp8_weights", 1.05)

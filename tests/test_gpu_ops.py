@@ -100,6 +100,62 @@ def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
     assert_bf16_close(got, ref, f"gemm_tiled_swiglu[{M}x{I}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
+@pytest.mark.parametrize("M", [1, 2, 8, 16])
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1024, 192)])
+def test_gemv_w8_fp8_weights(dev, M, N, K):
+    """fp8 (OCP e4m3 + fp32 row scale) weight-streaming GEMV: plain (+bias), split-K slabs, and the reference is the bf16 linear
+    of the exactly dequantised weights (e4m3 -> bf16 is exact; the scale multiplies the fp32 sum)."""
+    from livecc_amd import ops
+    from livecc_amd.weights import dequantize_fp8_rows, quantize_fp8_rows
+    x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.03, 2).float(), _rand((N,), dev, 0.1, 3)
+    q, sc = quantize_fp8_rows(w)
+    wd = dequantize_fp8_rows(q, sc)                       # fp32, exact products q * scale
+    w8, sc2 = ops.quantize_fp8(w)
+    assert torch.equal(sc2, sc)
+    got = ops.linear_w8(x, w8, sc, b)
+    ref, atol = _ref_linear(x, wd, b, with_atol=True)
+    assert_bf16_close(got, ref, f"gemv_w8[{M}x{N}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+    S = ops.gemv_num_splits(N, K)
+    if S <= K // 64:
+        part = ops.linear_w8(x, w8, sc, nsplit=S)
+        r32 = x.float() @ wd.t()
+        err = (part.sum(0) - r32).abs().max().item()
+        assert err <= 2e-5 * float(r32.abs().max()) * math.sqrt(K / 256) + 1e-5, f"fp8 split-K slabs: {err}"
+
+
+@pytest.mark.parametrize("M,I,K", [(1, 512, 256), (8, 2432, 896), (300, 2432, 896), (40, 512, 256)])
+def test_gemm_w8_swiglu(dev, M, I, K):
+    """gate/up with fp8 weights: skinny GEMV (M <= 16) and the dequantise-then-GEMM path (M > 16), SwiGLU epilogue with the
+    row scales applied before the activation."""
+    from livecc_amd import ops
+    from livecc_amd.weights import dequantize_fp8_rows, quantize_fp8_rows
+    x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2).float()
+    q, sc = quantize_fp8_rows(w)
+    w8, _ = ops.quantize_fp8(w)
+    got = ops.linear_w8(x, w8, sc, None, ops.EPI_SWIGLU)
+    ref, atol = _ref_linear(x, dequantize_fp8_rows(q, sc), None, 4, with_atol=True)
+    assert_bf16_close(got, ref, f"gemm_w8_swiglu[{M}x{I}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 512, 256), (386, 1536, 1024), (700, 768, 512), (33, 272, 192)])
+@pytest.mark.parametrize("epi", [0, 3])
+def test_gemm_w8_tiled(dev, M, N, K, epi):
+    """M > 16 with fp8 weights: exact dequantisation into the bf16 fragment order + bf16 GEMM with the scale in the epilogue
+    (covers the 4-wave and the 8-wave kernels)."""
+    from livecc_amd import ops
+    from livecc_amd.weights import dequantize_fp8_rows, quantize_fp8_rows
+    x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2).float(), _rand((N,), dev, 0.1, 3)
+    res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
+    q, sc = quantize_fp8_rows(w)
+    w8, _ = ops.quantize_fp8(w)
+    got = ops.linear_w8(x, w8, sc, b, epi, res)
+    ref, atol = _ref_linear(x, dequantize_fp8_rows(q, sc), b, epi, res, with_atol=True)
+    assert_bf16_close(got, ref, f"gemm_w8[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+    part = ops.linear_w8(x, w8, sc, nsplit=2)
+    r32 = x.float() @ dequantize_fp8_rows(q, sc).t()
+    assert (part.sum(0) - r32).abs().max().item() <= 2e-5 * float(r32.abs().max()) * math.sqrt(K / 256) + 1e-5
+
+
 def test_gemm_no_bias_identity_layout(dev):
     """A = I with an asymmetric W catches a transposed C write (symmetric inputs would not)."""
     from livecc_amd import ops

@@ -105,3 +105,36 @@ def test_weight_broadcast_and_stream_sharding_gloo_world2():
     assert res[0][1] and res[1][1], "every rank must hold rank 0's weights after the broadcast"
     assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]     # stream s -> rank s % world
     assert res[0][3] == res[1][3] == 7.0 and res[0][4] == res[1][4] == 2.0
+
+
+def test_fp8_quantise_pack_roundtrip_and_arena_layout():
+    """OCP e4m3 row quantisation (the 72B weight path): error bound, PACKED8 pack/unpack, fp8 arena store/logical, and that a
+    second quantisation of the dequantised weights (even after bf16 rounding) reproduces the same integers -- which is what
+    lets the oracle run on `fake_quantize_llm_fp8` weights while the native arena is built from the same model."""
+    from livecc_amd.config import tiny
+    from livecc_amd.weights import (WeightArena, dequantize_fp8_rows, pack_weight_fp8, quantize_fp8_rows, unpack_weight_fp8)
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 256, generator=g) * 0.05
+    w[3] = 0.0                                            # an all-zero row must not divide by zero
+    q, sc = quantize_fp8_rows(w)
+    assert q.dtype == torch.uint8 and sc.dtype == torch.float32 and sc.shape == (64,)
+    d = dequantize_fp8_rows(q, sc)
+    assert torch.isfinite(d).all() and float(d[3].abs().max()) == 0.0
+    amax = w.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    assert float(((d - w).abs() / amax).max()) <= 2.0 ** -4 + 1e-6     # e4m3: 3 mantissa bits -> half-ulp 2^-4 of the row max
+    assert torch.equal(unpack_weight_fp8(pack_weight_fp8(q)), q)
+    q2, sc2 = quantize_fp8_rows(d.to(torch.bfloat16))
+    assert torch.equal(q2, q) and torch.allclose(sc2, sc, rtol=2.0 ** -7)
+    # PACKED8: lane (g,row) of fragment (row tile rt, 64-k block kb) holds k = kb*64 + g*16 .. +15
+    p = pack_weight_fp8(q).view(4, 4, 4, 16, 16)
+    assert torch.equal(p[2, 1, 3, 5], q[2 * 16 + 5, 64 + 48:64 + 64])
+    cfg = tiny()
+    arena = WeightArena(cfg, "cpu", llm_fp8=True)
+    assert "llm.0.qkv_w.scale" in arena.names() and "lm_head.scale" in arena.names() and "vit.0.qkv_w.scale" not in arena.names()
+    wq = torch.randn(cfg.qkv_dim, cfg.hidden_size, generator=g) * 0.03
+    arena.store("llm.0.qkv_w", wq)
+    assert arena.view("llm.0.qkv_w").dtype == torch.uint8 and arena.view("llm.0.qkv_w.scale").dtype == torch.float32
+    qq, ss = quantize_fp8_rows(wq)
+    assert torch.equal(arena.logical("llm.0.qkv_w"), dequantize_fp8_rows(qq, ss))
+    bf16 = WeightArena(cfg, "cpu")
+    assert arena.nbytes() < bf16.nbytes() and all(o[0] % 128 == 0 for o in arena.offsets.values())
