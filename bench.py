@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--fused-tails", type=int, default=None, choices=[0, 1],
                     help="debug A/B: fuse add+rmsnorm / rope+append into the decode GEMV tails (default: library default)")
+    ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: LLM Linear weights as OCP e4m3 + fp32 row scales (BASELINE.json configs[4], 72B on one GPU)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
@@ -146,7 +148,8 @@ def main():
     spg = args.streams_per_gpu
 
     # weights: generated on rank 0, broadcast once over RCCL/xGMI -- no collective afterwards
-    arena = WeightArena(cfg, dev)
+    fp8 = args.weights == "fp8"
+    arena = WeightArena(cfg, dev, llm_fp8=fp8)
     if rank == 0:
         arena.fill_random(seed=0)
     bcast_s = D.broadcast_weights(arena.flat, src=0)
@@ -188,7 +191,7 @@ def main():
     # dominant kernel: gemv_skinny_kernel<2,2> (gate/up + SwiGLU), algorithmic bytes per launch:
     # weights 2I*H*2 + activations in M*H*2 + out M*I*2, M = streams per GPU
     I, H = cfg.intermediate_size, cfg.hidden_size
-    alg_bytes = 2 * I * H * 2 + spg * H * 2 + spg * I * 2
+    alg_bytes = 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + spg * H * 2 + spg * I * 2   # fp8: 1 B/weight + row scales
     roof = None
     if len(ms):
         avg_ms = float(np.mean(ms))
@@ -196,11 +199,12 @@ def main():
         traffic = None
         tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("gemv_gate_up_hbm_bytes_per_launch")
+            try:   # the committed PMC pass measured the LiveCC-7B bf16 single-stream launch; other shapes have no counter data
+                if cfg.name == "livecc-7b" and spg == 1 and not fp8:
+                    traffic = json.load(open(tp)).get("gemv_gate_up_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = dict(bound="hbm", kernel="gemv_skinny_kernel<2,2> (decode gate/up + SwiGLU)", achieved=round(ach, 1), peak=8000.0,
+        roof = dict(bound="hbm", kernel=("gemv_w8_kernel<2,2>" if fp8 else "gemv_skinny_kernel<2,2>") + " (decode gate/up + SwiGLU)", achieved=round(ach, 1), peak=8000.0,
                     unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic, avg_launch_us=round(avg_ms * 1e3, 2),
                     launches_timed=int(len(ms)), algorithmic_bytes_per_launch=alg_bytes)
     cpu = None
@@ -216,12 +220,14 @@ def main():
             cpu = dict(value=None, unit="tokens/s/stream", cores=os.cpu_count(), kind="reference", sample=f"failed: {e!r}")
     n_streams = world * spg
     out = {
-        "metric": "commentary tokens/s (all streams) + frames/s ingested, LiveCC-7B streaming", "value": round(total_tokens / dt, 3),
+        "metric": f"commentary tokens/s (all streams) + frames/s ingested, {'LiveCC-7B' if cfg.name == 'livecc-7b' else cfg.name} streaming", "value": round(total_tokens / dt, 3),
         "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic frames + synthetic prompt ids, random weights of the real architecture",
+        "dtype": "bf16 (fp8 e4m3 LLM weights, bf16 MFMA)" if fp8 else "bf16", "data": "synthetic frames + synthetic prompt ids, random weights of the real architecture",
         "config": {"workload": f"{cfg.name} single stream per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
-                               f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05 (BASELINE.json configs[1])",
+                               f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05"
+                               + (" (BASELINE.json configs[1])" if cfg.name == "livecc-7b" and args.frames == 60 and spg == 1 and not fp8 else "")
+                               + (" (BASELINE.json configs[4])" if cfg.name == "qwen2vl-72b" and fp8 else ""),
                    "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)"},
         "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
         "weight_broadcast_s": round(bcast_s, 3), "roofline": roof, "cpu_baseline": cpu,

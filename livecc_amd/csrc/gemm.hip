@@ -25,6 +25,13 @@ namespace lcc {
 
 __device__ unsigned int lcc_zero_page[256];  // 1 KB of zeros: operand source of absent K chunks (address select, no branch)
 
+// 8 OCP e4m3 bytes (two dwords) -> 8 bf16 (exact): v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32
+LCC_DEVICE bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
+  const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
+  const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
+  return as_bf16x8((u32x4){pack2(a0[0], a0[1]), pack2(a1[0], a1[1]), pack2(b0[0], b0[1]), pack2(b1[0], b1[1])});
+}
+
 // epilogue shared by the tiled kernels.  acc[i][j][r] = C[mbase + i*16 + li][nbase + j*16 + g*4 + r] (swapped operands).
 template <int EPI, int MT, int NT>
 LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int ocbase, int li, int g,
@@ -351,16 +358,20 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
 //   * pipeline: BM = 256: two 64-KB stages (128 KB), vmcnt(0) + s_barrier per k-tile, the DMA of tile kt+1 runs under the
 //     MFMAs of tile kt.  BM = 128: three 48-KB stages, counted vmcnt so that one tile stays in flight across the barrier.
 // Requires packed W, K % 64 == 0 (every shape of the 7B/2B/72B models except the 1176-wide patch embedding).
-template <int BM, int EPI, int SCHED>
+// W8 = true: W is fp8 e4m3 in the PACKED8 order (one 1-KB DMA = a 16-row x 64-k fragment = both k-steps of a k-tile); the
+// fragment read is one ds_read_b128 per 16 rows whose halves are converted to bf16 in registers, and the activation chunk
+// order follows PACKED8's k assignment (MFMA h of lane group g takes k = g*16 + h*8 ..).  Half the W bytes in L2 and LDS;
+// the stage shrinks to 48 KB (BM 256) so that three stages fit and one tile stays in flight across the barrier.
+template <int BM, int EPI, int SCHED, bool W8>
 __global__ __launch_bounds__(512) void gemm_big_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
     float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale) {
-  constexpr int BN = 256, BK = 64, NSTAGE = (BM == 256) ? 2 : 3;
+  constexpr int BN = 256, BK = 64, NSTAGE = (BM == 256 && !W8) ? 2 : 3;
   constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
   constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
-  constexpr int B_SUB = (BN / 16) * 2;            // 1-KB fragment sub-tiles of the W tile
+  constexpr int B_SUB = (BN / 16) * (W8 ? 1 : 2); // 1-KB fragment sub-tiles of the W tile
   constexpr int STAGE = A_UNITS + B_SUB * 64;     // 16-byte units per stage
   constexpr int A_PER_WAVE = BM / 64;             // 8-row x 128-B pieces per wave (BM/8 pieces over 8 waves)
   constexpr int B_PER_WAVE = B_SUB / 8;
@@ -390,9 +401,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
   }
 #pragma unroll
   for (int q = 0; q < B_PER_WAVE; ++q) {
-    const int st = wave * B_PER_WAVE + q;          // sub-tile: n-fragment row st >> 1, 32-k block st & 1
-    const int fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
-    bsrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+    const int st = wave * B_PER_WAVE + q;
+    if (W8) {                                      // sub-tile = n-fragment row st, all 64 k of the tile (1 KB of fp8)
+      const int fr = min((n0 >> 4) + st, nfrag - 1);
+      bsrc[q] = W + ((size_t)fr * (K >> 6)) * 512 + lane * 8;          // bf16_t units: 1024 B = 512 units per fragment
+    } else {                                       // sub-tile: n-fragment row st >> 1, 32-k block st & 1
+      const int fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
+      bsrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+    }
   }
 
   auto issue = [&](int kt, int stage) {
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
                                        (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
 #pragma unroll
     for (int q = 0; q < B_PER_WAVE; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * 1024),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * (W8 ? 512 : 1024)),
                                        (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (wave * B_PER_WAVE + q) * 64), 16, 0, 0);
   };
 
@@ -423,13 +439,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
   // fragment read offsets (16-byte units within a stage)
   int aoff[2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (wm * WM + li) * 8 + ((kk * 4 + g) ^ (li & 7));
-  const int boff = A_UNITS + (wn * NT * 2) * 64 + lane;
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (wm * WM + li) * 8 + ((W8 ? g * 2 + kk : kk * 4 + g) ^ (li & 7));
+  const int boff = A_UNITS + (wn * NT * (W8 ? 1 : 2)) * 64 + lane;
 
   for (int kt = kt0; kt < nkt; ++kt) {
     // this wave's pieces of tile kt have landed; NSTAGE-2 later tiles may stay in flight across the barrier
     if (NSTAGE == 3 && kt + 1 < nkt) {
-      if (G == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (G == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -446,7 +463,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 fa[MT], fb[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+        for (int j = 0; j < NT; ++j) {
+          if (W8) { const u32x4 raw = s[boff + j * 64]; fb[j] = fp8x8_to_bf16x8(raw[2 * kk], raw[2 * kk + 1]); }
+          else fb[j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = as_bf16x8(s[aoff[kk] + i * 128]);
 #pragma unroll
@@ -459,10 +479,19 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       // fragments stream through a 3-register ring two steps (8 MFMAs = 128 cycles) ahead of their use; the issue order is
       // pinned with sched_group_barrier (DS read = 0x100, MFMA = 0x008) so that hipcc does not fall back to read-wait-use.
       bf16x8 fb[2][NT], fa[3];
+      if (W8) {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+        for (int j = 0; j < NT; ++j) {
+          const u32x4 raw = s[boff + j * 64];
+          fb[0][j] = fp8x8_to_bf16x8(raw[0], raw[1]);
+          fb[1][j] = fp8x8_to_bf16x8(raw[2], raw[3]);
+        }
+      } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[kk][j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) fb[kk][j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+      }
       fa[0] = as_bf16x8(s[aoff[0]]);
       fa[1] = as_bf16x8(s[aoff[0] + 128]);
 #pragma unroll
@@ -471,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[t % MT][j] = mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (W8 ? NT : 2 * NT) + 2, 0);
 #pragma unroll
       for (int t = 0; t < 2 * MT; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -510,23 +539,25 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
       (nkt + S - 1) / S, a.wscale);
 }
 
-template <int BM, int EPI, int SCHED>
+template <int BM, int EPI, int SCHED, bool W8>
 static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  constexpr size_t lds = (size_t)(BM == 256 ? 2 : 3) * (BM * 8 + 2048) * 16;   // 128 KB (BM 256) / 144 KB (BM 128)
+  // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages
+  constexpr size_t lds = (size_t)((BM == 256 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  gemm_big_kernel<BM, EPI, SCHED><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+  gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale);
 }
 template <int BM, int EPI>
 static void launch_big(const GemmArgs& a, hipStream_t st) {
-  if (g_gemm_sched) launch_big_s<BM, EPI, 1>(a, st);
-  else launch_big_s<BM, EPI, 0>(a, st);
+  if (a.w_fp8) launch_big_s<BM, EPI, 1, true>(a, st);
+  else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
+  else launch_big_s<BM, EPI, 0, false>(a, st);
 }
 static bool big_eligible(const GemmArgs& a) { return a.w_packed && (a.K % 64) == 0 && a.M > 16; }
 
@@ -783,11 +814,6 @@ static void launch_gemv_l(dim3 grid, const GemmArgs& a, void* out, int ldo, int 
 // k -> MFMA-slot assignment is arbitrary as long as the activation fragment uses the same one (x[kb*64 + g*16 + 0..7] and
 // + 8..15).  e4m3 -> bf16 is exact (v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32), products accumulate in fp32, and the row scale is
 // applied once to the fp32 sum -- so the result is the bf16 GEMV of the exactly dequantised integers times the scale.
-LCC_DEVICE bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
-  const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
-  const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
-  return as_bf16x8((u32x4){pack2(a0[0], a0[1]), pack2(a1[0], a1[1]), pack2(b0[0], b0[1]), pack2(b1[0], b1[1])});
-}
 
 template <int NTILE, int MODE>   // MODE 0 fp32 split-K slabs, 1 bf16 + bias, 2 SwiGLU (tile 0 = 16 gate rows, tile 1 = their up rows)
 __global__ __launch_bounds__(256) void gemv_w8_kernel(
@@ -969,7 +995,29 @@ static int gemm_w8(const GemmArgs& a, hipStream_t st) {
     }
     return 0;
   }
-  // M > 16: exact dequantisation into the bf16 packed order, then the bf16 GEMM with the row scale in its epilogue
+  // M > 16: the 8-wave kernel consumes the fp8 fragments directly (e4m3 -> bf16 after the LDS read) ...
+  {
+    GemmArgs c = a; c.w_packed = 1;
+    const bool part = a.partial != nullptr;
+    if (part && (a.epilogue != EPI_NONE || a.nsplit < 1 || a.nsplit > 8 || a.nsplit > a.K / 64)) return LCC_ERR_ARG;
+    if (a.epilogue == EPI_RESIDUAL && a.residual == nullptr) return LCC_ERR_ARG;
+    const int big = (g_gemm_variant == 7) ? 0 : big_tile_rows(c, part ? a.nsplit : 1);
+    if (big != 0) {
+#define LCC_BIG8(EPI) (big == 256 ? launch_big<256, EPI>(c, st) : launch_big<128, EPI>(c, st))
+      if (part) { LCC_BIG8(EPI_PARTIAL); return 0; }
+      switch (a.epilogue) {
+        case EPI_NONE: LCC_BIG8(EPI_NONE); return 0;
+        case EPI_QUICK_GELU: LCC_BIG8(EPI_QUICK_GELU); return 0;
+        case EPI_GELU_ERF: LCC_BIG8(EPI_GELU_ERF); return 0;
+        case EPI_RESIDUAL: LCC_BIG8(EPI_RESIDUAL); return 0;
+        case EPI_SWIGLU: LCC_BIG8(EPI_SWIGLU); return 0;
+        default: return LCC_ERR_ARG;
+      }
+#undef LCC_BIG8
+    }
+  }
+  // ... shapes with too few 256-column tiles: exact dequantisation into the bf16 packed order, then the 4-wave bf16 GEMM with
+  // the row scale in its epilogue
   if (a.dq_scratch == nullptr) return LCC_ERR_ARG;
   const size_t pieces = (size_t)a.N * a.K / 16;
   dequant_w8_kernel<<<dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st>>>(W8, a.dq_scratch, pieces);

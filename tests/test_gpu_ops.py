@@ -123,8 +123,9 @@ def test_gemv_w8_fp8_weights(dev, M, N, K):
         assert err <= 2e-5 * float(r32.abs().max()) * math.sqrt(K / 256) + 1e-5, f"fp8 split-K slabs: {err}"
 
 
-@pytest.mark.parametrize("M,I,K", [(1, 512, 256), (8, 2432, 896), (300, 2432, 896), (40, 512, 256)])
-def test_gemm_w8_swiglu(dev, M, I, K):
+@pytest.mark.parametrize("M,I,K", [(1, 512, 256), (8, 2432, 896), (300, 2432, 896), (40, 512, 256), (530, 400, 128)])
+@pytest.mark.parametrize("variant", [2, 3, 4])
+def test_gemm_w8_swiglu(dev, M, I, K, variant):
     """gate/up with fp8 weights: skinny GEMV (M <= 16) and the dequantise-then-GEMM path (M > 16), SwiGLU epilogue with the
     row scales applied before the activation."""
     from livecc_amd import ops
@@ -132,26 +133,36 @@ def test_gemm_w8_swiglu(dev, M, I, K):
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2).float()
     q, sc = quantize_fp8_rows(w)
     w8, _ = ops.quantize_fp8(w)
-    got = ops.linear_w8(x, w8, sc, None, ops.EPI_SWIGLU)
+    ops.set_gemm_variant(variant)
+    try:
+        got = ops.linear_w8(x, w8, sc, None, ops.EPI_SWIGLU)
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     ref, atol = _ref_linear(x, dequantize_fp8_rows(q, sc), None, 4, with_atol=True)
     assert_bf16_close(got, ref, f"gemm_w8_swiglu[{M}x{I}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
-@pytest.mark.parametrize("M,N,K", [(100, 512, 256), (386, 1536, 1024), (700, 768, 512), (33, 272, 192)])
-@pytest.mark.parametrize("epi", [0, 3])
-def test_gemm_w8_tiled(dev, M, N, K, epi):
-    """M > 16 with fp8 weights: exact dequantisation into the bf16 fragment order + bf16 GEMM with the scale in the epilogue
-    (covers the 4-wave and the 8-wave kernels)."""
+@pytest.mark.parametrize("M,N,K", [(100, 512, 256), (386, 1536, 1024), (700, 768, 512), (33, 272, 192), (300, 4608, 3584)])
+@pytest.mark.parametrize("epi", [0, 1, 3])
+@pytest.mark.parametrize("variant", [2, 3, 4, 7])
+def test_gemm_w8_tiled(dev, M, N, K, epi, variant):
+    """M > 16 with fp8 weights.  variant 3 / 4: the 8-wave 256x256 / 128x256 kernel reads the fp8 fragments directly (e4m3 ->
+    bf16 after the LDS read, three 48-KB stages); 7: exact dequantisation into the bf16 fragment order + the 4-wave bf16 GEMM;
+    2: the shipped choice.  The row scale is applied in the epilogue in every case."""
     from livecc_amd import ops
     from livecc_amd.weights import dequantize_fp8_rows, quantize_fp8_rows
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2).float(), _rand((N,), dev, 0.1, 3)
     res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
     q, sc = quantize_fp8_rows(w)
     w8, _ = ops.quantize_fp8(w)
-    got = ops.linear_w8(x, w8, sc, b, epi, res)
+    ops.set_gemm_variant(variant)
+    try:
+        got = ops.linear_w8(x, w8, sc, b, epi, res)
+        part = ops.linear_w8(x, w8, sc, nsplit=2)
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     ref, atol = _ref_linear(x, dequantize_fp8_rows(q, sc), b, epi, res, with_atol=True)
-    assert_bf16_close(got, ref, f"gemm_w8[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
-    part = ops.linear_w8(x, w8, sc, nsplit=2)
+    assert_bf16_close(got, ref, f"gemm_w8[{M}x{N}x{K},epi{epi},v{variant}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
     r32 = x.float() @ dequantize_fp8_rows(q, sc).t()
     assert (part.sum(0) - r32).abs().max().item() <= 2e-5 * float(r32.abs().max()) * math.sqrt(K / 256) + 1e-5
 
