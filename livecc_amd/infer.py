@@ -1,8 +1,10 @@
 """Stream orchestrator with the surface of the reference's `LiveCCDemoInfer` (ref demo/infer.py:25-310), driving the
 native model instead of HF.  Video decode / resize (decord, torchvision) are outside this round's scope:
 clips arrive as uint8 frame tensors already at the model resolution (what `get_smart_resized_clip`,
-ref livecc_utils/video_process_patch.py:126-156, returns), and text arrives either through a real HF processor /
-tokenizer (when a checkpoint directory with tokenizer files is given) or as synthetic turn ids (`TurnBuilder`).
+ref livecc_utils/video_process_patch.py:126-156, returns).  Text: with tokenizer files (a checkpoint directory, or a
+`text.TextFrontEnd` passed in) the turns are built from real strings exactly as the reference does -- chat template,
+'Time=a-bs' prefix, query appended on the first turn or when it changes, '<|im_end|>\n' glue, `processor.decode` of the
+answer (ref demo/infer.py:134-157, 175); without them the turn ids are synthetic (`protocol.TurnBuilder`, benchmarks).
 """
 from __future__ import annotations
 
@@ -33,23 +35,38 @@ class LiveCCDemoInfer:
 
     def __init__(self, model: LiveCCForConditionalGeneration = None, model_path: str = None, device: str = None,
                  turn_builder: Optional[protocol.TurnBuilder] = None, decode: Optional[Callable[[List[int]], str]] = None,
-                 streaming_eos_token_id: Optional[int] = None):
+                 streaming_eos_token_id: Optional[int] = None, text=None):
+        """`text`: a `text.TextFrontEnd` (real tokenizer).  With `model_path` it is created from the checkpoint directory's
+        tokenizer files when they exist (ref demo/infer.py:48-58)."""
         if model is None:
             device = device or "cuda"
             model = LiveCCForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map=device)
         self.model = model
         self.cfg = model.cfg
+        if text is None and model_path is not None:
+            import os
+            if any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.json", "vocab.json", "tokenizer_config.json")):
+                from .text import TextFrontEnd
+                text = TextFrontEnd(model_path, self.cfg)
+        self.text = text
         self.turn_builder = turn_builder or protocol.TurnBuilder(self.cfg)
-        self.decode = decode or (lambda ids: " ".join(str(i) for i in ids))
-        # ref infer.py:49: tokenizer(' ...').input_ids[-1]; without tokenizer files the caller supplies it
-        self.streaming_eos_token_id = streaming_eos_token_id
+        if text is not None:
+            self.decode = decode or (lambda ids: text.decode(ids, skip_special_tokens=True))
+            self.streaming_eos_token_id = text.streaming_eos_token_id if streaming_eos_token_id is None else streaming_eos_token_id
+        else:
+            self.decode = decode or (lambda ids: " ".join(str(i) for i in ids))
+            # ref infer.py:49: tokenizer(' ...').input_ids[-1]; without tokenizer files the caller supplies it
+            self.streaming_eos_token_id = streaming_eos_token_id
 
     @torch.inference_mode()
     def live_cc(self, clip: torch.Tensor, state: dict, frames_layout: str = "TCHW", do_sample: bool = False,
                 repetition_penalty: float = 1.05, streaming_eos_base_threshold: float = None,
-                streaming_eos_threshold_step: float = None, max_new_tokens: int = 16, force_length: bool = False):
+                streaming_eos_threshold_step: float = None, max_new_tokens: int = 16, force_length: bool = False,
+                message: Optional[str] = None, default_query: str = "Please describe the video."):
         """One call = the frames that became due since the last call (ref infer.py:61-180, steps 4-5).
-        `clip`: uint8 frames [T,3,H,W] (or THWC).  Yields ((start, stop), text, state) per chunk."""
+        `clip`: uint8 frames [T,3,H,W] (or THWC).  Yields ((start, stop), text, state) per chunk.
+        `message` / `default_query` (real-tokenizer mode): the user query, appended to the turn when it is new or changed
+        (ref infer.py:141-146)."""
         if do_sample:
             raise NotImplementedError("pass do_sample=False (greedy); see modeling.generate")
         initialized = state.get("last_timestamp", -1.0) >= 0
@@ -60,8 +77,17 @@ class LiveCCDemoInfer:
             stop = t0 + b * self.frame_time_interval
             turn = state.get("turn_index", 0)
             grid = protocol.grid_of(frames.shape[0], *(frames.shape[2:] if frames_layout == "TCHW" else frames.shape[1:3]), self.cfg)
-            new_ids = self.turn_builder.turn_ids(turn, protocol.num_video_tokens(grid, self.cfg))
             past_ids = state.get("past_ids")
+            if self.text is not None:
+                if not message and not state.get("message"):
+                    message = default_query                       # ref infer.py:141-143
+                query = None
+                if message and state.get("message") != message:   # ref infer.py:144-146
+                    query = message
+                    state["message"] = message
+                new_ids = self.text.turn_ids(start, stop, grid, query, continuing=past_ids is not None)
+            else:
+                new_ids = self.turn_builder.turn_ids(turn, protocol.num_video_tokens(grid, self.cfg))
             ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
             procs = None
             if streaming_eos_base_threshold is not None and self.streaming_eos_token_id is not None:
@@ -81,18 +107,27 @@ class LiveCCDemoInfer:
             yield (start, stop), self.decode([t for t in new_tokens if t != self.cfg.eos_token_id]), state
 
     @torch.inference_mode()
-    def video_qa(self, query_len: int, state: dict, clip: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
+    def video_qa(self, query_len, state: dict, clip: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
                  repetition_penalty: float = 1.05, max_new_tokens: int = 512, force_length: bool = False):
         """Multi-turn QA with KV reuse (ref demo/infer.py:182-242): the first turn prefills the WHOLE clip in one shot
-        (up to 480 frames / 24k visual tokens), later turns are text only.  Returns (generated ids, state)."""
+        (up to 480 frames / 24k visual tokens), later turns are text only.  `query_len`: the query STRING in real-tokenizer
+        mode (the reference's `message`), or the number of synthetic query ids.  Returns (generated ids, state) -- with a
+        tokenizer, `self.decode(ids)` is the reference's `response`."""
         turn = state.get("turn_index", 0)
         past_ids = state.get("past_ids")
         n_vid = 0
+        grid = None
         if past_ids is None and clip is not None:       # "only use once" (infer.py:213-214)
             grid = protocol.grid_of(clip.shape[0], *(clip.shape[2:] if frames_layout == "TCHW" else clip.shape[1:3]), self.cfg)
             n_vid = protocol.num_video_tokens(grid, self.cfg)
-        self.turn_builder.query_len = query_len
-        new_ids = self.turn_builder.turn_ids(turn, n_vid, with_query=True)
+        if isinstance(query_len, str):
+            if self.text is None:
+                raise ValueError("a query string needs tokenizer files (pass text=TextFrontEnd(...) or a checkpoint directory)")
+            new_ids = self.text.encode(self.text.qa_text(query_len, continuing=past_ids is not None, with_video=grid is not None),
+                                       [grid] if grid is not None else [])
+        else:
+            self.turn_builder.query_len = query_len
+            new_ids = self.turn_builder.turn_ids(turn, n_vid, with_query=True)
         ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
         out = self.model.generate(
             input_ids=torch.from_numpy(ids).view(1, -1), frames=clip if n_vid else None, frames_layout=frames_layout,
@@ -107,12 +142,13 @@ class LiveCCDemoInfer:
 
     @torch.inference_mode()
     def live_cc_once_for_evaluation(self, clip: torch.Tensor, frames_layout: str = "TCHW", max_new_tokens: int = 32,
-                                    repetition_penalty: float = 1.05, video_start: float = 0.0, force_length: bool = False):
+                                    repetition_penalty: float = 1.05, video_start: float = 0.0, force_length: bool = False,
+                                    query: Optional[str] = None):
         """Offline replay of a whole clip (ref infer.py:244-310): chunks 6,2,2,...; returns [[t0, t1, text], ...]."""
         state: dict = {}
         responses = []
         for (a, b), text, state in self.live_cc(clip, state, frames_layout=frames_layout, repetition_penalty=repetition_penalty,
-                                                max_new_tokens=max_new_tokens, force_length=force_length):
+                                                max_new_tokens=max_new_tokens, force_length=force_length, message=query):
             responses.append([video_start + a, video_start + b, text])
         self.last_state = state
         return responses

@@ -366,3 +366,63 @@ def test_streaming_generate_fp8_llm_weights_matches_oracle(dev):
     turns = _replay_native(native, cfg, frames, protocol.TurnBuilder(cfg, seed=77), max_new_tokens=8, repetition_penalty=1.05,
                            max_turns=3)
     _compare_stream(cfg, hf16, hf32, turns, frames, "stream_tiny_fp8_weights", 1.05)
+
+
+def test_demo_infer_with_real_tokenizer_text_in_text_out(dev, tmp_path):
+    """`LiveCCDemoInfer` with tokenizer files: query string in, commentary strings out, the reference's turn protocol
+    (query only on the first turn or when it changes, '<|im_end|>\\n' glue, past_ids = sequences[:-1]); the ids the front end
+    builds are replayed through the HF oracle and the native logits must match it."""
+    import dataclasses
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.infer import LiveCCDemoInfer
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.text import TextFrontEnd
+    from oracle import hf_oracle as O
+    from tests.test_text import make_tokenizer_dir
+    fe0 = TextFrontEnd(make_tokenizer_dir(tmp_path))
+    tk = fe0.tokenizer
+    cfg = dataclasses.replace(tiny(), video_token_id=fe0.video_token_id, eos_token_id=fe0.eos_token_id,
+                              image_token_id=tk.convert_tokens_to_ids("<|image_pad|>"),
+                              vision_start_token_id=tk.convert_tokens_to_ids("<|vision_start|>"),
+                              vision_end_token_id=tk.convert_tokens_to_ids("<|vision_end|>"),
+                              bos_token_id=tk.convert_tokens_to_ids("<|endoftext|>"))
+    hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=5, init_scale=2.0)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=2, max_kv_len=2048, max_new_rows=1024,
+                                                          max_patches=4096, max_history=32)
+    infer = LiveCCDemoInfer(model=native, text=TextFrontEnd(tk, cfg))
+    assert infer.streaming_eos_token_id == tk(" ...").input_ids[-1]
+    frames = torch.from_numpy(protocol.synth_frames(10, 56, 84, seed=9, layout="TCHW"))
+    state, outs, lens = {}, [], []
+    for (a, b), text, state in infer.live_cc(frames, state, message="what is happening now?", max_new_tokens=6, force_length=True):
+        assert isinstance(text, str)
+        outs.append(((a, b), text))
+        lens.append(len(state["past_ids"]))
+    assert [o[0] for o in outs] == [(0.0, 3.0), (3.0, 4.0), (4.0, 5.0)] and state["message"] == "what is happening now?"
+    full = tk.decode(state["past_ids"].tolist(), skip_special_tokens=False)
+    assert full.count("what is happening now?") == 1, "the query is sent once (ref infer.py:144-146)"
+    assert full.count("<|im_start|>system") == 1 and full.count("Time=3.0-4.0s") == 1 and full.count("<|im_start|>assistant\n") == 3
+    # a changed query is appended to the next turn
+    more = torch.from_numpy(protocol.synth_frames(2, 56, 84, seed=10, layout="TCHW"))
+    (_, _), _, state = next(iter(infer.live_cc(more, state, message="and now?", max_new_tokens=4, force_length=True)))
+    assert tk.decode(state["past_ids"].tolist(), skip_special_tokens=False).count("and now?") == 1
+    state["past_key_values"].release()
+    # the front end's ids through the HF oracle: same logits (teacher-forced along the native tokens)
+    fe = infer.text
+    st2, past, s16 = None, None, O.OracleStream(hf16, cfg)
+    for ti, (a, b) in enumerate(protocol.split_clip(10)):
+        clip = frames[a:b]
+        grid = protocol.grid_of(clip.shape[0], 56, 84, cfg)
+        new_ids = fe.turn_ids(a * 0.5, b * 0.5, grid, "what is happening now?" if ti == 0 else None, continuing=past is not None)
+        ids = new_ids if past is None else np.concatenate([past, new_ids])
+        r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=clip, past_key_values=st2, repetition_penalty=1.05,
+                            max_new_tokens=6, min_new_tokens=6, output_logits=True)
+        st2, seq = r.past_key_values, r.sequences[0].cpu().numpy()
+        past = seq[:-1]
+        toks = seq[len(ids):].tolist()
+        pv, g = O.patchify_normalize_ref(clip, cfg)
+        ro = s16.turn(new_ids, pv, g, max_new_tokens=6, repetition_penalty=1.05, teacher_tokens=toks)
+        for k in range(6):
+            lo, ln = ro["logits"][k], r.logits[k].float().cpu()
+            assert (ln - lo).abs().max().item() <= 6e-2 * lo.abs().max().item(), f"turn {ti} step {k}"
+    st2.release()
