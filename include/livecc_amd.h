@@ -79,6 +79,15 @@ int lcc_debug_mfma_probe(const void* A, const void* B, float* D, void* stream);
  * HF:image_processing_backends.py:307-333).  frames: uint8, layout 0=[T,H,W,3], 1=[T,3,H,W]; out bf16 [P,ld]. */
 int lcc_patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W, const float mean255[3],
                          const float std255[3], void* out, int ld, void* stream);
+/* Frame resize in front of the hot path: ref livecc_utils/video_process_patch.py:150-155 =
+ * torchvision.transforms.functional.resize(uint8 clip, [Hout, Wout], BICUBIC, antialias=True), i.e. ATen's float32 separable
+ * antialias bicubic (width pass, then height pass, taps accumulated in order with FMAs), clamp to [0,255], round half to even.
+ * src: uint8 frames, layout 0 = [T,Hin,Win,3], 1 = [T,3,Hin,Win]; dst: uint8 [T,3,Hout,Wout].  Tap tables per output index
+ * (first source index, tap count, fp32 weights [out][k]) are computed by the caller with ATen's arithmetic
+ * (livecc_amd/resize.py:aa_bicubic_taps); tmp = T*3*Hin*Wout floats.  Bit-identical to the reference's CPU result. */
+int lcc_resize_bicubic_aa_u8(const uint8_t* src, int layout, int T, int Hin, int Win, uint8_t* dst, int Hout, int Wout,
+                             const int32_t* xmin, const int32_t* xsize, const float* wx, int kx, const int32_t* ymin,
+                             const int32_t* ysize, const float* wy, int ky, float* tmp, void* stream);
 int lcc_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);  /* pixel_values.type(bf16) Q2VL:1044 */
 
 int lcc_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, void* stream); /* Q2VL:428-429,281 */

@@ -102,6 +102,7 @@ def load():
         "lcc_mrope_table": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "lcc_rope_kv_append_bf16": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, vp]),
         "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "lcc_resize_bicubic_aa_u8": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp]),
         "lcc_gemm_w8_bf16": (i32, [vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
         "lcc_attn_decode_bf16": (i32, [vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, vp, vp, vp]),
         "lcc_attn_decode_fused_bf16": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp, vp, vp, vp]),

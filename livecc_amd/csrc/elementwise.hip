@@ -505,4 +505,64 @@ int swiglu_bf16(const bf16_t* g, const bf16_t* u, bf16_t* out, int64_t n, hipStr
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bicubic antialias resize of uint8 frames (ref livecc_utils/video_process_patch.py:150-155 =
+// torchvision.transforms.functional.resize(uint8, BICUBIC, antialias=True) = float32 ATen `_upsample_bicubic2d_aa` + clamp +
+// round-half-even).  Separable, width pass then height pass, fp32, taps accumulated in order: t = s0*w0; t = fma(s_j, w_j, t)
+// (ATen's `interpolate_aa_single_dim` as compiled: bit-identical results, tests/test_gpu_resize.py).  The tap tables come from
+// the host (livecc_amd/resize.py) so that no weight is ever computed with different rounding on the device.
+// HBM-bound byte work: pass 1 reads each source byte ~support times out of L2, writes Hin*Wout floats; pass 2 reads them
+// coalesced along x and writes the uint8 result.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_aa_h_kernel(const uint8_t* __restrict__ src, int layout, int T, int Hin, int Win,
+                                                          int Wout, const int32_t* __restrict__ xmin, const int32_t* __restrict__ xsize,
+                                                          const float* __restrict__ wx, int kx, float* __restrict__ tmp) {
+  const size_t total = (size_t)T * 3 * Hin * Wout;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % Wout);
+  size_t r = i / Wout;
+  const int y = (int)(r % Hin); r /= Hin;
+  const int c = (int)(r % 3);
+  const int t = (int)(r / 3);
+  const int x0 = xmin[xo], n = xsize[xo];
+  const float* w = wx + (size_t)xo * kx;
+  const uint8_t* p;
+  size_t stride;
+  if (layout == 0) { p = src + (((size_t)t * Hin + y) * Win + x0) * 3 + c; stride = 3; }          // THWC
+  else { p = src + (((size_t)t * 3 + c) * Hin + y) * Win + x0; stride = 1; }                      // TCHW
+  float acc = __fmul_rn((float)p[0], w[0]);
+  for (int j = 1; j < n; ++j) acc = fmaf((float)p[(size_t)j * stride], w[j], acc);
+  tmp[i] = acc;                                                                                    // [T][3][Hin][Wout]
+}
+
+__global__ __launch_bounds__(256) void resize_aa_v_kernel(const float* __restrict__ tmp, int T, int Hin, int Hout, int Wout,
+                                                          const int32_t* __restrict__ ymin, const int32_t* __restrict__ ysize,
+                                                          const float* __restrict__ wy, int ky, uint8_t* __restrict__ dst) {
+  const size_t total = (size_t)T * 3 * Hout * Wout;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % Wout);
+  size_t r = i / Wout;
+  const int yo = (int)(r % Hout);
+  const size_t tc = r / Hout;
+  const int y0 = ymin[yo], n = ysize[yo];
+  const float* w = wy + (size_t)yo * ky;
+  const float* p = tmp + (tc * Hin + y0) * Wout + xo;
+  float acc = __fmul_rn(p[0], w[0]);
+  for (int j = 1; j < n; ++j) acc = fmaf(p[(size_t)j * Wout], w[j], acc);
+  acc = fminf(fmaxf(acc, 0.f), 255.f);          // torchvision clamps the bicubic overshoot, then rounds half to even
+  dst[i] = (uint8_t)rintf(acc);                 // [T][3][Hout][Wout]
+}
+
+int resize_bicubic_aa_u8(const uint8_t* src, int layout, int T, int Hin, int Win, uint8_t* dst, int Hout, int Wout,
+                         const int32_t* xmin, const int32_t* xsize, const float* wx, int kx, const int32_t* ymin,
+                         const int32_t* ysize, const float* wy, int ky, float* tmp, hipStream_t st) {
+  if (T <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || kx <= 0 || ky <= 0 || (layout != 0 && layout != 1)) return LCC_ERR_SHAPE;
+  const size_t n1 = (size_t)T * 3 * Hin * Wout, n2 = (size_t)T * 3 * Hout * Wout;
+  resize_aa_h_kernel<<<dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st>>>(src, layout, T, Hin, Win, Wout, xmin, xsize, wx, kx, tmp);
+  resize_aa_v_kernel<<<dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st>>>(tmp, T, Hin, Hout, Wout, ymin, ysize, wy, ky, dst);
+  return 0;
+}
+
 }  // namespace lcc

@@ -851,6 +851,13 @@ extern "C" int lcc_patchify_norm_u8(const uint8_t* frames, int layout, int T, in
   if (!frames || !out || !mean255 || !std255) return fail(LCC_ERR_ARG, "lcc_patchify_norm_u8: null pointer");
   OP_RET(patchify_norm_u8(frames, layout, T, H, W, mean255, std255, (bf16_t*)out, ld, (hipStream_t)stream), "lcc_patchify_norm_u8");
 }
+extern "C" int lcc_resize_bicubic_aa_u8(const uint8_t* src, int layout, int T, int Hin, int Win, uint8_t* dst, int Hout, int Wout,
+                                        const int32_t* xmin, const int32_t* xsize, const float* wx, int kx, const int32_t* ymin,
+                                        const int32_t* ysize, const float* wy, int ky, float* tmp, void* stream) {
+  if (!src || !dst || !xmin || !xsize || !wx || !ymin || !ysize || !wy || !tmp) return fail(LCC_ERR_ARG, "lcc_resize_bicubic_aa_u8: null pointer");
+  OP_RET(resize_bicubic_aa_u8(src, layout, T, Hin, Win, dst, Hout, Wout, xmin, xsize, wx, kx, ymin, ysize, wy, ky, tmp, (hipStream_t)stream),
+         "lcc_resize_bicubic_aa_u8");
+}
 extern "C" int lcc_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
   if (!in || !out) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(cast_f32_bf16(in, (bf16_t*)out, n, (hipStream_t)stream), "lcc_cast_f32_bf16");

@@ -57,6 +57,9 @@ int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
 // ---- elementwise / normalisation / layout (elementwise.hip) ----
 int patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W, const float* mean255,
                      const float* std255, bf16_t* out, int ld, hipStream_t st);
+int resize_bicubic_aa_u8(const uint8_t* src, int layout, int T, int Hin, int Win, uint8_t* dst, int Hout, int Wout,
+                         const int32_t* xmin, const int32_t* xsize, const float* wx, int kx, const int32_t* ymin,
+                         const int32_t* ysize, const float* wy, int ky, float* tmp, hipStream_t st);
 int cast_f32_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st);
 int layernorm_bf16(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int dim, float eps,
                    hipStream_t st);

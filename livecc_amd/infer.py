@@ -107,6 +107,40 @@ class LiveCCDemoInfer:
             yield (start, stop), self.decode([t for t in new_tokens if t != self.cfg.eos_token_id]), state
 
     @torch.inference_mode()
+    def live_cc_from_video(self, video_frames: torch.Tensor, video_pts, state: dict, video_timestamp: float,
+                           max_pixels: int = 384 * 28 * 28, frames_layout: str = "THWC", **kw):
+        """The whole `live_cc` of the reference (ref demo/infer.py:61-180) on a decoded video that is resident on the GPU
+        (`video_frames` uint8 [N,H,W,3], `video_pts` seconds per frame; decoding itself stays external): decide which frames
+        became due at wall-clock `video_timestamp` (steps 1-2), fetch and resize them on the GPU (step 3,
+        `resize.get_smart_resized_clip`), then chunk + generate (steps 4-5, `live_cc`).  `state` carries `last_timestamp`,
+        `last_video_pts_index`, `resized_hw`, `video_end` as the reference's does.  Yields ((start, stop), text, state)."""
+        from . import resize as R
+        pts = np.asarray(video_pts, dtype=np.float64)
+        last_timestamp = state.get("last_timestamp", -1 / self.fps)
+        if "resized_hw" not in state:                                  # get_smart_resized_video_reader, once per video
+            hw = video_frames.shape[1:3] if frames_layout == "THWC" else video_frames.shape[2:4]
+            state["resized_hw"] = R.smart_resized_hw(int(hw[0]), int(hw[1]), int(video_frames.shape[0]), max_pixels)
+            state["last_video_pts_index"] = -1
+        video_timestamp = min(float(video_timestamp), float(pts[-1]))
+        if last_timestamp + self.frame_time_interval > pts[-1]:
+            state["video_end"] = True
+            return
+        initialized = last_timestamp >= 0
+        if not initialized:
+            video_timestamp = max(video_timestamp, self.initial_time_interval)
+        if video_timestamp <= last_timestamp + self.frame_time_interval:
+            return
+        timestamps = torch.arange(last_timestamp + self.frame_time_interval, video_timestamp, self.frame_time_interval).tolist()
+        h, w = state["resized_hw"]
+        clip, clip_ts, idxs = R.get_smart_resized_clip(video_frames, h, w, timestamps, pts, state["last_video_pts_index"] + 1, frames_layout)
+        if len(idxs) == 0:
+            return
+        state["last_video_pts_index"] = idxs[-1]
+        for out in self.live_cc(clip, state, frames_layout="TCHW", **kw):
+            yield out
+        state["last_timestamp"] = clip_ts[-1]                          # ref infer.py:118 (set from the fetched timestamps)
+
+    @torch.inference_mode()
     def video_qa(self, query_len, state: dict, clip: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
                  repetition_penalty: float = 1.05, max_new_tokens: int = 512, force_length: bool = False):
         """Multi-turn QA with KV reuse (ref demo/infer.py:182-242): the first turn prefills the WHOLE clip in one shot

@@ -58,3 +58,4 @@ if __name__ == "__main__":
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
     for ti in range(int(o["n_turns"])):
         print(ti, o[f"t{ti}_grid"].tolist(), o[f"t{ti}_tokens"].tolist())
+
