@@ -175,6 +175,33 @@ class LiveCCDemoInfer:
         return seq[len(ids):].tolist(), state
 
     @torch.inference_mode()
+    def mcq_predict(self, clip: Optional[torch.Tensor], question: str, options: List[str], letters=("A", "B", "C", "D"),
+                    frames_layout: str = "TCHW", question_prefix: str = "", question_postfix: str = "\nPlease select the correct answer.",
+                    answer_prefix: str = "Answer:", abcd_previous_str: str = ": ", subtitles: Optional[str] = None):
+        """Prefill-only multiple-choice scoring (ref evaluation/distributed_mcq_predictor.py:33-105): one-shot
+        prefill of [video] + question + options + 'Answer:', logits of the LAST prompt position restricted to the option-letter
+        ids (`tokenizer(': A').input_ids[-1]`, ...), argmax.  Returns (index of the chosen option, restricted logits).
+        Needs tokenizer files (`self.text`)."""
+        if self.text is None:
+            raise ValueError("mcq_predict needs tokenizer files (pass text=TextFrontEnd(...) or a checkpoint directory)")
+        tok = self.text.tokenizer
+        letter_ids = [tok(f"{abcd_previous_str}{x}").input_ids[-1] for x in letters]             # ref :91
+        query = question_prefix + question + "\n" + "\n".join(options) + question_postfix       # ref :37
+        if subtitles is not None:                                                                # ref :50-52
+            query = f"This video's subtitles are listed below:\n{subtitles}\nAccording to the video and subtitles, " + query
+        grid = None
+        if clip is not None:
+            grid = protocol.grid_of(clip.shape[0], *(clip.shape[2:] if frames_layout == "TCHW" else clip.shape[1:3]), self.cfg)
+        text = self.text.qa_text(query, continuing=False, with_video=grid is not None) + answer_prefix   # ref :56-57
+        ids = self.text.encode(text, [grid] if grid is not None else [])
+        out = self.model.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=clip, frames_layout=frames_layout,
+                                  return_dict_in_generate=True, do_sample=False, repetition_penalty=1.0, max_new_tokens=1,
+                                  output_logits=True, pad_token_id=self.cfg.eos_token_id)
+        out.past_key_values.release()
+        logits = out.logits[0].float().view(-1)[torch.as_tensor(letter_ids, device=out.logits.device)]
+        return int(torch.argmax(logits)), logits.cpu()
+
+    @torch.inference_mode()
     def live_cc_once_for_evaluation(self, clip: torch.Tensor, frames_layout: str = "TCHW", max_new_tokens: int = 32,
                                     repetition_penalty: float = 1.05, video_start: float = 0.0, force_length: bool = False,
                                     query: Optional[str] = None):

@@ -426,3 +426,45 @@ def test_demo_infer_with_real_tokenizer_text_in_text_out(dev, tmp_path):
             lo, ln = ro["logits"][k], r.logits[k].float().cpu()
             assert (ln - lo).abs().max().item() <= 6e-2 * lo.abs().max().item(), f"turn {ti} step {k}"
     st2.release()
+
+
+def test_mcq_prefill_only_scoring_matches_oracle(dev, tmp_path):
+    """prefill-only multiple-choice scoring (ref evaluation/distributed_mcq_predictor.py): the restricted
+    option-letter logits of the last prompt position against the HF oracle's forward on the same ids."""
+    import dataclasses
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.infer import LiveCCDemoInfer
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.text import TextFrontEnd
+    from oracle import hf_oracle as O
+    from tests.test_text import make_tokenizer_dir
+    fe0 = TextFrontEnd(make_tokenizer_dir(tmp_path))
+    tk = fe0.tokenizer
+    cfg = dataclasses.replace(tiny(), video_token_id=fe0.video_token_id, eos_token_id=fe0.eos_token_id,
+                              image_token_id=tk.convert_tokens_to_ids("<|image_pad|>"),
+                              vision_start_token_id=tk.convert_tokens_to_ids("<|vision_start|>"),
+                              vision_end_token_id=tk.convert_tokens_to_ids("<|vision_end|>"),
+                              bos_token_id=tk.convert_tokens_to_ids("<|endoftext|>"))
+    hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=8, init_scale=2.0)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=2048, max_new_rows=1024,
+                                                          max_patches=4096, max_history=8)
+    infer = LiveCCDemoInfer(model=native, text=TextFrontEnd(tk, cfg))
+    frames = torch.from_numpy(protocol.synth_frames(4, 56, 84, seed=4, layout="TCHW"))
+    question, options = "what is happening now?", ["A. system", "B. user", "C. assistant", "D. video"]
+    choice, lg = infer.mcq_predict(frames, question, options)
+    assert lg.shape == (4,) and 0 <= choice < 4
+    # oracle: same ids, one forward, logits at the last position
+    fe = infer.text
+    letter_ids = [tk(f": {x}").input_ids[-1] for x in "ABCD"]
+    query = question + "\n" + "\n".join(options) + "\nPlease select the correct answer."
+    grid = protocol.grid_of(4, 56, 84, cfg)
+    ids = fe.encode(fe.qa_text(query, continuing=False, with_video=True) + "Answer:", [grid])
+    assert fe.decode(ids, skip_special_tokens=False).endswith("<|im_start|>assistant\nAnswer:")
+    pv, g = O.patchify_normalize_ref(frames, cfg)
+    ro = O.OracleStream(hf16, cfg).turn(ids, pv, g, max_new_tokens=1, repetition_penalty=1.0)
+    ref = ro["logits"][0][letter_ids]
+    assert (lg - ref).abs().max().item() <= 6e-2 * ro["logits"][0].abs().max().item()
+    margin = torch.topk(ref, 2).values
+    if (margin[0] - margin[1]).item() > 2 * (lg - ref).abs().max().item():
+        assert choice == int(torch.argmax(ref))
