@@ -1,0 +1,187 @@
+"""Multi-stream real-time loop: what replaces `LiveCCDemoInfer.live_cc`'s per-stream generator and its Gradio /
+CLI callers (ref demo/infer.py:61-180, demo/app.py:108-146, demo/cli.py) when MANY 2-fps video streams share one GPU.
+
+The reference serves one stream per blocking `generate` call; with concurrent callers it is not even safe (`rope_deltas` is
+module state, HF modeling_qwen2_vl.py:857).  Here every stream keeps its own state (KV slot, rope_delta, past_ids, timestamps)
+and one scheduler thread owns the device:
+
+  * `step(now)`: for every stream, decide with the reference's rule which frames became due at its video time (`demo/infer.py`
+    steps 1-2), take its OLDEST pending chunk (6 frames first, then 2), fetch + resize it on the GPU (step 3), build the turn
+    ids (step 5) -- and run ALL the streams' chunks as ONE `generate_batch` call: one batched ViT, one packed prefill, decode
+    steps that stream the weights once for the whole batch (continuous batching at chunk granularity);
+  * pacing (the reference's): the first chunk (6 frames = 3 s) is taken at once, every later 2-frame chunk becomes due when
+    the stream's video clock passes its first frame time; `run()` sleeps until the next due time (real-time mode) or jumps
+    its clock there (offline replay);
+  * back-pressure: a stream that falls more than `max_lag_s` behind either keeps catching up one chunk per step ("catch_up",
+    the reference's behaviour: it processes every pending chunk) or skips the stale frames ("drop": the skipped interval is
+    never shown to the model, the next chunk starts at the newest due frame pair);
+  * stateless mode (`hf_spaces`, ref demo/infer.py:176-178): results carry a light state without KV / past_ids.
+
+Video decoding stays external: a stream is a GPU-resident uint8 frame tensor plus its pts (or any object with the same two
+attributes that a decoder thread appends to).
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import protocol
+from . import resize as R
+from .infer import LiveCCDemoInfer, ThresholdLogitsProcessor
+
+
+@dataclasses.dataclass
+class _Stream:
+    sid: object
+    frames: torch.Tensor                 # uint8 [N,H,W,3] (THWC) on the GPU
+    pts: np.ndarray                      # seconds
+    query: Optional[str]
+    layout: str
+    t_start: float                       # wall-clock time at which the stream's video time is 0
+    resized_hw: Tuple[int, int]
+    last_timestamp: float = -1.0 / protocol.FPS
+    last_pts_index: int = -1
+    turn_index: int = 0
+    past_ids: Optional[np.ndarray] = None
+    kv: object = None
+    sent_query: Optional[str] = None
+    ended: bool = False
+    dropped_s: float = 0.0
+
+
+class StreamServer:
+    def __init__(self, infer: LiveCCDemoInfer, max_new_tokens: int = 16, repetition_penalty: float = 1.05,
+                 streaming_eos_base_threshold: Optional[float] = None, streaming_eos_threshold_step: float = 0.0,
+                 default_query: str = "Please describe the video.", max_lag_s: float = 4.0, lag_policy: str = "catch_up",
+                 force_length: bool = False):
+        if lag_policy not in ("catch_up", "drop"):
+            raise ValueError(lag_policy)
+        self.infer, self.model, self.cfg = infer, infer.model, infer.cfg
+        self.max_new_tokens, self.repetition_penalty = max_new_tokens, repetition_penalty
+        self.thr = (streaming_eos_base_threshold, streaming_eos_threshold_step)
+        self.default_query, self.max_lag_s, self.lag_policy, self.force_length = default_query, max_lag_s, lag_policy, force_length
+        self.streams: Dict[object, _Stream] = {}
+
+    # ---- stream management ----
+    def add_stream(self, sid, video_frames: torch.Tensor, video_pts, query: Optional[str] = None, t_start: float = 0.0,
+                   max_pixels: int = 384 * 28 * 28, layout: str = "THWC") -> None:
+        if len(self.streams) >= self.model.engine.max_slots:
+            raise RuntimeError(f"all {self.model.engine.max_slots} stream slots of this GPU are in use")
+        hw = video_frames.shape[1:3] if layout == "THWC" else video_frames.shape[2:4]
+        rh, rw = R.smart_resized_hw(int(hw[0]), int(hw[1]), int(video_frames.shape[0]), max_pixels)
+        self.streams[sid] = _Stream(sid, video_frames, np.asarray(video_pts, dtype=np.float64), query, layout, float(t_start), (rh, rw))
+
+    def remove_stream(self, sid) -> None:
+        st = self.streams.pop(sid)
+        if st.kv is not None:
+            st.kv.release()
+
+    # ---- which chunk of a stream is due (ref demo/infer.py steps 1-2, one chunk at a time) ----
+    def _next_chunk_timestamps(self, st: _Stream, now: float) -> Optional[List[float]]:
+        fti = protocol.FRAME_TIME_INTERVAL
+        if now < st.t_start:                              # the stream has not started yet
+            return None
+        video_time = min(now - st.t_start, float(st.pts[-1]))
+        if st.last_timestamp + fti > st.pts[-1]:
+            st.ended = True
+            return None
+        first = st.last_timestamp < 0
+        n = protocol.INITIAL_FPS_FRAMES if first else protocol.STREAMING_FPS_FRAMES
+        start = st.last_timestamp + fti
+        if first:
+            return [start + i * fti for i in range(n)]   # ref :107-110: the first call always takes the initial 3 s (6 frames)
+        # ref :111-113: a chunk is due as soon as the video clock has passed its FIRST frame time; its second frame is fetched
+        # with it (timestamps are padded to an even count, video_process_patch.py:134-135)
+        if video_time <= start:
+            return None
+        if self.lag_policy == "drop" and video_time - start > self.max_lag_s:
+            skip = float(int((video_time - start) / (n * fti))) * n * fti      # skip stale pairs: restart at the newest due pair
+            st.dropped_s += skip
+            start += skip
+        return [start + i * fti for i in range(n)]
+
+    def due_time(self, sid) -> Optional[float]:
+        """Wall-clock time at which the stream's next chunk becomes due (None when the stream has ended)."""
+        st = self.streams[sid]
+        if st.ended or st.last_timestamp + protocol.FRAME_TIME_INTERVAL > st.pts[-1]:
+            return None
+        if st.last_timestamp < 0:
+            return st.t_start
+        return st.t_start + st.last_timestamp + protocol.FRAME_TIME_INTERVAL + 1e-6
+
+    # ---- one scheduler step: at most one chunk per stream, all chunks in one batched generate ----
+    @torch.inference_mode()
+    def step(self, now: float, hf_spaces: bool = False):
+        reqs, metas = [], []
+        for st in self.streams.values():
+            if st.ended:
+                continue
+            ts = self._next_chunk_timestamps(st, now)
+            if ts is None:
+                continue
+            clip, clip_ts, idxs = R.get_smart_resized_clip(st.frames, st.resized_hw[0], st.resized_hw[1], ts, st.pts, st.last_pts_index + 1,
+                                                           st.layout)
+            if len(idxs) == 0:
+                st.ended = True
+                continue
+            start, stop = clip_ts[0], clip_ts[len(idxs) - 1] + protocol.FRAME_TIME_INTERVAL
+            grid = protocol.grid_of(clip.shape[0], clip.shape[2], clip.shape[3], self.cfg)
+            if self.infer.text is not None:
+                msg = st.query or self.default_query
+                q = msg if st.sent_query != msg else None
+                st.sent_query = msg
+                new_ids = self.infer.text.turn_ids(start, stop, grid, q, continuing=st.past_ids is not None)
+            else:
+                new_ids = self.infer.turn_builder.turn_ids(st.turn_index, protocol.num_video_tokens(grid, self.cfg))
+            ids = new_ids if st.past_ids is None else np.concatenate([st.past_ids, new_ids])
+            reqs.append(dict(input_ids=torch.from_numpy(ids), frames=clip, frames_layout="TCHW", state=st.kv))
+            metas.append((st, start, stop, len(ids), idxs[-1], clip_ts[-1]))     # ref :117-118 keeps timestamps[-1]
+        if not reqs:
+            return []
+        procs = None
+        if self.thr[0] is not None and self.infer.streaming_eos_token_id is not None:
+            procs = [ThresholdLogitsProcessor(self.infer.streaming_eos_token_id, self.thr[0], self.thr[1] or 0.0)]
+        outs = self.model.generate_batch(reqs, repetition_penalty=self.repetition_penalty, logits_processor=procs,
+                                         max_new_tokens=self.max_new_tokens, force_length=self.force_length)
+        results = []
+        for (st, start, stop, n_in, last_idx, last_ts), o in zip(metas, outs):
+            seq = o.sequences[0].cpu().numpy()
+            st.kv, st.past_ids = o.past_key_values, seq[:-1]            # ref demo/infer.py:173-174
+            st.turn_index += 1
+            st.last_pts_index, st.last_timestamp = last_idx, last_ts
+            toks = [int(t) for t in seq[n_in:] if t != self.cfg.eos_token_id]
+            state = dict(last_timestamp=st.last_timestamp, turn_index=st.turn_index, dropped_s=st.dropped_s)
+            if not hf_spaces:
+                state.update(past_ids=st.past_ids, past_key_values=st.kv)
+            results.append((st.sid, (start, stop), self.infer.decode(toks), state))
+        return results
+
+    # ---- driver loops ----
+    def run(self, until: Optional[float] = None, realtime: bool = True, clock: Callable[[], float] = time.monotonic,
+            sleep: Callable[[float], None] = time.sleep, on_result: Optional[Callable] = None, t0: Optional[float] = None):
+        """Serve until every stream has ended (or wall time `until`).  realtime=False replays back to back: the scheduler's
+        clock jumps to the next due time instead of sleeping (offline evaluation / benchmark)."""
+        out = []
+        base = clock() if t0 is None else t0
+        now = 0.0
+        while True:
+            now = (clock() - base) if realtime else now
+            res = self.step(now)
+            for r in res:
+                out.append(r)
+                if on_result:
+                    on_result(*r)
+            dues = [d for d in (self.due_time(s) for s in list(self.streams)) if d is not None]
+            if not dues or (until is not None and now >= until):
+                break
+            nxt = min(dues)
+            if not res and nxt > now:
+                if realtime:
+                    sleep(min(nxt - now, 0.25))
+                else:
+                    now = nxt
+        return out
