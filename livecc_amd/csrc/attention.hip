@@ -66,7 +66,7 @@ LCC_DEVICE void load_v(u32x4 (&vf)[D / 16], const bf16_t* vt_block, int li, int 
 template <int D, int NQ>
 LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (&vf)[D / 16],
                           const u32x4 (&qf)[NQ][(D + 31) / 32], int kb, int g, const int (&key_limit)[NQ],
-                          float scale_log2e) {
+                          float scale_log2e, const int (&min_limit)[NQ]) {
   constexpr int KS = (D + 31) / 32;
   f32x4 s[2][NQ];
 #pragma unroll
@@ -81,19 +81,31 @@ LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (
   bf16x8 pf[NQ];
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
+    // Row maximum over the RAW scores (scale > 0), then p = exp2(fma(s, scale, -m)): one FMA per score instead of a multiply
+    // and a subtract.  Tiles that lie entirely below this wave's smallest key limit (all but the diagonal / last tile of a
+    // long key range) skip the per-score compare + select.  (wave-uniform branch; the VALU work per score is what bounds
+    // these kernels: 7 head-waves x 32 MFMAs per 32-key tile leave the SIMDs VALU-limited.)
+    const bool masked = kb + 32 > __builtin_amdgcn_readfirstlane(min_limit[n]);
     float mx = -INFINITY;
+    if (masked) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb + g * 8 + kt * 4 + r;
-        float v = (key < key_limit[n]) ? s[kt][n][r] * scale_log2e : -INFINITY;
-        s[kt][n][r] = v;
-        mx = fmaxf(mx, v);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + g * 8 + kt * 4 + r;
+          const float v = (key < key_limit[n]) ? s[kt][n][r] : -INFINITY;
+          s[kt][n][r] = v;
+          mx = fmaxf(mx, v);
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][n][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(acc.m[n], mx);
+    const float m_new = fmaxf(acc.m[n], mx * scale_log2e);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = exp2f(acc.m[n] - m_use);  // acc.m = -inf -> 0
     acc.m[n] = m_new;
@@ -102,13 +114,18 @@ LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float e = exp2f(s[kt][n][r] - m_use);
+        float e = exp2f(fmaf(s[kt][n][r], scale_log2e, -m_use));   // masked scores are -inf -> 0
         p[kt * 4 + r] = e;
         psum += e;
       }
     acc.l[n] = acc.l[n] * alpha + psum;
+    // lazy rescale: once the running maximum has settled (almost every tile of a long key range) alpha is exactly 1.0 for
+    // every lane and the D/16 accumulator multiplies -- the bulk of the per-tile VALU work -- are skipped.  x * 1.0f is exact,
+    // so the result is bit-identical to always rescaling.  (wave-uniform branch)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int dt = 0; dt < D / 16; ++dt) acc.o[dt][n] *= alpha;
+      for (int dt = 0; dt < D / 16; ++dt) acc.o[dt][n] *= alpha;
+    }
     u32x4 pk = (u32x4){pack2(p[0], p[1]), pack2(p[2], p[3]), pack2(p[4], p[5]), pack2(p[6], p[7])};
     pf[n] = as_bf16x8(pk);
   }
@@ -121,12 +138,26 @@ LCC_DEVICE void attn_tile(AttnAcc<D, NQ>& acc, const KFrag<D>& kf, const u32x4 (
 // key-tile loop [t0, t1) with a two-tile register ring: while tile t is multiplied the loads of tile t+1 are already in
 // flight and those of tile t+2 are issued right after tile t's operands are consumed.  All loads are unconditional
 // (tile index clamped to t1-1, so a re-load of the last tile may be issued and ignored): straight-line code, counted waits.
+// wave-wide minimum of the per-lane key limits (tiles entirely below it need no mask)
+template <int NQ>
+LCC_DEVICE void wave_min_limits(const int (&key_limit)[NQ], int (&min_limit)[NQ]) {
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    int v = key_limit[n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    min_limit[n] = v;
+  }
+}
+
 struct NoHook { LCC_DEVICE void operator()() const {} };
 // `after_first_loads` runs once the first two tiles' loads have been issued (e.g. to build the q fragments while they fly)
 template <int D, int NQ, class KRow, class VBlk, class Hook = NoHook>
 LCC_DEVICE void attn_loop(AttnAcc<D, NQ>& acc, KRow krow, VBlk vblk, int t0, int t1, const u32x4 (&qf)[NQ][(D + 31) / 32],
                           int li, int g, const int (&key_limit)[NQ], float scale_log2e, Hook after_first_loads = Hook()) {
   if (t0 >= t1) { after_first_loads(); return; }
+  int min_limit[NQ];
+  wave_min_limits<NQ>(key_limit, min_limit);
   const int tl = t1 - 1;
   KFrag<D> ka, kb;
   u32x4 va[D / 16], vb[D / 16];
@@ -136,11 +167,11 @@ LCC_DEVICE void attn_loop(AttnAcc<D, NQ>& acc, KRow krow, VBlk vblk, int t0, int
   load_v<D>(vb, vblk(min(t0 + 1, tl)), li, g);
   after_first_loads();
   for (int t = t0; t < t1; t += 2) {
-    attn_tile<D, NQ>(acc, ka, va, qf, t * 32, g, key_limit, scale_log2e);
+    attn_tile<D, NQ>(acc, ka, va, qf, t * 32, g, key_limit, scale_log2e, min_limit);
     load_k<D>(ka, krow, min(t + 2, tl) * 32, li, g);
     load_v<D>(va, vblk(min(t + 2, tl)), li, g);
     if (t + 1 < t1) {
-      attn_tile<D, NQ>(acc, kb, vb, qf, (t + 1) * 32, g, key_limit, scale_log2e);
+      attn_tile<D, NQ>(acc, kb, vb, qf, (t + 1) * 32, g, key_limit, scale_log2e, min_limit);
       load_k<D>(kb, krow, min(t + 3, tl) * 32, li, g);
       load_v<D>(vb, vblk(min(t + 3, tl)), li, g);
     }
@@ -347,8 +378,8 @@ LCC_DEVICE void wait_two_tiles_in_flight(int pw) {   // pw = DMA instructions pe
 
 __device__ unsigned int lcc_attn_zero_page[256];
 
-template <int D, int NQ, int MODE>
-__global__ __launch_bounds__(512) void attn_shared_kernel(
+template <int D, int NQ, int MODE, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
     const int32_t* __restrict__ t0a, const int32_t* __restrict__ t1a, const int32_t* __restrict__ t2a,
     const int32_t* __restrict__ t3a, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
@@ -356,9 +387,9 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
     int heads, int total_blocks, float scale_log2e, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
   constexpr int KS = (D + 31) / 32, KP = 2 * KS, VP = D / 16, NP = KP + VP, NSTAGE = 4;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int nwave = NWAVE, pw = (NP + NWAVE - 1) / NWAVE;   // DMA instructions per wave per tile
   const int li = lane & 15, g = lane >> 4;
-  const int pw = (NP + nwave - 1) / nwave;
   const int grp = blockIdx.x;
 
   // ---- what this block streams (K rows, V^T blocks, number of keys) and what this wave computes
@@ -413,20 +444,38 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
   }
 
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn_zero_page) + lane * 8;
+  // Per-lane source pointers of this wave's pieces for key tile 0 and their per-tile strides are computed ONCE: a DMA issue is
+  // then one 64-bit multiply-add per piece.  (The first version recomputed piece -> (row, chunk) -> address in a runtime
+  // loop for every tile: ~200 of the ~300 VALU instructions per tile, on a kernel the SQ counters show VALU-issue bound.)
+  // Keys past `nkeys` in the last tile: the KV cache (MODE 1) is allocated in whole 32-key tiles, so the rows exist and are
+  // masked; the ViT qkv buffer (MODE 0) is not, so its last tile clamps the row index.
+  const bf16_t* pbase[pw];
+  size_t pstride[pw];
+  int pkey0[pw], pd0[pw];
+#pragma unroll
+  for (int j = 0; j < pw; ++j) {
+    const int p = min(j * nwave + wave, NP - 1);   // surplus slots re-fetch the last piece (same bytes, same place)
+    if (p < KP) {
+      const int kt = p / KS, ks = p - kt * KS;
+      pkey0[j] = (li >> 2) * 8 + kt * 4 + (li & 3);
+      pd0[j] = ks * 32 + g * 8;
+      pbase[j] = (pd0[j] < D) ? kbase + (size_t)pkey0[j] * kstride + pd0[j] : zp;
+      pstride[j] = (pd0[j] < D) ? (size_t)32 * kstride : 0;
+    } else {
+      pkey0[j] = -1; pd0[j] = 0;
+      pbase[j] = vbase + ((p - KP) * 16 + li) * 32 + g * 8;
+      pstride[j] = (size_t)D * 32;
+    }
+  }
   auto issue = [&](int t) {
     const int tc = min(t, ntile - 1);
     u32x4* sbase = alds + ((t - tb) % NSTAGE) * (NP * 64);
+#pragma unroll
     for (int j = 0; j < pw; ++j) {
-      const int p = min(j * nwave + wave, NP - 1);   // surplus slots re-fetch the last piece (same bytes, same place)
-      const bf16_t* src;
-      if (p < KP) {
-        const int kt = p / KS, ks = p - kt * KS;
-        const int key = min(tc * 32 + (li >> 2) * 8 + kt * 4 + (li & 3), nkeys - 1);
-        const int d0 = ks * 32 + g * 8;
-        src = (d0 < D) ? kbase + (size_t)key * kstride + d0 : zp;
-      } else {
-        src = vbase + (size_t)tc * (D * 32) + ((p - KP) * 16 + li) * 32 + g * 8;
-      }
+      const int p = min(j * nwave + wave, NP - 1);
+      const bf16_t* src = pbase[j] + (size_t)tc * pstride[j];
+      if (MODE == 0 && tc == ntile - 1 && pkey0[j] >= 0 && pd0[j] < D)
+        src = kbase + (size_t)min(tc * 32 + pkey0[j], nkeys - 1) * kstride + pd0[j];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
     }
@@ -434,6 +483,8 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
 
   AttnAcc<D, NQ> acc;
   acc.init();
+  int min_limit[NQ];
+  wave_min_limits<NQ>(key_limit, min_limit);
   issue(tb); issue(tb + 1); issue(tb + 2);
   for (int t = tb; t < te; ++t) {
     wait_two_tiles_in_flight(pw);
@@ -449,7 +500,7 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(
         for (int ks = 0; ks < KS; ++ks) kf.v[kt][ks] = s[(kt * KS + ks) * 64 + lane];
 #pragma unroll
       for (int dt = 0; dt < VP; ++dt) vf[dt] = s[(KP + dt) * 64 + lane];
-      attn_tile<D, NQ>(acc, kf, vf, qf, t * 32, g, key_limit, scale_log2e);
+      attn_tile<D, NQ>(acc, kf, vf, qf, t * 32, g, key_limit, scale_log2e, min_limit);
     }
   }
   if (!active) return;
@@ -736,7 +787,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 #pragma unroll
       for (int dt = 0; dt < D / 16; ++dt) vf[dt] = (g == 0) ? (u32x4){(unsigned)vnew[dt * 16 + li], 0u, 0u, 0u} : z;
       const int one[NQ] = {1};
-      attn_tile<D, NQ>(acc, kf, vf, qf, 0, g, one, scale_log2e);
+      attn_tile<D, NQ>(acc, kf, vf, qf, 0, g, one, scale_log2e, one);
     }
     __syncthreads();          // staging area is reused by the merge below
   }
@@ -850,8 +901,8 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
   if (g_attn_variant == 2 && n_groups > 0) {
     constexpr size_t lds = (size_t)4 * (6 + 5) * 1024;
     static bool once = false;
-    if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0>, lds); once = true; }
-    attn_shared_kernel<80, 2, 0><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
+    if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0, 4>, lds); once = true; }
+    attn_shared_kernel<80, 2, 0, 4><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
         qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
         heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
     return 0;
@@ -876,16 +927,22 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
   // 2-3 waves for the dependent MFMA->softmax->MFMA chain).  g_attn_variant 0 forces the per-wave kernel.
   if (g_attn_variant != 0 && G >= 2 && G <= 8) {
     constexpr size_t lds = (size_t)4 * 16 * 1024;
-    static bool once = false;
-    if (!once) { set_lds_attr(attn_shared_kernel<128, 1, 1>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1>, lds); once = true; }
-    if (tile_rows == 32)
-      attn_shared_kernel<128, 2, 1><<<dim3(n_tiles, lay.n_kv_heads, S), dim3(G * 64), lds, st>>>(
-          q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0,
-          scale_l2e(128), S, ws_o, ws_ml);
-    else
-      attn_shared_kernel<128, 1, 1><<<dim3(n_tiles, lay.n_kv_heads, S), dim3(G * 64), lds, st>>>(
-          q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0,
-          scale_l2e(128), S, ws_o, ws_ml);
+    const dim3 grid(n_tiles, lay.n_kv_heads, S);
+#define LCC_ATTN_SH(GW)                                                                                                          \
+  case GW: {                                                                                                                     \
+    static bool once = false;                                                                                                    \
+    if (!once) { set_lds_attr(attn_shared_kernel<128, 1, 1, GW>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1, GW>, lds); once = true; } \
+    if (tile_rows == 32)                                                                                                         \
+      attn_shared_kernel<128, 2, 1, GW><<<grid, dim3(GW * 64), lds, st>>>(q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, \
+                                                                          nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml); \
+    else                                                                                                                         \
+      attn_shared_kernel<128, 1, 1, GW><<<grid, dim3(GW * 64), lds, st>>>(q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, \
+                                                                          nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml); \
+  } break;
+    switch (G) {
+      LCC_ATTN_SH(2) LCC_ATTN_SH(3) LCC_ATTN_SH(4) LCC_ATTN_SH(5) LCC_ATTN_SH(6) LCC_ATTN_SH(7) LCC_ATTN_SH(8)
+    }
+#undef LCC_ATTN_SH
     if (S > 1) attn_prefill_combine_kernel<<<dim3(n_q_heads, n_rows), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads, S);
     return 0;
   }

@@ -67,8 +67,6 @@ class LiveCCDemoInfer:
         `clip`: uint8 frames [T,3,H,W] (or THWC).  Yields ((start, stop), text, state) per chunk.
         `message` / `default_query` (real-tokenizer mode): the user query, appended to the turn when it is new or changed
         (ref infer.py:141-146)."""
-        if do_sample:
-            raise NotImplementedError("pass do_sample=False (greedy); see modeling.generate")
         initialized = state.get("last_timestamp", -1.0) >= 0
         t0 = state.get("last_timestamp", -self.frame_time_interval) + self.frame_time_interval
         for a, b in protocol.split_clip(clip.shape[0], initialized):
@@ -95,7 +93,7 @@ class LiveCCDemoInfer:
                                                   streaming_eos_threshold_step or 0.0)]
             out = self.model.generate(
                 input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, frames_layout=frames_layout,
-                past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=False,
+                past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=do_sample,
                 repetition_penalty=repetition_penalty, logits_processor=procs, max_new_tokens=max_new_tokens,
                 min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id)
             seq = out.sequences[0].cpu().numpy()

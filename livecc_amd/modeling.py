@@ -92,6 +92,7 @@ class LiveCCForConditionalGeneration:
         self._free_slots = list(range(max_streams - 1, -1, -1))
         self.text_offset_rule = text_offset_rule
         self.prepare_inputs_for_generation = None   # assignable, as ref demo/infer.py:50 does
+        self.generation_config: dict = {}            # from_pretrained fills it from generation_config.json (do_sample / top_k ...)
 
     # ---- constructors ----
     @classmethod
@@ -104,7 +105,13 @@ class LiveCCForConditionalGeneration:
             raise RuntimeError("livecc_amd has no CPU path; use device_map='cuda[:i]' (the oracle under oracle/ is the CPU path)")
         cfg = get_config(model_path)
         arena = _arena_from_pretrained(model_path, cfg, device, llm_fp8=bool(kw.pop("llm_fp8", False)))
-        return cls(cfg, arena, device, **kw)
+        model = cls(cfg, arena, device, **kw)
+        import json
+        import os
+        gc = os.path.join(model_path, "generation_config.json")
+        if os.path.exists(gc):
+            model.generation_config = json.load(open(gc))
+        return model
 
     @classmethod
     def from_config(cls, cfg: LiveCCConfig, device="cuda", seed: int = 0, llm_fp8: bool = False, **kw):
@@ -156,8 +163,13 @@ class LiveCCForConditionalGeneration:
                  eos_token_id: Optional[int] = None, frames: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
                  output_logits: bool = False, output_scores: bool = False, attention_mask=None, **unused):
         if do_sample:
-            raise NotImplementedError("sampling is not implemented; the released generation_config (top_k=1) is greedy "
-                                      "up to ties, pass do_sample=False")
+            # The reference's live_cc defaults to do_sample=True (ref demo/infer.py:68) with the checkpoints' generation_config
+            # (top_k = 1): the top-k warper leaves ONE finite score, so multinomial sampling is the argmax -- served by the
+            # greedy sampler.  Any other sampling configuration is not implemented.
+            top_k = unused.get("top_k", self.generation_config.get("top_k"))
+            if top_k != 1:
+                raise NotImplementedError("sampling is only supported in its degenerate top_k=1 form (the released "
+                                          "generation_config); pass do_sample=False or top_k=1")
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).all()):
             raise NotImplementedError("padding masks are not supported (the reference passes none, infer.py:156)")
         if input_ids.dim() != 2 or input_ids.shape[0] != 1:

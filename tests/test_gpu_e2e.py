@@ -468,3 +468,25 @@ def test_mcq_prefill_only_scoring_matches_oracle(dev, tmp_path):
     margin = torch.topk(ref, 2).values
     if (margin[0] - margin[1]).item() > 2 * (lg - ref).abs().max().item():
         assert choice == int(torch.argmax(ref))
+
+
+def test_do_sample_with_top_k_1_is_the_greedy_path(dev, tiny_models):
+    """ref demo/infer.py:68 defaults to do_sample=True; with the released generation_config (top_k = 1) that is the argmax."""
+    from livecc_amd import protocol
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(2, 56, 84, seed=2, layout="TCHW"))
+    ids = protocol.TurnBuilder(cfg, seed=2).turn_ids(0, protocol.num_video_tokens(protocol.grid_of(2, 56, 84, cfg), cfg))
+    kw = dict(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, repetition_penalty=1.05, max_new_tokens=5, min_new_tokens=5)
+    a = native.generate(do_sample=False, **kw)
+    a.past_key_values.release()
+    with pytest.raises(NotImplementedError):
+        native.generate(do_sample=True, **kw)
+    b = native.generate(do_sample=True, top_k=1, **kw)
+    b.past_key_values.release()
+    native.generation_config = {"do_sample": True, "top_k": 1, "top_p": 0.001, "temperature": 0.01}
+    try:
+        c = native.generate(do_sample=True, **kw)
+        c.past_key_values.release()
+    finally:
+        native.generation_config = {}
+    assert torch.equal(a.sequences, b.sequences) and torch.equal(a.sequences, c.sequences)
