@@ -38,13 +38,19 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--fused-tails", type=int, default=None, choices=[0, 1],
                     help="debug A/B: fuse add+rmsnorm / rope+append into the decode GEMV tails (default: library default)")
+    ap.add_argument("--workload", choices=["stream60", "long480"], default="stream60",
+                    help="long480 = BASELINE.json configs[3]: one 480-frame 280x280 video (24k visual tokens), 12 tokens per turn, "
+                         "KV growing to ~32k; overrides --frames/--height/--width/--max-new-tokens")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: LLM Linear weights as OCP e4m3 + fp32 row scales (BASELINE.json configs[4], 72B on one GPU)")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock budget of the CPU baseline leg, seconds")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload == "long480":
+        a.frames, a.height, a.width, a.max_new_tokens = 480, 280, 280, 12
+    return a
 
 
 def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod):
@@ -226,7 +232,8 @@ def main():
         "dtype": "bf16 (fp8 e4m3 LLM weights, bf16 MFMA)" if fp8 else "bf16", "data": "synthetic frames + synthetic prompt ids, random weights of the real architecture",
         "config": {"workload": f"{cfg.name} single stream per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
                                f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05"
-                               + (" (BASELINE.json configs[1])" if cfg.name == "livecc-7b" and args.frames == 60 and spg == 1 and not fp8 else "")
+                               + (" (BASELINE.json configs[1])" if cfg.name == "livecc-7b" and args.frames == 60 and args.workload == "stream60" and spg == 1 and not fp8 else "")
+                               + (" (BASELINE.json configs[3]: 24k visual tokens, KV to ~32k)" if args.workload == "long480" and cfg.name == "livecc-7b" else "")
                                + (" (BASELINE.json configs[4])" if cfg.name == "qwen2vl-72b" and fp8 else ""),
                    "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)"},
         "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
