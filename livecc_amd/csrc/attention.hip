@@ -485,22 +485,29 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
   acc.init();
   int min_limit[NQ];
   wave_min_limits<NQ>(key_limit, min_limit);
-  issue(tb); issue(tb + 1); issue(tb + 2);
-  for (int t = tb; t < te; ++t) {
-    wait_two_tiles_in_flight(pw);
+  // Two key tiles per barrier: the ring's four stages form two pair-stages.  After the barrier of pair P (its DMAs have landed,
+  // every wave is done with pair P-1) the DMAs of pair P+1 are issued into the stages pair P-1 used and fly under the
+  // QK^T / softmax / PV of both tiles of pair P -- half the barriers and waits of the one-tile-per-barrier loop.
+  auto compute = [&](int t) {
+    const u32x4* s = alds + ((t - tb) % NSTAGE) * (NP * 64);
+    KFrag<D> kf;
+    u32x4 vf[VP];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf.v[kt][ks] = s[(kt * KS + ks) * 64 + lane];
+#pragma unroll
+    for (int dt = 0; dt < VP; ++dt) vf[dt] = s[(KP + dt) * 64 + lane];
+    attn_tile<D, NQ>(acc, kf, vf, qf, t * 32, g, key_limit, scale_log2e, min_limit);
+  };
+  issue(tb); issue(tb + 1);
+  for (int t = tb; t < te; t += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(t + 3);
+    issue(t + 2); issue(t + 3);
     if (active) {
-      const u32x4* s = alds + ((t - tb) % NSTAGE) * (NP * 64);
-      KFrag<D> kf;
-      u32x4 vf[VP];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf.v[kt][ks] = s[(kt * KS + ks) * 64 + lane];
-#pragma unroll
-      for (int dt = 0; dt < VP; ++dt) vf[dt] = s[(KP + dt) * 64 + lane];
-      attn_tile<D, NQ>(acc, kf, vf, qf, t * 32, g, key_limit, scale_log2e, min_limit);
+      compute(t);
+      if (t + 1 < te) compute(t + 1);
     }
   }
   if (!active) return;
@@ -884,9 +891,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
-// 0: per-wave kernels everywhere (operands straight from L2);  1 (default): prefill = LDS-shared kernel + key split, ViT =
-// per-wave kernel (measured 64 vs 75 us: one head per block has nothing to share but query tiles);  2: LDS-shared for both.
-static int g_attn_variant = 1;
+// 0: per-wave kernels everywhere (operands straight from L2);  1: prefill = LDS-shared kernel + key split, ViT = per-wave
+// kernel;  2 (default): LDS-shared for both.  (With the per-tile DMA address math hoisted out of the key loop the shared ViT
+// kernel went from 75 us -- slower than the 64-us per-wave kernel -- to on par for one stream and +1.7 % end to end at 8.)
+static int g_attn_variant = 2;
 void set_attn_variant(int v) { g_attn_variant = v; }
 
 template <class Kern>

@@ -3,14 +3,14 @@
 // W keeps the nn.Linear layout [N,K] (K contiguous) so that both MFMA operands are read as 8 contiguous
 // bf16 (16 bytes) per lane.  fp32 accumulation, one rounding to bf16 at the points where HF rounds.
 //
-//  * gemm_tiled_kernel   : M >= 17 (ViT, merger, LLM prefill).  MFMA-bound.  BMx128x64 block tile,
-//                          4 waves (2x2), register-staged double-buffered LDS with an XOR swizzle,
-//                          v_mfma_f32_16x16x32_bf16, XCD-aware block remap so that the blocks that share a
-//                          W panel run on one XCD (one L2).
-//  * gemv_skinny_kernel  : M <= 16 (decode, lm_head).  HBM-bound weight streaming.  One wave per block,
-//                          16 (or 32) W rows x a K slice per wave, W fragments loaded straight from HBM into
-//                          the MFMA operand registers (no LDS round trip - the operand is used once), split-K
-//                          partial sums as fp32 slabs that the consumer kernel reduces.
+//  * gemm_big_kernel     : M >= 17, packed W, K % 64 == 0 (LLM prefill, ViT).  MFMA-bound.  8 waves, BM x 256 x 64 tile
+//                          (BM 256 / 128), LDS-DMA for both operands, optional fp8-e4m3 W converted after the LDS read.
+//  * gemm_glds_kernel /   : shapes with few 256-column tiles, row-major W, K % 64 != 0.  64x128x64 (128x128x64) tile, 4 waves,
+//    gemm_tiled_kernel     LDS-DMA 3-stage ring / register-staged double buffer with an XOR swizzle, XCD-aware block remap.
+//  * gemv_skinny_kernel  : M <= 16 (decode, lm_head).  HBM-bound weight streaming.  4 waves per block share 16 (or 32) W rows,
+//                          each wave a slice of K; W fragments go straight from HBM into the MFMA operand registers (no LDS
+//                          round trip - the operand is used once), split-K partial sums as fp32 slabs that the consumer reduces.
+//  * gemv_w8_kernel      : the same for fp8-e4m3 weights + fp32 row scales (PACKED8 order), e4m3 -> bf16 exactly in registers.
 //
 // Replaces: every nn.Linear / Conv3d of HF modeling_qwen2_vl.py on the path
 //   (PatchEmbed 251-274, VisionAttention.qkv/proj 349-350, VisionMlp 293-301, PatchMerger 277-290,

@@ -37,8 +37,9 @@ def analyse(src):
 
 def demangle(names):
     try:
-        p = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
-        return p.stdout.splitlines()
+        p = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
+        out = p.stdout.splitlines()
+        return out if len(out) == len(names) else names
     except OSError:
         return names
 
