@@ -123,8 +123,9 @@ def cpu_baseline(cfg_name, args, budget_s=240.0):
     toks = [e for e in ev if e["event"] == "token"]
     done = next((e for e in ev if e["event"] == "done"), None)
     n = args.max_new_tokens
-    base = dict(unit="tokens/s/stream", cores=info.get("cores", os.cpu_count()), kind="reference", cpu=info.get("cpu", ""),
-                build_seconds=built["seconds"] if built else None)
+    # `cores` = the threads the baseline actually used (torch's intra-op pool), not the logical CPU count of the box
+    base = dict(unit="tokens/s/stream", cores=info.get("threads", info.get("cores", os.cpu_count())), logical_cpus=info.get("cores"),
+                kind="reference", cpu=info.get("cpu", ""), build_seconds=built["seconds"] if built else None)
     what = (f"HF transformers CPU path (bf16, sdpa, {info.get('threads', '?')} threads) at {cfg_name} shapes: one streaming turn = "
             f"ViT on 2 frames ({inputs.get('patches', '?')} patches) + {inputs.get('prompt_tokens', '?')}-token prefill + {n} greedy tokens")
     if done is not None:
