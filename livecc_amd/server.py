@@ -108,6 +108,7 @@ class StreamServer:
         """Wall-clock time at which the stream's next chunk becomes due (None when the stream has ended)."""
         st = self.streams[sid]
         if st.ended or st.last_timestamp + protocol.FRAME_TIME_INTERVAL > st.pts[-1]:
+            st.ended = True
             return None
         if st.last_timestamp < 0:
             return st.t_start

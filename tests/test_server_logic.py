@@ -1,0 +1,95 @@
+"""Scheduler logic of the multi-stream loop (livecc_amd/server.py) on the CPU with a stand-in model: the reference's pacing rule
+(first 6-frame chunk at once, then one 2-frame chunk whenever the stream's video clock passes the chunk's first frame), one
+batched generate per step, catch-up vs drop back-pressure, end of stream."""
+import numpy as np
+import pytest
+import torch
+
+from livecc_amd import protocol, server
+from livecc_amd.config import tiny
+
+
+class _KV:
+    def release(self):
+        pass
+
+
+class FakeModel:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.engine = type("E", (), {"max_slots": 4})()
+        self.batches = []
+
+    def generate_batch(self, reqs, **kw):
+        self.batches.append(len(reqs))
+        outs = []
+        for r in reqs:
+            seq = torch.cat([r["input_ids"].view(-1), torch.tensor([7, 8, 9])]).view(1, -1)
+            outs.append(type("O", (), {"sequences": seq, "past_key_values": r["state"] or _KV()})())
+        return outs
+
+
+class FakeInfer:
+    def __init__(self):
+        self.cfg = tiny()
+        self.model = FakeModel(self.cfg)
+        self.text = None
+        self.turn_builder = protocol.TurnBuilder(self.cfg)
+        self.streaming_eos_token_id = None
+        self.decode = lambda ids: " ".join(str(i) for i in ids)
+
+
+@pytest.fixture()
+def srv(monkeypatch):
+    def fake_clip(frames, h, w, ts, pts, index_from, layout="THWC"):
+        from livecc_amd import resize as R
+        idxs, kept = R.select_clip_frames(ts, pts, index_from)
+        return (torch.zeros(len(idxs), 3, h, w, dtype=torch.uint8) if idxs else None), kept, idxs
+    monkeypatch.setattr(server.R, "get_smart_resized_clip", fake_clip)
+    return server.StreamServer(FakeInfer(), max_new_tokens=3)
+
+
+def _video(n):
+    return torch.zeros(n, 60, 90, 3, dtype=torch.uint8), np.arange(n) / 30.0
+
+
+def test_pacing_batching_and_end(srv):
+    srv.add_stream("a", *_video(180), t_start=0.0, max_pixels=4 * 28 * 28)      # 6 s
+    srv.add_stream("b", *_video(180), t_start=0.0, max_pixels=4 * 28 * 28)
+    srv.add_stream("c", *_video(120), t_start=2.0, max_pixels=4 * 28 * 28)      # starts later, 4 s long
+    r = srv.step(0.0)
+    assert sorted(x[0] for x in r) == ["a", "b"] and all(x[1] == (0.0, 3.0) for x in r) and srv.model.batches == [2]
+    r = srv.step(2.9)                                                    # c started at wall 2.0: its first chunk is taken at once
+    assert [x[0] for x in r] == ["c"] and r[0][1] == (0.0, 3.0)
+    # at wall 3.2: a and b have passed video time 3.0 -> their (3.0, 4.0) chunks run in ONE batch
+    r = srv.step(3.2)
+    assert sorted(x[0] for x in r) == ["a", "b"] and all(x[1] == (3.0, 4.0) for x in r) and srv.model.batches[-1] == 2
+    assert srv.step(3.3) == []
+    assert srv.due_time("a") == pytest.approx(4.0, abs=1e-3) and srv.due_time("c") == pytest.approx(2.0 + 3.0, abs=1e-3)
+    out = srv.run(realtime=False)
+    spans = {}
+    for sid, span, text, state in out:
+        spans.setdefault(sid, []).append(span)
+    assert spans["a"] == [(4.0, 5.0), (5.0, 6.0)] and spans["c"] == [(3.0, 4.0)]
+    assert all(st.ended for st in srv.streams.values())
+    assert "7 8" in out[0][2]                                           # decoded text of the generated ids (minus the dropped last)
+
+
+def test_catch_up_and_drop(srv):
+    srv.add_stream("x", *_video(600), t_start=0.0, max_pixels=4 * 28 * 28)      # 20 s
+    assert srv.step(0.0)[0][1] == (0.0, 3.0)
+    # a stalled consumer under the reference's policy: one pending chunk per step until it has caught up
+    got = [srv.step(8.2)[0][1] for _ in range(3)]
+    assert got == [(3.0, 4.0), (4.0, 5.0), (5.0, 6.0)]
+    drop = server.StreamServer(FakeInfer(), max_new_tokens=3, lag_policy="drop", max_lag_s=2.0)
+    drop.add_stream("y", *_video(600), t_start=0.0, max_pixels=4 * 28 * 28)
+    assert drop.step(0.0)[0][1] == (0.0, 3.0)
+    sid, span, _, st = drop.step(10.3)[0]
+    assert span == (10.0, 11.0) and st["dropped_s"] == 7.0
+    with pytest.raises(ValueError):
+        server.StreamServer(FakeInfer(), lag_policy="nope")
+    full = server.StreamServer(FakeInfer())
+    for i in range(4):
+        full.add_stream(i, *_video(60))
+    with pytest.raises(RuntimeError):
+        full.add_stream(9, *_video(60))
