@@ -170,11 +170,22 @@ def _run_stream_tiny(cfg, hf16, hf32, native, use_pixel_values, fused_tails, tok
     assert toks == prev, "fused-tail / pixel_values variants must generate identical tokens (bit-identical arithmetic)"
 
 
-def test_interleaved_streams_are_independent(dev, tiny_models):
+@pytest.mark.parametrize("fused_attn_mode", [1, 5])
+def test_interleaved_streams_are_independent(dev, tiny_models, fused_attn_mode):
     """Two streams advanced alternately (per-stream rope_delta / KV / seen bitmap) give the same tokens as each alone --
-    the reference cannot do this: HF keeps rope_deltas on the module (modeling_qwen2_vl.py:857)."""
-    from livecc_amd import protocol
+    the reference cannot do this: HF keeps rope_deltas on the module (modeling_qwen2_vl.py:857).  Mode 5 runs every decode
+    step (alone and batched) through the fused rope + append + attention kernel that multi-stream batches use."""
+    from livecc_amd import _lib, protocol
     cfg, hf16, hf32, native = tiny_models
+    _lib.load().lcc_debug_set_fused_attn(fused_attn_mode)
+    try:
+        _interleaved_body(cfg, native)
+    finally:
+        _lib.load().lcc_debug_set_fused_attn(1)
+
+
+def _interleaved_body(cfg, native):
+    from livecc_amd import protocol
     fa = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=1, layout="TCHW"))
     fb = torch.from_numpy(protocol.synth_frames(8, 84, 56, seed=2, layout="TCHW"))
     alone_a = _replay_native(native, cfg, fa, protocol.TurnBuilder(cfg, seed=11), 6, 1.05, 2)

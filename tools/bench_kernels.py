@@ -162,9 +162,31 @@ def main_attn():
                                   nsplit=ns_sep if variant == 0 else ns_fused, us_per_layer=round(us.value, 2))), flush=True)
 
 
+def main_resize():
+    """Antialias bicubic uint8 resize (8f-1): decoder-order frames -> model resolution, algorithmic bytes = src + dst."""
+    from livecc_amd import resize as R
+    dev = torch.device("cuda:0")
+    for T, hi, wi, ho, wo in [(2, 1080, 1920, 392, 728), (6, 1080, 1920, 392, 728), (2, 720, 1280, 392, 700), (480, 360, 640, 280, 504)]:
+        x = torch.randint(0, 256, (T, hi, wi, 3), dtype=torch.uint8, device=dev)
+        R.resize_bicubic_aa(x, ho, wo, "THWC")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            R.resize_bicubic_aa(x, ho, wo, "THWC")
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        alg = T * 3 * (hi * wi + ho * wo)
+        print(json.dumps(dict(kernel="resize_bicubic_aa_u8", T=T, src=[hi, wi], dst=[ho, wo], us=round(us, 1),
+                              algorithmic_GBps=round(alg / us / 1e3, 1), frames_per_s=round(T / us * 1e6))), flush=True)
+
+
 def main():
     if "--gemm" in sys.argv:
         return main_gemm()
+    if "--resize" in sys.argv:
+        return main_resize()
     if "--attn" in sys.argv:
         return main_attn()
     if "--mall" in sys.argv:
