@@ -72,17 +72,34 @@ LCC_DEVICE float block_sum(float v, float* red) {
   return t;
 }
 
-// activations, with HF's bf16 rounding points (inputs are already-rounded bf16 values held in fp32)
+// activations, with HF's bf16 rounding points (inputs are already-rounded bf16 values held in fp32).
+// exp and the reciprocal use the hardware units (v_exp_f32, v_rcp_f32) with the error terms folded back in:
+//   exp(t): t*log2(e) split into hi + lo (FMA residual), exp2(hi) * (1 + lo*ln2)      -> ~1 ulp of fp32
+//   1/d   : v_rcp_f32 + one Newton step                                              -> ~0.5 ulp of fp32
+// i.e. 10 VALU instructions instead of ~30 for libm expf + IEEE division; the fp32 result is then rounded to bf16 (2^-9
+// relative), so it differs from the correctly rounded activation in ~5e-5 of the elements by one bf16 ulp -- two orders of
+// magnitude below the effect of the fp32 summation order of the GEMM that feeds it.  (The epilogue was 9 % of the SwiGLU
+// gate/up GEMM and ~25 % of the ViT fc1 GEMM.)
+LCC_DEVICE float exp_fast(float t) {
+  const float L2E_HI = 1.4426950216293335f, L2E_LO = 1.9259629911266175e-8f;   // log2(e) = hi + lo
+  const float hi = t * L2E_HI;
+  const float lo = fmaf(t, L2E_HI, -hi) + t * L2E_LO;
+  return __builtin_amdgcn_exp2f(hi) * fmaf(lo, 0.6931471805599453f, 1.0f);
+}
+LCC_DEVICE float rcp_fast(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
 // quick_gelu: HF activations.py QuickGELUActivation: input * sigmoid(1.702 * input) on bf16 tensors
 LCC_DEVICE float quick_gelu_bf16(float x) {
   float t = rbf(1.702f * x);
-  float s = rbf(1.0f / (1.0f + expf(-t)));
+  float s = rbf(rcp_fast(1.0f + exp_fast(-t)));
   return rbf(x * s);
 }
 // exact (erf) GELU: torch gelu on bf16 computes in fp32 and rounds once
 LCC_DEVICE float gelu_erf_bf16(float x) { return rbf(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f))); }
 // silu on bf16: x / (1 + exp(-x)) in fp32, rounded once
-LCC_DEVICE float silu_bf16(float x) { return rbf(x / (1.0f + expf(-x))); }
+LCC_DEVICE float silu_bf16(float x) { return rbf(x * rcp_fast(1.0f + exp_fast(-x))); }
 
 enum Epilogue : int {
   EPI_NONE = 0,        // C = bf16(acc + bias)
