@@ -501,3 +501,49 @@ def test_do_sample_with_top_k_1_is_the_greedy_path(dev, tiny_models):
     finally:
         native.generation_config = {}
     assert torch.equal(a.sequences, b.sequences) and torch.equal(a.sequences, c.sequences)
+
+
+def test_reference_entry_point_from_a_checkpoint_directory(dev, tmp_path):
+    """The reference's own construction path (ref demo/infer.py:35-59): `LiveCCDemoInfer(model_path=<dir>)` with config.json,
+    sharded safetensors, tokenizer files and generation_config.json (do_sample / top_k = 1) -- then `live_cc` with its default
+    do_sample=True.  Must give the tokens of the same weights loaded through `from_hf_model` with greedy decoding."""
+    import dataclasses
+    import json
+    from safetensors.torch import save_file
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.infer import LiveCCDemoInfer
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.text import TextFrontEnd
+    from oracle import hf_oracle as O
+    from tests.test_text import make_tokenizer_dir
+    d = tmp_path / "LiveCC-tiny"
+    d.mkdir()
+    tk = TextFrontEnd(make_tokenizer_dir(d)).tokenizer
+    cfg = dataclasses.replace(tiny(), video_token_id=tk.convert_tokens_to_ids("<|video_pad|>"), eos_token_id=tk.convert_tokens_to_ids("<|im_end|>"),
+                              image_token_id=tk.convert_tokens_to_ids("<|image_pad|>"),
+                              vision_start_token_id=tk.convert_tokens_to_ids("<|vision_start|>"),
+                              vision_end_token_id=tk.convert_tokens_to_ids("<|vision_end|>"),
+                              bos_token_id=tk.convert_tokens_to_ids("<|endoftext|>"))
+    hf = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=6, init_scale=2.0)
+    sd = {k: v.contiguous() for k, v in hf.state_dict().items()}
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[::2]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in keys[1::2]}, str(d / "model-00002-of-00002.safetensors"))
+    (d / "config.json").write_text(json.dumps(cfg.to_hf().to_dict(), default=str))
+    (d / "generation_config.json").write_text(json.dumps({"do_sample": True, "top_k": 1, "top_p": 0.001, "temperature": 0.01}))
+    infer = LiveCCDemoInfer(model_path=str(d), device=str(dev))
+    assert infer.text is not None and infer.model.generation_config["top_k"] == 1 and infer.cfg.video_token_id == cfg.video_token_id
+    frames = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=3, layout="TCHW"))
+    state, texts = {}, []
+    for _, text, state in infer.live_cc(frames, state, message="what is happening now?", do_sample=True, max_new_tokens=5, force_length=True):
+        texts.append(text)
+    ids_a = state["past_ids"].tolist()
+    state["past_key_values"].release()
+    ref = LiveCCDemoInfer(model=LiveCCForConditionalGeneration.from_hf_model(hf, cfg, dev, max_streams=1, max_kv_len=2048, max_new_rows=1024,
+                                                                              max_patches=4096, max_history=16), text=TextFrontEnd(tk, cfg))
+    state2 = {}
+    for _, text, state2 in ref.live_cc(frames, state2, message="what is happening now?", do_sample=False, max_new_tokens=5, force_length=True):
+        pass
+    assert ids_a == state2["past_ids"].tolist() and len(texts) == 2
+    state2["past_key_values"].release()
