@@ -62,7 +62,7 @@ class LiveCCDemoInfer:
     def live_cc(self, clip: torch.Tensor, state: dict, frames_layout: str = "TCHW", do_sample: bool = False,
                 repetition_penalty: float = 1.05, streaming_eos_base_threshold: float = None,
                 streaming_eos_threshold_step: float = None, max_new_tokens: int = 16, force_length: bool = False,
-                message: Optional[str] = None, default_query: str = "Please describe the video."):
+                message: Optional[str] = None, default_query: str = "Please describe the video.", hf_spaces: bool = False):
         """One call = the frames that became due since the last call (ref infer.py:61-180, steps 4-5).
         `clip`: uint8 frames [T,3,H,W] (or THWC).  Yields ((start, stop), text, state) per chunk.
         `message` / `default_query` (real-tokenizer mode): the user query, appended to the turn when it is new or changed
@@ -102,7 +102,11 @@ class LiveCCDemoInfer:
             state["turn_index"] = turn + 1
             state["last_timestamp"] = stop - self.frame_time_interval
             new_tokens = seq[len(ids):].tolist()
-            yield (start, stop), self.decode([t for t in new_tokens if t != self.cfg.eos_token_id]), state
+            text_out = self.decode([t for t in new_tokens if t != self.cfg.eos_token_id])
+            if hf_spaces:   # ref infer.py:176-178: the caller gets a light copy without the device-side state
+                yield (start, stop), text_out, {k: v for k, v in state.items() if k not in ("past_ids", "past_key_values")}
+            else:
+                yield (start, stop), text_out, state
 
     @torch.inference_mode()
     def live_cc_from_video(self, video_frames: torch.Tensor, video_pts, state: dict, video_timestamp: float,
