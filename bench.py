@@ -43,6 +43,7 @@ def parse():
                          "KV growing to ~32k; overrides --frames/--height/--width/--max-new-tokens")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: LLM Linear weights as OCP e4m3 + fp32 row scales (BASELINE.json configs[4], 72B on one GPU)")
+    ap.add_argument("--gemv-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemv_variant")
     ap.add_argument("--attn-variant", type=int, default=None, help="debug A/B: lcc_debug_set_attn_variant")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
@@ -172,6 +173,9 @@ def main():
     if args.attn_variant is not None:
         from livecc_amd import ops
         ops.set_attn_variant(args.attn_variant)
+    if args.gemv_variant is not None:
+        from livecc_amd import ops
+        ops.set_gemv_variant(args.gemv_variant)
     model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
                                            max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
                                            max_history=max(16, args.max_new_tokens))

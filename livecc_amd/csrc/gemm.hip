@@ -16,6 +16,7 @@
 //   (PatchEmbed 251-274, VisionAttention.qkv/proj 349-350, VisionMlp 293-301, PatchMerger 277-290,
 //    Qwen2VLAttention q/k/v/o_proj 501-504, Qwen2MLP 453-466, lm_head 1218/1323).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -960,9 +961,12 @@ int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st) {
 // number of inter-block K splits of a skinny GEMV: enough blocks (x4 waves) to keep >= ~16 waves per CU in flight,
 // every wave keeps >= ~3 64-element chunks, and the fp32 slab traffic stays small (S <= 8)
 int gemv_num_splits(int N, int K) {
+  // tuning knobs (debug): LCC_GEMV_TARGET = blocks aimed at (default 1024), LCC_GEMV_MINCHUNK = 64-k chunks per split at least (12)
+  static const int target = [] { const char* e = getenv("LCC_GEMV_TARGET"); return e ? std::max(64, atoi(e)) : 1024; }();
+  static const int minchunk = [] { const char* e = getenv("LCC_GEMV_MINCHUNK"); return e ? std::max(1, atoi(e)) : 12; }();
   const int tiles = (N + 15) / 16, nchunk = (K + 63) / 64;
-  int s = (1024 + tiles - 1) / tiles;
-  s = std::min(s, std::max(1, nchunk / 12));
+  int s = (target + tiles - 1) / tiles;
+  s = std::min(s, std::max(1, nchunk / minchunk));
   return std::max(1, std::min(8, s));
 }
 
