@@ -83,8 +83,9 @@ int lcc_patchify_norm_u8(const uint8_t* frames, int layout, int T, int H, int W,
  * torchvision.transforms.functional.resize(uint8 clip, [Hout, Wout], BICUBIC, antialias=True), i.e. ATen's float32 separable
  * antialias bicubic (width pass, then height pass, taps accumulated in order with FMAs), clamp to [0,255], round half to even.
  * src: uint8 frames, layout 0 = [T,Hin,Win,3], 1 = [T,3,Hin,Win]; dst: uint8 [T,3,Hout,Wout].  Tap tables per output index
- * (first source index, tap count, fp32 weights [out][k]) are computed by the caller with ATen's arithmetic
- * (livecc_amd/resize.py:aa_bicubic_taps); tmp = T*3*Hin*Wout floats.  Bit-identical to the reference's CPU result. */
+ * (first source index, tap count, fp32 weights) are computed by the caller with ATen's arithmetic
+ * (livecc_amd/resize.py:aa_bicubic_taps): wx is TAP-MAJOR [kx][Wout] (coalesced across the lanes of the width pass), wy is
+ * [Hout][ky]; tmp = T*3*Hin*Wout floats.  Bit-identical to the reference's CPU result. */
 int lcc_resize_bicubic_aa_u8(const uint8_t* src, int layout, int T, int Hin, int Win, uint8_t* dst, int Hout, int Wout,
                              const int32_t* xmin, const int32_t* xsize, const float* wx, int kx, const int32_t* ymin,
                              const int32_t* ysize, const float* wy, int ky, float* tmp, void* stream);

@@ -541,23 +541,43 @@ int swiglu_bf16(const bf16_t* g, const bf16_t* u, bf16_t* out, int64_t n, hipStr
 __global__ __launch_bounds__(256) void resize_aa_h_kernel(const uint8_t* __restrict__ src, int layout, int T, int Hin, int Win,
                                                           int Wout, const int32_t* __restrict__ xmin, const int32_t* __restrict__ xsize,
                                                           const float* __restrict__ wx, int kx, float* __restrict__ tmp) {
-  const size_t total = (size_t)T * 3 * Hin * Wout;
+  // one thread = one output column of one source row, all three colour channels: the taps are loaded once for the three
+  // channels, and the tap table is TAP-MAJOR ([kx][Wout]) so that the lanes of a wave (consecutive xo) read consecutive floats
+  const size_t total = (size_t)T * Hin * Wout;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int xo = (int)(i % Wout);
-  size_t r = i / Wout;
-  const int y = (int)(r % Hin); r /= Hin;
-  const int c = (int)(r % 3);
-  const int t = (int)(r / 3);
+  const size_t r = i / Wout;
+  const int y = (int)(r % Hin);
+  const int t = (int)(r / Hin);
   const int x0 = xmin[xo], n = xsize[xo];
-  const float* w = wx + (size_t)xo * kx;
-  const uint8_t* p;
-  size_t stride;
-  if (layout == 0) { p = src + (((size_t)t * Hin + y) * Win + x0) * 3 + c; stride = 3; }          // THWC
-  else { p = src + (((size_t)t * 3 + c) * Hin + y) * Win + x0; stride = 1; }                      // TCHW
-  float acc = __fmul_rn((float)p[0], w[0]);
-  for (int j = 1; j < n; ++j) acc = fmaf((float)p[(size_t)j * stride], w[j], acc);
-  tmp[i] = acc;                                                                                    // [T][3][Hin][Wout]
+  const float* w = wx + xo;
+  const size_t plane = (size_t)Hin * Wout;
+  float* o = tmp + ((size_t)t * 3 * Hin + y) * Wout + xo;                                          // [T][3][Hin][Wout]
+  if (layout == 0) {                                                                                // THWC: 3 adjacent bytes per pixel
+    const uint8_t* p = src + (((size_t)t * Hin + y) * Win + x0) * 3;
+    const float w0 = w[0];
+    float a0 = __fmul_rn((float)p[0], w0), a1 = __fmul_rn((float)p[1], w0), a2 = __fmul_rn((float)p[2], w0);
+    for (int j = 1; j < n; ++j) {
+      const float wj = w[(size_t)j * Wout];
+      a0 = fmaf((float)p[j * 3], wj, a0);
+      a1 = fmaf((float)p[j * 3 + 1], wj, a1);
+      a2 = fmaf((float)p[j * 3 + 2], wj, a2);
+    }
+    o[0] = a0; o[plane] = a1; o[2 * plane] = a2;
+  } else {                                                                                          // TCHW
+    const uint8_t* p = src + ((size_t)t * 3 * Hin + y) * Win + x0;
+    const size_t cp = (size_t)Hin * Win;
+    const float w0 = w[0];
+    float a0 = __fmul_rn((float)p[0], w0), a1 = __fmul_rn((float)p[cp], w0), a2 = __fmul_rn((float)p[2 * cp], w0);
+    for (int j = 1; j < n; ++j) {
+      const float wj = w[(size_t)j * Wout];
+      a0 = fmaf((float)p[j], wj, a0);
+      a1 = fmaf((float)p[cp + j], wj, a1);
+      a2 = fmaf((float)p[2 * cp + j], wj, a2);
+    }
+    o[0] = a0; o[plane] = a1; o[2 * plane] = a2;
+  }
 }
 
 __global__ __launch_bounds__(256) void resize_aa_v_kernel(const float* __restrict__ tmp, int T, int Hin, int Hout, int Wout,
@@ -583,7 +603,7 @@ int resize_bicubic_aa_u8(const uint8_t* src, int layout, int T, int Hin, int Win
                          const int32_t* xmin, const int32_t* xsize, const float* wx, int kx, const int32_t* ymin,
                          const int32_t* ysize, const float* wy, int ky, float* tmp, hipStream_t st) {
   if (T <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || kx <= 0 || ky <= 0 || (layout != 0 && layout != 1)) return LCC_ERR_SHAPE;
-  const size_t n1 = (size_t)T * 3 * Hin * Wout, n2 = (size_t)T * 3 * Hout * Wout;
+  const size_t n1 = (size_t)T * Hin * Wout, n2 = (size_t)T * 3 * Hout * Wout;
   resize_aa_h_kernel<<<dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st>>>(src, layout, T, Hin, Win, Wout, xmin, xsize, wx, kx, tmp);
   resize_aa_v_kernel<<<dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st>>>(tmp, T, Hin, Hout, Wout, ymin, ysize, wy, ky, dst);
   return 0;

@@ -118,12 +118,13 @@ def aa_bicubic_taps(in_size: int, out_size: int):
 _TAPS_CACHE = {}
 
 
-def _taps_on(device, in_size, out_size):
-    key = (str(device), in_size, out_size)
+def _taps_on(device, in_size, out_size, tap_major=False):
+    """tap_major: weights as [K][out] (the width pass reads them coalesced across output columns), else [out][K]."""
+    key = (str(device), in_size, out_size, tap_major)
     if key not in _TAPS_CACHE:
         xmin, xsize, W = aa_bicubic_taps(in_size, out_size)
-        _TAPS_CACHE[key] = (torch.from_numpy(xmin).to(device), torch.from_numpy(xsize).to(device),
-                            torch.from_numpy(np.ascontiguousarray(W)).to(device), W.shape[1])
+        Wd = np.ascontiguousarray(W.T if tap_major else W)
+        _TAPS_CACHE[key] = (torch.from_numpy(xmin).to(device), torch.from_numpy(xsize).to(device), torch.from_numpy(Wd).to(device), W.shape[1])
     return _TAPS_CACHE[key]
 
 
@@ -143,7 +144,7 @@ def resize_bicubic_aa(frames: torch.Tensor, height: int, width: int, layout: str
     if C != 3:
         raise ValueError("3 channels expected")
     dev = frames.device
-    xmin, xsize, wx, kx = _taps_on(dev, Win, width)
+    xmin, xsize, wx, kx = _taps_on(dev, Win, width, tap_major=True)
     ymin, ysize, wy, ky = _taps_on(dev, Hin, height)
     out = torch.empty(T, 3, height, width, dtype=torch.uint8, device=dev)
     tmp = torch.empty(T * 3 * Hin * width, dtype=torch.float32, device=dev)

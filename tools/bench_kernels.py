@@ -166,7 +166,7 @@ def main_resize():
     """Antialias bicubic uint8 resize (8f-1): decoder-order frames -> model resolution, algorithmic bytes = src + dst."""
     from livecc_amd import resize as R
     dev = torch.device("cuda:0")
-    for T, hi, wi, ho, wo in [(2, 1080, 1920, 392, 728), (6, 1080, 1920, 392, 728), (2, 720, 1280, 392, 700), (480, 360, 640, 280, 504)]:
+    for T, hi, wi, ho, wo in [(2, 1080, 1920, 392, 728), (6, 1080, 1920, 392, 728), (32, 1080, 1920, 392, 728), (2, 720, 1280, 392, 700), (480, 360, 640, 280, 504)]:
         x = torch.randint(0, 256, (T, hi, wi, 3), dtype=torch.uint8, device=dev)
         R.resize_bicubic_aa(x, ho, wo, "THWC")
         torch.cuda.synchronize()
