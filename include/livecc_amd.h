@@ -51,12 +51,16 @@ int lcc_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
  * w_layout 0: W row-major [N,K] (nn.Linear);  1: W pre-packed in MFMA fragment order [N/16][ceil(K/32)][4][16][8]
  * (element (n,k) at ((n/16*ceil(K/32) + k/32)*4 + (k%32)/8)*128 + (n%16)*8 + k%8, K zero-padded to 32): every wave load
  * of the weight-streaming path is then one contiguous KB.  The engine stores all Linear weights packed.
- * M<=16 takes the HBM-bound skinny path; `partial` (fp32 [nsplit][M][N], skinny path only) returns raw split-K slabs. */
+ * M<=16 takes the HBM-bound skinny path; `partial` (fp32 [nsplit][M][N]) returns raw split-K slabs instead of C (both paths;
+ * epilogue must be NONE, nsplit <= 8). */
 int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual, int ldr,
                   void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream);
 /* tuning knob of the skinny kernel (0: 2 chunks single stage, 1: 1-chunk two-stage pipeline, 2: 2-chunk two-stage) */
 int lcc_debug_set_gemv_variant(int variant);
-/* tiled kernel: 0 = register-staged double-buffered LDS, 1 = LDS-DMA (global_load_lds) 3-stage ring, 2 = per tile shape (default) */
+/* tiled kernels: 0 = 4-wave register-staged double-buffered LDS, 1 = 4-wave LDS-DMA (global_load_lds) 3-stage ring, 2 = scored per
+ * shape (default: 8-wave 256x256 / 128x256 LDS-DMA kernel where its grid fills the chip, else the 4-wave kernels), 3 / 4 = force the
+ * 8-wave kernel with 256 / 128 rows where eligible, 5 / 6 = the same with the compiler's fragment-read schedule, 7 = 2 without the
+ * 8-wave kernel */
 int lcc_debug_set_gemm_variant(int variant);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 (default) = prefill shares K/V tiles through an LDS-DMA ring,
  * ViT per-wave; 2 = LDS-shared for both */
