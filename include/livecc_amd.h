@@ -62,11 +62,11 @@ int lcc_debug_set_gemv_variant(int variant);
  * 8-wave kernel with 256 / 128 rows where eligible, 5 / 6 = the same with the compiler's fragment-read schedule, 7 = 2 without the
  * 8-wave kernel */
 int lcc_debug_set_gemm_variant(int variant);
-/* attention: 0 = per-wave kernels (operands straight from L2); 1 (default) = prefill shares K/V tiles through an LDS-DMA ring,
- * ViT per-wave; 2 = LDS-shared for both */
+/* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
+ * ViT per-wave; 2 (default) = LDS-shared for both */
 int lcc_debug_set_attn_variant(int variant);
-/* 1 (default): on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add +
- * RMSNorm) run as the TAIL of that GEMV in its last-arriving block (agent-scope release/acquire), 0: separate kernels */
+/* 1: on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add + RMSNorm) run as the
+ * TAIL of that GEMV in its last-arriving block (agent-scope release/acquire); 0 (default, measured faster): separate kernels */
 int lcc_debug_set_fused_tails(int on);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
@@ -154,12 +154,26 @@ int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode use
 int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
                           const void* vit_rows, void* out, int S, int dim, void* stream);             /* Q2VL:1159-1176 */
 int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, void* stream);
-/* RepetitionPenalty -> ThresholdLogitsProcessor -> argmax  (HF:generation/logits_process.py, ref:demo/infer.py:10-23) */
+/* RepetitionPenalty -> ThresholdLogitsProcessor -> argmax  (HF:generation/logits_process.py, ref:demo/infer.py:10-23).
+ * eos_token / eos_token2: the (up to two) EOS ids of generation_config.json (<|im_end|>, <|endoftext|>; -1 = unused): both are
+ * masked while suppress_eos (MinNewTokensLength) and either one sets the slot's done flag. */
 int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                       const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
-                      int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
+                      int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
                       int32_t* hist_col, float* scores_out, float* ws /* optional scratch B*256 floats: two-stage path */,
                       void* stream);
+/* do_sample=True (ref:demo/infer.py:68 default of live_cc; HF:generation/utils.py:1296-1318, 2920-2925): the processors above,
+ * then TemperatureLogitsWarper (scores / temperature), TopKLogitsWarper (top_k 0 = off; keeps scores >= the k-th largest),
+ * TopPLogitsWarper (top_p 1 = off; removes the ascending tail whose cumulative softmax mass is <= 1 - top_p, the largest score
+ * is always kept), softmax, one multinomial draw per stream.  scores_out (optional, fp32 [B,V]) receives the processed scores
+ * HF would hand to softmax (-inf where removed).  Randomness: Philox4x32-10 keyed by `seed`, counter = (rng_ctr[slot]++, slot):
+ * a per-slot draw counter in device memory (uint32 [n_slots], zero for a fresh stream) -- reproducible for a given seed,
+ * independent of batching.  Deterministic: no floating-point atomics (masses are accumulated as 2^40-scaled integers). */
+int lcc_sample_topk_topp(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
+                         const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
+                         int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history,
+                         int hist_ld, int32_t* hist_col, float* scores_out, float temperature, int top_k, float top_p,
+                         uint64_t seed, uint32_t* rng_ctr, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Model level -- what `model.generate(**inputs, past_key_values=...)` (ref:demo/infer.py:165-172) executes:
@@ -226,6 +240,12 @@ typedef struct {
   int suppress_eos;          /* 1 = MinNewTokensLength active for the whole call (min_new_tokens == max_new_tokens) */
   float* scores_out;         /* optional device fp32 [n_streams, V] of processed scores of the LAST step */
   void* logits_out;          /* optional device bf16 [steps, n_streams, V] raw logits of every step (parity tests) */
+  int eos_token2;            /* second EOS id of generation_config.json (<|endoftext|>) or -1 */
+  int do_sample;             /* 0: argmax (lcc_sample_greedy); 1: lcc_sample_topk_topp with the fields below */
+  float temperature;         /* > 0 */
+  int top_k;                 /* 0 = off */
+  float top_p;               /* (0, 1]; 1 = off */
+  uint64_t seed;             /* Philox key; the per-slot draw counters live in the engine state (reset by lcc_slot_reset) */
 } lcc_sampling;
 
 /* Prefill of n_streams streams: host arrays are copied through the engine's pinned meta ring.

@@ -44,7 +44,8 @@ class Clip(C.Structure):
 class Sampling(C.Structure):
     _fields_ = [("repetition_penalty", C.c_float), ("thr_token", C.c_int), ("use_thr", C.c_int),
                 ("thr_base", C.c_float), ("thr_step", C.c_float), ("eos_token", C.c_int), ("suppress_eos", C.c_int),
-                ("scores_out", C.c_void_p), ("logits_out", C.c_void_p)]
+                ("scores_out", C.c_void_p), ("logits_out", C.c_void_p), ("eos_token2", C.c_int), ("do_sample", C.c_int),
+                ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float), ("seed", C.c_uint64)]
 
 
 def declared_symbols() -> List[str]:
@@ -111,8 +112,10 @@ def load():
                                             C.POINTER(f32), vp]),
         "lcc_embed_gather_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "lcc_seen_set": (i32, [vp, i32, vp, vp, i32, vp]),
-        "lcc_sample_greedy": (i32, [vp, i32, i32, i32, vp, i32, vp, f32, i32, i32, f32, i32, i32, vp, vp, vp, i32, vp,
+        "lcc_sample_greedy": (i32, [vp, i32, i32, i32, vp, i32, vp, f32, i32, i32, f32, i32, i32, i32, vp, vp, vp, i32, vp,
                                     vp, vp, vp]),
+        "lcc_sample_topk_topp": (i32, [vp, i32, i32, i32, vp, i32, vp, f32, i32, i32, f32, i32, i32, i32, vp, vp, vp, i32, vp,
+                                       vp, f32, i32, f32, C.c_uint64, vp, vp]),
         "lcc_engine_create": (vp, [C.POINTER(ModelConfig), C.POINTER(EngineLimits)]),
         "lcc_engine_destroy": (None, [vp]),
         "lcc_engine_workspace_bytes": (sz, [vp]),

@@ -123,6 +123,7 @@ struct lcc_engine {
   int32_t* d_counter = nullptr;   // arrival counter of the fused GEMV tails (zero between launches)
   int32_t* d_attn_cnt = nullptr;  // [16 streams x Hkv] arrival counters of the fused decode attention (zero between launches)
   uint32_t* d_seen = nullptr;
+  uint32_t* d_rng_ctr = nullptr;  // per-slot Philox draw counter of the sampling kernel (zero for a fresh stream)
   bf16_t** d_kv_base = nullptr;
   // optional live timing of the dominant kernel (decode gate/up GEMV): hipEvent pairs on the launch stream
   std::vector<hipEvent_t> prof_ev;   // 2 * capacity
@@ -216,7 +217,7 @@ extern "C" int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, 
 extern "C" size_t lcc_engine_workspace_bytes(const lcc_engine* e) { return std::max(e->llm_ws_bytes(), e->vit_ws_bytes()); }
 extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
   const size_t B = e->lim.max_slots;
-  return align_up(B * 4) * 5 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096 + 1024;
+  return align_up(B * 4) * 6 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096 + 1024;
 }
 extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->lay.total() * 2; }
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
@@ -240,7 +241,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
   const size_t B = e->lim.max_slots;
   Carver cv; cv.base = e->state;
   e->d_kv_len = cv.take<int32_t>(B); e->d_pos = cv.take<int32_t>(B); e->d_hist_col = cv.take<int32_t>(B);
-  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_attn_cnt = cv.take<int32_t>(256); e->d_kv_base = cv.take<bf16_t*>(B);
+  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_rng_ctr = cv.take<uint32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_attn_cnt = cv.take<int32_t>(256); e->d_kv_base = cv.take<bf16_t*>(B);
   e->d_history = cv.take<int32_t>(B * (size_t)e->lim.max_history);
   e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
   HIP_TRY(hipMemset(e->state, 0, state_bytes));
@@ -356,6 +357,7 @@ extern "C" int lcc_slot_reset(lcc_engine* e, int slot, void* stream) {
   HIP_TRY(hipMemsetAsync(e->d_pos + slot, 0, 4, st));
   HIP_TRY(hipMemsetAsync(e->d_hist_col + slot, 0, 4, st));
   HIP_TRY(hipMemsetAsync(e->d_done + slot, 0, 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_rng_ctr + slot, 0, 4, st));
   HIP_TRY(hipMemsetAsync(e->d_seen + (size_t)slot * e->words, 0, (size_t)e->words * 4, st));
   return 0;
 }
@@ -639,8 +641,16 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   const int thr_tok = sp ? sp->thr_token : -1;
   const int use_thr = sp ? sp->use_thr : 0;
   const float thr = sp ? sp->thr_base + sp->thr_step * (float)step_index : 0.f;
+  const int eos2 = sp ? sp->eos_token2 : -1;
+  if (sp && sp->do_sample && sp->top_k != 1) {
+    LCC_TRY(sample_topk_topp(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr, sp->eos_token,
+                             eos2, sp->suppress_eos, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col,
+                             sp->scores_out, sp->temperature, sp->top_k, sp->top_p, sp->seed, e->d_rng_ctr, st));
+    return 0;
+  }
+  // top_k == 1 (the released generation_config): the top-k warper leaves one finite score -> the draw IS the argmax
   LCC_TRY(sample_greedy(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr,
-                        sp ? sp->eos_token : -1, sp ? sp->suppress_eos : 0, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
+                        sp ? sp->eos_token : -1, eos2, sp ? sp->suppress_eos : 0, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
                         e->d_hist_col, sp ? sp->scores_out : nullptr, b.ws_ml, st));
   return 0;
 }
@@ -981,11 +991,21 @@ extern "C" int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t*
   OP_RET(seen_set(seen, words_per_stream, ids, slot_of_id, n, 0, nullptr, (hipStream_t)stream), "lcc_seen_set");
 }
 extern "C" int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream, const int32_t* stream_slot,
-                                 float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token,
+                                 float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token, int eos_token2,
                                  int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
                                  int32_t* hist_col, float* scores_out, float* ws, void* stream) {
   if (!logits || !seen || !stream_slot || !out_tokens || (history && !hist_col)) return fail(LCC_ERR_ARG, "null pointer");
   OP_RET(sample_greedy((const bf16_t*)logits, ld, B, V, seen, words_per_stream, stream_slot, repetition_penalty, thr_token, use_thr,
-                       thr_value, eos_token, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out, ws, (hipStream_t)stream),
-         "lcc_sample_greedy");
+                       thr_value, eos_token, eos_token2, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out, ws,
+                       (hipStream_t)stream), "lcc_sample_greedy");
+}
+extern "C" int lcc_sample_topk_topp(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
+                                    const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
+                                    int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens,
+                                    int32_t* history, int hist_ld, int32_t* hist_col, float* scores_out, float temperature, int top_k,
+                                    float top_p, uint64_t seed, uint32_t* rng_ctr, void* stream) {
+  if (!logits || !seen || !stream_slot || !out_tokens || (history && !hist_col)) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(sample_topk_topp((const bf16_t*)logits, ld, B, V, seen, words_per_stream, stream_slot, repetition_penalty, thr_token, use_thr,
+                          thr_value, eos_token, eos_token2, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out,
+                          temperature, top_k, top_p, seed, rng_ctr, (hipStream_t)stream), "lcc_sample_topk_topp");
 }

@@ -106,8 +106,13 @@ int seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int
              const int32_t* done, hipStream_t st);
 int sample_greedy(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                   const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
-                  int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
+                  int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
                   int32_t* hist_col, float* scores_out, float* ws, hipStream_t st);
+// do_sample: temperature -> top-k -> top-p -> multinomial (Philox stream per slot); top_k 0 = off, top_p 1 = off
+int sample_topk_topp(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream, const int32_t* stream_slot,
+                     float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token, int eos_token2,
+                     int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld, int32_t* hist_col,
+                     float* scores_out, float temperature, int top_k, float top_p, uint64_t seed, uint32_t* rng_ctr, hipStream_t st);
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st);
 
 }  // namespace lcc

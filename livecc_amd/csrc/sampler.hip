@@ -43,7 +43,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void sample_greedy_kernel(
     const bf16_t* __restrict__ logits, int ld, int V, uint32_t* __restrict__ seen, int words,
     const int32_t* __restrict__ stream_slot, float penalty, int thr_token, int use_thr, float thr_value,
-    int eos_token, int suppress_eos, int32_t* __restrict__ done,
+    int eos_token, int eos_token2, int suppress_eos, int32_t* __restrict__ done,
     int32_t* __restrict__ out_tokens, int32_t* __restrict__ history, int hist_ld, int32_t* __restrict__ hist_col,
     float* __restrict__ scores_out) {
   __shared__ float s_max[NT / 64], s_sum[NT / 64], s_bv[NT / 64];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void sample_greedy_kernel(
     for (int e = 0; e < 8; ++e) {
       if (penalty != 1.0f && ((bits >> e) & 1u)) v[e] = v[e] < 0.f ? v[e] * penalty : v[e] / penalty;
       const int id = c * 8 + e;
-      if (suppress_eos && id == eos_token) v[e] = -INFINITY;  // MinNewTokensLengthLogitsProcessor
+      if (suppress_eos && (id == eos_token || id == eos_token2)) v[e] = -INFINITY;  // MinNewTokensLengthLogitsProcessor
       if (so) so[id] = v[e];
       // online max / exp-sum over ALL scores (softmax denominator of the threshold processor)
       if (v[e] > mx) { sum = sum * __expf(mx - v[e]) + 1.f; mx = v[e]; }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void sample_greedy_kernel(
       if (col < hist_ld) history[(size_t)slot * hist_ld + col] = tok;
       hist_col[slot] = col + 1;
     }
-    if (done != nullptr && tok == eos_token) done[slot] = 1;
+    if (done != nullptr && (tok == eos_token || tok == eos_token2)) done[slot] = 1;
   }
 }
 
@@ -124,7 +124,7 @@ constexpr int SAMPLE_NB = 32;
 
 __global__ __launch_bounds__(256) void sample_partial_kernel(
     const bf16_t* __restrict__ logits, int ld, int V, const uint32_t* __restrict__ seen, int words,
-    const int32_t* __restrict__ stream_slot, float penalty, int thr_token, int eos_token, int suppress_eos,
+    const int32_t* __restrict__ stream_slot, float penalty, int thr_token, int eos_token, int eos_token2, int suppress_eos,
     const int32_t* __restrict__ done, float* __restrict__ part, float* __restrict__ scores_out) {
   __shared__ float s_max[4], s_sum[4], s_bv[4], s_thr[4];
   __shared__ int s_bi[4];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(
     for (int e = 0; e < 8; ++e) {
       if (penalty != 1.0f && ((bits >> e) & 1u)) v[e] = v[e] < 0.f ? v[e] * penalty : v[e] / penalty;
       const int id = c * 8 + e;
-      if (suppress_eos && id == eos_token) v[e] = -INFINITY;
+      if (suppress_eos && (id == eos_token || id == eos_token2)) v[e] = -INFINITY;
       if (so) so[id] = v[e];
       if (v[e] > mx) { sum = sum * __expf(mx - v[e]) + 1.f; mx = v[e]; }
       else sum += __expf(v[e] - mx);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(
 
 __global__ __launch_bounds__(64) void sample_final_kernel(
     const float* __restrict__ part, int V, const int32_t* __restrict__ stream_slot, int thr_token, int use_thr, float thr_value,
-    int eos_token, int32_t* __restrict__ done, int32_t* __restrict__ out_tokens, int32_t* __restrict__ history, int hist_ld,
+    int eos_token, int eos_token2, int32_t* __restrict__ done, int32_t* __restrict__ out_tokens, int32_t* __restrict__ history, int hist_ld,
     int32_t* __restrict__ hist_col, float* __restrict__ scores_out) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int slot = stream_slot[b];
@@ -214,25 +214,311 @@ __global__ __launch_bounds__(64) void sample_final_kernel(
     if (col < hist_ld) history[(size_t)slot * hist_ld + col] = tok;
     hist_col[slot] = col + 1;
   }
-  if (done != nullptr && tok == eos_token) done[slot] = 1;
+  if (done != nullptr && (tok == eos_token || tok == eos_token2)) done[slot] = 1;
 }
 
 int sample_greedy(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                   const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
-                  int eos_token, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
+                  int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
                   int32_t* hist_col, float* scores_out, float* ws, hipStream_t st) {
   if (B <= 0) return 0;
   if ((V & 31) || (ld & 7) || words_per_stream * 32 < V) return LCC_ERR_SHAPE;
   if (ws != nullptr && V >= 8192) {   // ws: B * 32 * 8 floats of scratch
     sample_partial_kernel<<<dim3(SAMPLE_NB, B), dim3(256), 0, st>>>(logits, ld, V, seen, words_per_stream, stream_slot, repetition_penalty,
-                                                                   thr_token, eos_token, suppress_eos, done, ws, scores_out);
-    sample_final_kernel<<<dim3(B), dim3(64), 0, st>>>(ws, V, stream_slot, thr_token, use_thr, thr_value, eos_token, done, out_tokens,
+                                                                   thr_token, eos_token, eos_token2, suppress_eos, done, ws, scores_out);
+    sample_final_kernel<<<dim3(B), dim3(64), 0, st>>>(ws, V, stream_slot, thr_token, use_thr, thr_value, eos_token, eos_token2, done, out_tokens,
                                                       history, hist_ld, hist_col, scores_out);
     return 0;
   }
   sample_greedy_kernel<1024><<<dim3(B), dim3(1024), 0, st>>>(logits, ld, V, seen, words_per_stream, stream_slot,
-                                                             repetition_penalty, thr_token, use_thr, thr_value, eos_token,
+                                                             repetition_penalty, thr_token, use_thr, thr_value, eos_token, eos_token2,
                                                              suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// General sampling (do_sample=True with top_k != 1): HF's order (generation/utils.py:1171-1330, 2894-2925)
+//   repetition penalty -> min-new-tokens EOS mask -> custom processors (ThresholdLogitsProcessor) ->
+//   TemperatureLogitsWarper (scores / T) -> TopKLogitsWarper (keep scores >= k-th largest) ->
+//   TopPLogitsWarper (ascending cumulative softmax mass <= 1 - top_p removed, the largest always kept) ->
+//   softmax -> multinomial.
+// One block of 1024 threads per stream, no sort and no atomics: the k-th largest score and the top-p cut are found by
+// radix-16 descents over the order-preserving integer key of the fp32 score (8 passes of per-thread REGISTER histograms +
+// a block reduction each).  Probability masses are accumulated as 2^40-scaled integers, so every sum is independent of the
+// summation order: the same seed gives the same tokens on every run.  The draw is an inverse-CDF walk over a fixed
+// (thread-major) order of the vocabulary with one Philox4x32-10 uniform per (seed, slot, draw counter).
+// The processed score of id i is recomputed from the bf16 logits + the seen bitmap in every pass (cheaper than an fp32
+// scratch row: 304 KB of L2-resident logits per pass).
+LCC_DEVICE uint32_t order_key(float x) {   // monotone: x < y  <=>  key(x) < key(y)   (-inf lowest; NaN not expected)
+  const uint32_t b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+LCC_DEVICE void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+LCC_DEVICE unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
+struct SampleParams {
+  const bf16_t* logits; int ld, V; const uint32_t* seen; int words; const int32_t* stream_slot;
+  float penalty; int thr_token, use_thr; float thr_value; int eos_token, eos_token2, suppress_eos;
+  int32_t* done; int32_t* out_tokens; int32_t* history; int hist_ld; int32_t* hist_col; float* scores_out;
+  float temperature; int top_k; float top_p; uint32_t seed_lo, seed_hi; uint32_t* rng_ctr;
+};
+
+constexpr int SNT = 1024;                       // threads per block
+constexpr double MASS_SCALE = 1099511627776.0;  // 2^40
+
+__global__ __launch_bounds__(SNT) void sample_topk_topp_kernel(SampleParams P) {
+  __shared__ float s_f[SNT / 64][3];
+  __shared__ unsigned long long s_hist[16][SNT];   // 128 KB: per-thread radix-16 histograms (the block may use all 160 KB of LDS)
+  __shared__ unsigned long long s_tot[16];
+  __shared__ unsigned long long s_scan[SNT / 64];
+  __shared__ uint32_t s_u[4];
+  __shared__ unsigned long long s_ull[2];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = P.stream_slot[b];
+  if (P.done != nullptr && P.done[slot]) return;
+  const bf16_t* lg = P.logits + (size_t)b * P.ld;
+  const uint32_t* sb = P.seen + (size_t)slot * P.words;
+  const int V = P.V, nch = V / 8;
+  const float penalty = P.penalty;
+  const int eos1 = P.suppress_eos ? P.eos_token : -1, eos2 = P.suppress_eos ? P.eos_token2 : -1;
+
+  // processed scores BEFORE the warpers of the 8 ids of chunk c (penalty, EOS mask; `thr_dead` = threshold processor fired)
+  auto load8 = [&](int c, int thr_dead, float (&v)[8]) {
+    const u32x4 q = ld16(lg + c * 8);
+    const uint32_t bits = (sb[c >> 2] >> ((c & 3) * 8)) & 0xffu;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = lo2f(q[e]); v[2 * e + 1] = hi2f(q[e]); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (penalty != 1.0f && ((bits >> e) & 1u)) v[e] = v[e] < 0.f ? v[e] * penalty : v[e] / penalty;
+      const int id = c * 8 + e;
+      if (id == eos1 || id == eos2 || id == thr_dead) v[e] = -INFINITY;
+    }
+  };
+
+  // ---- pass A: max / exp-sum of the processed scores (ThresholdLogitsProcessor's softmax), score of its token ----
+  float mx = -INFINITY, sum = 0.f, thr_score = -INFINITY;
+  for (int c = tid; c < nch; c += SNT) {
+    float v[8];
+    load8(c, -1, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (v[e] > mx) { sum = sum * expf(mx - v[e]) + 1.f; mx = v[e]; }
+      else if (v[e] != -INFINITY) sum += expf(v[e] - mx);
+      if (c * 8 + e == P.thr_token) thr_score = v[e];
+    }
+  }
+  {
+    const float wmx = wave_max(mx);
+    sum *= (mx == -INFINITY) ? 0.f : expf(mx - wmx);
+    sum = wave_sum(sum);
+    thr_score = wave_max(thr_score);
+    if (lane == 0) { s_f[wave][0] = wmx; s_f[wave][1] = sum; s_f[wave][2] = thr_score; }
+    __syncthreads();
+    if (tid == 0) {
+      float M = -INFINITY, tot = 0.f, ts = -INFINITY;
+      for (int w = 0; w < SNT / 64; ++w) M = fmaxf(M, s_f[w][0]);
+      for (int w = 0; w < SNT / 64; ++w) { tot += (s_f[w][0] == -INFINITY) ? 0.f : s_f[w][1] * expf(s_f[w][0] - M); ts = fmaxf(ts, s_f[w][2]); }
+      int dead = -1;
+      if (P.thr_token >= 0 && P.use_thr && (expf(ts - M) / tot) <= P.thr_value) dead = P.thr_token;
+      s_u[0] = (uint32_t)dead;
+    }
+    __syncthreads();
+  }
+  const int thr_dead = (int)s_u[0];
+  const float invT_is_one = (P.temperature == 1.0f) ? 1.f : 0.f;
+  auto warp_t = [&](float v) { return invT_is_one != 0.f ? v : v / P.temperature; };   // TemperatureLogitsWarper: scores / T
+
+  // ---- maximum of the tempered scores (softmax shift; the top element is always kept) ----
+  float xm = -INFINITY;
+  for (int c = tid; c < nch; c += SNT) {
+    float v[8];
+    load8(c, thr_dead, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xm = fmaxf(xm, warp_t(v[e]));
+  }
+  xm = wave_max(xm);
+  __syncthreads();
+  if (lane == 0) s_f[wave][0] = xm;
+  __syncthreads();
+  xm = -INFINITY;
+  for (int w = 0; w < SNT / 64; ++w) xm = fmaxf(xm, s_f[w][0]);
+  auto mass_of = [&](float x) -> unsigned long long {   // 2^40-scaled softmax numerator, exact integer accumulation
+    return x == -INFINITY ? 0ull : (unsigned long long)((double)expf(x - xm) * MASS_SCALE);
+  };
+
+  // radix-16 descent.  from_top: the key t with  weight(keys > t) < target <= weight(keys >= t)   (k-th largest, weights 1)
+  //                    else    : the smallest key t with  weight(keys <= t) > target               (top-p cut, weights = mass)
+  // Only keys >= key_floor take part.  Returns t; *below = weight strictly below/above t on the walked side.
+  auto descend = [&](bool from_top, bool use_mass, unsigned long long target, uint32_t key_floor) -> uint32_t {
+    uint32_t prefix = 0, mask = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 28 - 4 * pass;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_hist[i][tid] = 0;          // this thread's private column: bank = tid, no conflicts, no atomics
+      for (int c = tid; c < nch; c += SNT) {
+        float v[8];
+        load8(c, thr_dead, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = warp_t(v[e]);
+          const uint32_t key = order_key(x);
+          if ((key & mask) != prefix || key < key_floor) continue;
+          s_hist[(key >> shift) & 15u][tid] += use_mass ? mass_of(x) : 1ull;
+        }
+      }
+      __syncthreads();
+      {   // wave w owns bin w (16 waves, 16 bins): 16 columns per lane, then a wave reduction
+        unsigned long long t = 0;
+#pragma unroll
+        for (int j = 0; j < SNT / 64; ++j) t += s_hist[wave][lane + 64 * j];
+        t = wave_sum_u64(t);
+        if (lane == 0) s_tot[wave] = t;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned long long* tot = s_tot;
+        int chosen = -1;
+        unsigned long long cum = 0;
+        if (from_top) {
+          for (int i = 15; i >= 0; --i) { if (cum + tot[i] >= target) { chosen = i; break; } cum += tot[i]; }
+          if (chosen < 0) { chosen = 0; cum -= tot[0]; }            // fewer eligible elements than k: keep everything
+        } else {
+          for (int i = 0; i < 16; ++i) { if (cum + tot[i] > target) { chosen = i; break; } cum += tot[i]; }
+          if (chosen < 0) { for (int i = 15; i >= 0; --i) if (tot[i]) { chosen = i; break; } if (chosen < 0) chosen = 15; cum = target; }
+        }
+        s_u[1] = (uint32_t)chosen;
+        s_ull[0] = target - cum;
+      }
+      __syncthreads();
+      prefix |= s_u[1] << shift;
+      mask |= 15u << shift;
+      target = s_ull[0];
+    }
+    return prefix;
+  };
+
+  uint32_t key_floor = 0;                                   // keys below it are removed by the warpers
+  if (P.top_k > 0 && P.top_k < V) key_floor = descend(true, false, (unsigned long long)P.top_k, 0u);
+  if (P.top_p < 1.0f) {
+    // total mass of what top-k kept
+    unsigned long long z = 0;
+    for (int c = tid; c < nch; c += SNT) {
+      float v[8];
+      load8(c, thr_dead, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float x = warp_t(v[e]); if (order_key(x) >= key_floor) z += mass_of(x); }
+    }
+    z = wave_sum_u64(z);
+    __syncthreads();
+    if (lane == 0) s_scan[wave] = z;
+    __syncthreads();
+    z = 0;
+    for (int w = 0; w < SNT / 64; ++w) z += s_scan[w];
+    // remove while ascending cumulative probability <= 1 - top_p  (TopPLogitsWarper), i.e. mass <= (1 - top_p) * Z
+    const unsigned long long cut = (unsigned long long)((double)(1.0f - P.top_p) * (double)z);
+    const uint32_t kp = descend(false, true, cut, key_floor);
+    key_floor = kp > key_floor ? kp : key_floor;
+    const uint32_t kmax = order_key(xm);
+    if (key_floor > kmax) key_floor = kmax;                 // min_tokens_to_keep = 1
+  }
+
+  // ---- final pass: masses of the kept set in thread-major order, processed scores out, inverse-CDF draw ----
+  float* so = P.scores_out ? P.scores_out + (size_t)b * V : nullptr;
+  unsigned long long mine = 0;
+  for (int c = tid; c < nch; c += SNT) {
+    float v[8];
+    load8(c, thr_dead, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = warp_t(v[e]);
+      const bool keep = order_key(x) >= key_floor;
+      if (so) so[c * 8 + e] = keep ? x : -INFINITY;
+      if (keep) mine += mass_of(x);
+    }
+  }
+  // exclusive scan over threads: waves first (shuffles), then the 16 wave totals
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t lo = __shfl_up((uint32_t)incl, o, 64), hi = __shfl_up((uint32_t)(incl >> 32), o, 64);
+    if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
+  }
+  __syncthreads();
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0, total = 0;
+  for (int w = 0; w < SNT / 64; ++w) { if (w < wave) base += s_scan[w]; total += s_scan[w]; }
+  if (tid == 0) {
+    const uint32_t ctr = P.rng_ctr ? P.rng_ctr[slot] : 0u;
+    if (P.rng_ctr) P.rng_ctr[slot] = ctr + 1u;
+    uint32_t c4[4] = {ctr, (uint32_t)slot, 0u, 0u};
+    philox4x32_10(c4, P.seed_lo, P.seed_hi);
+    const double u = (double)((((unsigned long long)c4[0] << 32) | c4[1]) >> 11) * (1.0 / 9007199254740992.0);   // [0,1), 53 bits
+    unsigned long long t = (unsigned long long)(u * (double)total);
+    if (t >= total) t = total ? total - 1 : 0;
+    s_ull[1] = t;
+    s_u[2] = 0xffffffffu;
+  }
+  __syncthreads();
+  const unsigned long long tgt = s_ull[1];
+  const unsigned long long lo_excl = base + incl - mine;
+  if (mine > 0 && tgt >= lo_excl && tgt < lo_excl + mine) {   // exactly one thread owns the target
+    unsigned long long cum = lo_excl;
+    int tok = -1;
+    for (int c = tid; c < nch && tok < 0; c += SNT) {
+      float v[8];
+      load8(c, thr_dead, v);
+      for (int e = 0; e < 8; ++e) {
+        const float x = warp_t(v[e]);
+        if (order_key(x) < key_floor) continue;
+        cum += mass_of(x);
+        if (cum > tgt) { tok = c * 8 + e; break; }
+      }
+    }
+    s_u[2] = (uint32_t)tok;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tok = (int)s_u[2];
+    if (tok < 0) tok = 0;                       // unreachable for finite scores; keeps the state machine defined
+    P.out_tokens[slot] = tok;
+    if (P.history != nullptr) {
+      const int col = P.hist_col[slot];
+      if (col < P.hist_ld) P.history[(size_t)slot * P.hist_ld + col] = tok;
+      P.hist_col[slot] = col + 1;
+    }
+    if (P.done != nullptr && (tok == P.eos_token || tok == P.eos_token2)) P.done[slot] = 1;
+  }
+}
+
+int sample_topk_topp(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream, const int32_t* stream_slot,
+                     float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token, int eos_token2,
+                     int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld, int32_t* hist_col,
+                     float* scores_out, float temperature, int top_k, float top_p, uint64_t seed, uint32_t* rng_ctr, hipStream_t st) {
+  if (B <= 0) return 0;
+  if ((V & 31) || (ld & 7) || words_per_stream * 32 < V) return LCC_ERR_SHAPE;
+  if (!(temperature > 0.f) || top_k < 0 || !(top_p > 0.f) || top_p > 1.f) return LCC_ERR_ARG;
+  SampleParams P{logits, ld, V, seen, words_per_stream, stream_slot, repetition_penalty, thr_token, use_thr, thr_value, eos_token,
+                 eos_token2, suppress_eos, done, out_tokens, history, hist_ld, hist_col, scores_out, temperature, top_k, top_p,
+                 (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), rng_ctr};
+  sample_topk_topp_kernel<<<dim3(B), dim3(SNT), 0, st>>>(P);
   return 0;
 }
 

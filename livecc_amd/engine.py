@@ -46,9 +46,11 @@ def vision_rope_tables(grids: Sequence[Sequence[int]], cfg: LiveCCConfig) -> Tup
 
 class Sampling:
     def __init__(self, repetition_penalty: float = 1.0, eos_token: int = -1, suppress_eos: bool = False,
-                 thr_token: int = -1, thr_base: Optional[float] = None, thr_step: float = 0.0):
+                 thr_token: int = -1, thr_base: Optional[float] = None, thr_step: float = 0.0, eos_token2: int = -1,
+                 do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, seed: int = 0):
         self.repetition_penalty, self.eos_token, self.suppress_eos = repetition_penalty, eos_token, suppress_eos
         self.thr_token, self.thr_base, self.thr_step = thr_token, thr_base, thr_step
+        self.eos_token2, self.do_sample, self.temperature, self.top_k, self.top_p, self.seed = eos_token2, do_sample, temperature, top_k, top_p, seed
 
     def to_c(self, scores_out=None, logits_out=None) -> _lib.Sampling:
         s = _lib.Sampling()
@@ -61,6 +63,12 @@ class Sampling:
         s.suppress_eos = 1 if self.suppress_eos else 0
         s.scores_out = scores_out.data_ptr() if scores_out is not None else None
         s.logits_out = logits_out.data_ptr() if logits_out is not None else None
+        s.eos_token2 = int(self.eos_token2)
+        s.do_sample = 1 if self.do_sample else 0
+        s.temperature = float(self.temperature)
+        s.top_k = int(self.top_k or 0)
+        s.top_p = float(self.top_p if self.top_p is not None else 1.0)
+        s.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
         return s
 
 

@@ -4,8 +4,10 @@ sharding, per-item JSON files (resumable), merge to JSONL -- but ONE process per
 by rank 0 only and broadcast over RCCL/xGMI (`distributed.broadcast_weights`) instead of every worker re-reading it (ref :46).
 
 The dataset (`datasets.load_dataset('stdKonjac/LiveSports-3K', ...)`) and video decoding are external: `records` is any
-sequence of dicts with the reference's fields (`video_id`, `event_id`, `begin`, `end`, `event_title`, `preasr_text`) plus
-`frames` -- a uint8 clip tensor or a zero-argument callable returning one (decoded lazily on the owning rank).
+sequence of dicts with the reference's fields (`video`, `video_id`, `event_id`, `begin`, `end`, `event_title`, `preasr_text`):
+`video` names a decoded video (`livecc_amd.video`: registered path or DecodedVideo) from which the [begin, end] range is
+sampled and resized exactly as the reference does; alternatively `frames` -- an already sampled uint8 clip tensor or a
+zero-argument callable returning one (decoded lazily on the owning rank).
 """
 from __future__ import annotations
 
@@ -47,10 +49,14 @@ def generate_shard(records: Sequence[dict], infer, save_dir: str, rank: int, wor
         if os.path.exists(path):
             continue
         rec = records[idx]
-        frames = rec["frames"]() if callable(rec["frames"]) else rec["frames"]
-        responses = infer.live_cc_once_for_evaluation(frames, query=overall_prompt(rec.get("event_title"), rec.get("preasr_text"), simple_ctx),
-                                                      video_start=rec.get("begin") or 0.0, max_new_tokens=max_new_tokens,
-                                                      repetition_penalty=repetition_penalty,
+        # ref :61-68, 84-89: `video` names the source (a registered path / DecodedVideo: frame selection for [begin, end] and the
+        # resize run inside live_cc_once_for_evaluation); `frames` = an already sampled + resized clip (or a callable making one)
+        video = rec.get("video")
+        if video is None:
+            video = rec["frames"]() if callable(rec["frames"]) else rec["frames"]
+        responses = infer.live_cc_once_for_evaluation(query=overall_prompt(rec.get("event_title"), rec.get("preasr_text"), simple_ctx),
+                                                      video=video, video_start=rec.get("begin"), video_end=rec.get("end"),
+                                                      max_new_tokens=max_new_tokens, repetition_penalty=repetition_penalty,
                                                       **({"frames_layout": rec["frames_layout"]} if "frames_layout" in rec else {}))
         tmp = path + ".tmp"
         with open(tmp, "w") as wf:
@@ -93,7 +99,7 @@ def distributed_generate(records: Sequence[dict], model_path: str, output_dir: s
     arena = from_pretrained(model_path, cfg, dev) if rank == 0 else WeightArena(cfg, dev)
     D.broadcast_weights(arena.flat, src=0)
     model = LiveCCForConditionalGeneration(cfg, arena, dev, **model_kw)
-    infer = LiveCCDemoInfer(model=model, model_path=model_path)
+    infer = LiveCCDemoInfer(model_path=model_path, model=model)
     save_dir = os.path.join(output_dir, os.path.basename(os.path.normpath(model_path)))
     generate_shard(records, infer, save_dir, rank, world, simple_ctx, repetition_penalty, max_new_tokens)
     D.barrier(dev)

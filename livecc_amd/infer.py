@@ -1,10 +1,27 @@
-"""Stream orchestrator with the surface of the reference's `LiveCCDemoInfer` (ref demo/infer.py:25-310), driving the
-native model instead of HF.  Video decode / resize (decord, torchvision) are outside this round's scope:
-clips arrive as uint8 frame tensors already at the model resolution (what `get_smart_resized_clip`,
-ref livecc_utils/video_process_patch.py:126-156, returns).  Text: with tokenizer files (a checkpoint directory, or a
-`text.TextFrontEnd` passed in) the turns are built from real strings exactly as the reference does -- chat template,
-'Time=a-bs' prefix, query appended on the first turn or when it changes, '<|im_end|>\n' glue, `processor.decode` of the
-answer (ref demo/infer.py:134-157, 175); without them the turn ids are synthetic (`protocol.TurnBuilder`, benchmarks).
+"""Stream orchestrator with the surface AND the signatures of the reference's `LiveCCDemoInfer` (ref demo/infer.py:25-310),
+driving the native model instead of HF, so that the L5 callers run unmodified given decoded frames:
+
+    infer = LiveCCDemoInfer(model_path=..., device='cuda:0')                          # ref demo/cli.py:9
+    state = {'video_path': path}; state['video_timestamp'] = t
+    for (t0, t1), response, state in infer.live_cc(message=query, state=state, max_pixels=..., repetition_penalty=1.05,
+                                                   streaming_eos_base_threshold=0.0, streaming_eos_threshold_step=0): ...
+    responses = infer.live_cc_once_for_evaluation(query=..., video=video, video_start=b, video_end=e,
+                                                  max_new_tokens=32, repetition_penalty=1.15)   # ref distributed_generate_livecc.py:84
+    response, state = infer.video_qa(message, history, state)                         # ref demo/app.py
+
+Video DECODING stays external (decord is a C++ dependency of the reference): `video_path` / `video` name a
+`livecc_amd.video.DecodedVideo` (uint8 frames + pts) registered with `video.register_video`, produced by a loader installed with
+`video.set_video_loader`, or passed directly.  Everything after the decoder runs here: frame selection
+(`video.read_video_decord_plus`, `resize.select_clip_frames`), the pixel-budget policy, the antialias-bicubic resize on the GPU,
+the chunking 6/2/2..., the turn text, and `generate` on the native engine.
+
+Text: with tokenizer files (a checkpoint directory, or a `text.TextFrontEnd` passed in) the turns are built from real strings
+exactly as the reference does -- chat template, 'Time=a-bs' prefix, query appended on the first turn or when it changes,
+'<|im_end|>\\n' glue, `processor.decode` of the answer (ref demo/infer.py:134-157, 175); without them the turn ids are synthetic
+(`protocol.TurnBuilder`; benchmarks and shape tests) and "responses" are the generated ids joined by spaces.
+
+The clip-level entry points (`live_cc_clip`, `video_qa_clip`) take an already fetched + resized uint8 clip; the multi-stream
+server and the benchmarks use them.
 """
 from __future__ import annotations
 
@@ -14,6 +31,7 @@ import numpy as np
 import torch
 
 from . import protocol
+from . import video as V
 from .modeling import LiveCCForConditionalGeneration
 
 
@@ -25,7 +43,13 @@ class ThresholdLogitsProcessor:
         self.token_id, self.base_threshold, self.step, self.count = token_id, base_threshold, step, 0
 
 
+def _hw(clip: torch.Tensor, layout: str):
+    return (clip.shape[2], clip.shape[3]) if layout == "TCHW" else (clip.shape[1], clip.shape[2])
+
+
 class LiveCCDemoInfer:
+    VIDEO_PLAY_END = object()
+    VIDEO_PLAY_CONTINUE = object()
     fps = protocol.FPS
     initial_fps_frames = protocol.INITIAL_FPS_FRAMES
     streaming_fps_frames = protocol.STREAMING_FPS_FRAMES
@@ -33,14 +57,15 @@ class LiveCCDemoInfer:
     streaming_time_interval = protocol.STREAMING_TIME_INTERVAL
     frame_time_interval = protocol.FRAME_TIME_INTERVAL
 
-    def __init__(self, model: LiveCCForConditionalGeneration = None, model_path: str = None, device: str = None,
+    def __init__(self, model_path: str = None, device: str = None, model: LiveCCForConditionalGeneration = None,
                  turn_builder: Optional[protocol.TurnBuilder] = None, decode: Optional[Callable[[List[int]], str]] = None,
-                 streaming_eos_token_id: Optional[int] = None, text=None):
-        """`text`: a `text.TextFrontEnd` (real tokenizer).  With `model_path` it is created from the checkpoint directory's
-        tokenizer files when they exist (ref demo/infer.py:48-58)."""
+                 streaming_eos_token_id: Optional[int] = None, text=None, **model_kw):
+        """ref demo/infer.py:35-59.  `text`: a `text.TextFrontEnd` (real tokenizer); with `model_path` it is created from the
+        checkpoint directory's tokenizer files when they exist.  `model_kw` (max_streams, max_kv_len, llm_fp8 ...) goes to
+        `from_pretrained`."""
         if model is None:
             device = device or "cuda"
-            model = LiveCCForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map=device)
+            model = LiveCCForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map=device, **model_kw)
         self.model = model
         self.cfg = model.cfg
         if text is None and model_path is not None:
@@ -53,137 +78,212 @@ class LiveCCDemoInfer:
         if text is not None:
             self.decode = decode or (lambda ids: text.decode(ids, skip_special_tokens=True))
             self.streaming_eos_token_id = text.streaming_eos_token_id if streaming_eos_token_id is None else streaming_eos_token_id
+            self.system_prompt_offset = text.system_prompt_offset
         else:
             self.decode = decode or (lambda ids: " ".join(str(i) for i in ids))
             # ref infer.py:49: tokenizer(' ...').input_ids[-1]; without tokenizer files the caller supplies it
             self.streaming_eos_token_id = streaming_eos_token_id
+            self.system_prompt_offset = None
+        self._cached_video_readers_with_hw = {}
 
-    @torch.inference_mode()
-    def live_cc(self, clip: torch.Tensor, state: dict, frames_layout: str = "TCHW", do_sample: bool = False,
-                repetition_penalty: float = 1.05, streaming_eos_base_threshold: float = None,
-                streaming_eos_threshold_step: float = None, max_new_tokens: int = 16, force_length: bool = False,
-                message: Optional[str] = None, default_query: str = "Please describe the video.", hf_spaces: bool = False):
-        """One call = the frames that became due since the last call (ref infer.py:61-180, steps 4-5).
-        `clip`: uint8 frames [T,3,H,W] (or THWC).  Yields ((start, stop), text, state) per chunk.
-        `message` / `default_query` (real-tokenizer mode): the user query, appended to the turn when it is new or changed
-        (ref infer.py:141-146)."""
-        initialized = state.get("last_timestamp", -1.0) >= 0
-        t0 = state.get("last_timestamp", -self.frame_time_interval) + self.frame_time_interval
-        for a, b in protocol.split_clip(clip.shape[0], initialized):
-            frames = clip[a:b]
-            start = t0 + a * self.frame_time_interval
-            stop = t0 + b * self.frame_time_interval
-            turn = state.get("turn_index", 0)
-            grid = protocol.grid_of(frames.shape[0], *(frames.shape[2:] if frames_layout == "TCHW" else frames.shape[1:3]), self.cfg)
-            past_ids = state.get("past_ids")
-            if self.text is not None:
-                if not message and not state.get("message"):
-                    message = default_query                       # ref infer.py:141-143
-                query = None
-                if message and state.get("message") != message:   # ref infer.py:144-146
-                    query = message
-                    state["message"] = message
-                new_ids = self.text.turn_ids(start, stop, grid, query, continuing=past_ids is not None)
-            else:
-                new_ids = self.turn_builder.turn_ids(turn, protocol.num_video_tokens(grid, self.cfg))
-            ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
-            procs = None
-            if streaming_eos_base_threshold is not None and self.streaming_eos_token_id is not None:
-                procs = [ThresholdLogitsProcessor(self.streaming_eos_token_id, streaming_eos_base_threshold,
-                                                  streaming_eos_threshold_step or 0.0)]
-            out = self.model.generate(
-                input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, frames_layout=frames_layout,
-                past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=do_sample,
-                repetition_penalty=repetition_penalty, logits_processor=procs, max_new_tokens=max_new_tokens,
-                min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id)
-            seq = out.sequences[0].cpu().numpy()
-            state["past_key_values"] = out.past_key_values
-            state["past_ids"] = seq[:-1]                      # ref infer.py:174
-            state["turn_index"] = turn + 1
-            state["last_timestamp"] = stop - self.frame_time_interval
-            new_tokens = seq[len(ids):].tolist()
-            text_out = self.decode([t for t in new_tokens if t != self.cfg.eos_token_id])
-            if hf_spaces:   # ref infer.py:176-178: the caller gets a light copy without the device-side state
-                yield (start, stop), text_out, {k: v for k, v in state.items() if k not in ("past_ids", "past_key_values")}
-            else:
-                yield (start, stop), text_out, state
+    # --------------------------------------------------------------------------------------------------------------
+    # one generate call per chunk (ref demo/infer.py:132-180, step 5)
+    # --------------------------------------------------------------------------------------------------------------
+    def _turn(self, frames, frames_layout, start, stop, state, message, default_query, do_sample, repetition_penalty,
+              streaming_eos_base_threshold, streaming_eos_threshold_step, max_new_tokens, force_length, gen_kw):
+        turn = state.get("turn_index", 0)
+        grid = protocol.grid_of(frames.shape[0], *_hw(frames, frames_layout), self.cfg)
+        past_ids = state.get("past_ids")
+        if self.text is not None:
+            if not message and not state.get("message"):
+                message = default_query                       # ref infer.py:141-143
+            query = None
+            if message and state.get("message") != message:   # ref infer.py:144-146
+                query = message
+                state["message"] = message
+            new_ids = self.text.turn_ids(start, stop, grid, query, continuing=past_ids is not None)
+        else:
+            new_ids = self.turn_builder.turn_ids(turn, protocol.num_video_tokens(grid, self.cfg))
+        ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
+        procs = None
+        if streaming_eos_base_threshold is not None and self.streaming_eos_token_id is not None:
+            procs = [ThresholdLogitsProcessor(self.streaming_eos_token_id, streaming_eos_base_threshold,
+                                              streaming_eos_threshold_step or 0.0)]
+        out = self.model.generate(
+            input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, frames_layout=frames_layout,
+            past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=do_sample,
+            repetition_penalty=repetition_penalty, logits_processor=procs, max_new_tokens=max_new_tokens,
+            min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id, **gen_kw)
+        seq = out.sequences[0].cpu().numpy()
+        state["past_key_values"] = out.past_key_values
+        state["past_ids"] = seq[:-1]                      # ref infer.py:174
+        state["turn_index"] = turn + 1
+        new_tokens = seq[len(ids):].tolist()
+        return self.decode([t for t in new_tokens if t not in self.model.eos_token_ids])
 
+    # --------------------------------------------------------------------------------------------------------------
+    # live_cc: the reference's signature (ref demo/infer.py:61-180)
+    # --------------------------------------------------------------------------------------------------------------
     @torch.inference_mode()
-    def live_cc_from_video(self, video_frames: torch.Tensor, video_pts, state: dict, video_timestamp: float,
-                           max_pixels: int = 384 * 28 * 28, frames_layout: str = "THWC", **kw):
-        """The whole `live_cc` of the reference (ref demo/infer.py:61-180) on a decoded video that is resident on the GPU
-        (`video_frames` uint8 [N,H,W,3], `video_pts` seconds per frame; decoding itself stays external): decide which frames
-        became due at wall-clock `video_timestamp` (steps 1-2), fetch and resize them on the GPU (step 3,
-        `resize.get_smart_resized_clip`), then chunk + generate (steps 4-5, `live_cc`).  `state` carries `last_timestamp`,
-        `last_video_pts_index`, `resized_hw`, `video_end` as the reference's does.  Yields ((start, stop), text, state)."""
-        from . import resize as R
-        pts = np.asarray(video_pts, dtype=np.float64)
-        last_timestamp = state.get("last_timestamp", -1 / self.fps)
-        if "resized_hw" not in state:                                  # get_smart_resized_video_reader, once per video
-            hw = video_frames.shape[1:3] if frames_layout == "THWC" else video_frames.shape[2:4]
-            state["resized_hw"] = R.smart_resized_hw(int(hw[0]), int(hw[1]), int(video_frames.shape[0]), max_pixels)
+    def live_cc(self, message: str, state: dict, max_pixels: int = 384 * 28 * 28, default_query: str = "Please describe the video.",
+                do_sample: bool = True, repetition_penalty: float = 1.05, streaming_eos_base_threshold: float = None,
+                streaming_eos_threshold_step: float = None, hf_spaces: bool = False, **kwargs):
+        """state keys as in the reference: video_path, video_timestamp, last_timestamp, last_video_pts_index, video_pts,
+        past_ids, past_key_values, message, video_end.  Extra keyword arguments: max_new_tokens (16), force_length,
+        and sampling parameters (top_k / top_p / temperature / seed) forwarded to `generate`.  Yields
+        ((start, stop), response, state)."""
+        max_new_tokens = int(kwargs.pop("max_new_tokens", 16))
+        force_length = bool(kwargs.pop("force_length", False))
+        # 1. preparation: video reader and last processing info (ref :86-104)
+        video_timestamp, last_timestamp = state.get("video_timestamp", 0), state.get("last_timestamp", -1 / self.fps)
+        video_path = state.get("video_path", None)
+        if video_path is None or (isinstance(video_path, str) and not video_path):
+            return
+        key = video_path if isinstance(video_path, str) else id(video_path)
+        if key not in self._cached_video_readers_with_hw:
+            self._cached_video_readers_with_hw[key] = V.get_smart_resized_video_reader(video_path, max_pixels)
+            state["video_pts"] = self._cached_video_readers_with_hw[key][0].pts
             state["last_video_pts_index"] = -1
-        video_timestamp = min(float(video_timestamp), float(pts[-1]))
-        if last_timestamp + self.frame_time_interval > pts[-1]:
+        video_pts = state.get("video_pts", None)
+        if video_pts is None:
+            return
+        video_timestamp = min(video_timestamp, video_pts[-1])
+        if last_timestamp + self.frame_time_interval > video_pts[-1]:
             state["video_end"] = True
             return
+        reader, resized_height, resized_width = self._cached_video_readers_with_hw[key]
+        last_video_pts_index = state["last_video_pts_index"]
+        # 2. which frames will be processed (ref :106-111)
         initialized = last_timestamp >= 0
         if not initialized:
             video_timestamp = max(video_timestamp, self.initial_time_interval)
         if video_timestamp <= last_timestamp + self.frame_time_interval:
             return
         timestamps = torch.arange(last_timestamp + self.frame_time_interval, video_timestamp, self.frame_time_interval).tolist()
-        h, w = state["resized_hw"]
-        clip, clip_ts, idxs = R.get_smart_resized_clip(video_frames, h, w, timestamps, pts, state["last_video_pts_index"] + 1, frames_layout)
-        if len(idxs) == 0:
+        # 3. fetch frames at the required timestamps, resized on the GPU (ref :113-118)
+        from . import resize as R
+        frames = reader.frames if reader.frames.is_cuda else reader.frames.to(self.model.device)
+        if frames is not reader.frames:
+            reader.frames = frames                       # keep the decoded video resident in HBM for the next calls
+        clip, clip_timestamps, clip_idxs = R.get_smart_resized_clip(frames, resized_height, resized_width, timestamps, video_pts,
+                                                                   last_video_pts_index + 1, reader.layout)
+        if len(clip_idxs) == 0:
             return
-        state["last_video_pts_index"] = idxs[-1]
-        for out in self.live_cc(clip, state, frames_layout="TCHW", **kw):
-            yield out
-        state["last_timestamp"] = clip_ts[-1]                          # ref infer.py:118 (set from the fetched timestamps)
+        state["last_video_pts_index"] = clip_idxs[-1]
+        state["last_timestamp"] = clip_timestamps[-1]
+        # 4. interleave: first chunk 6 frames, then chunks of 2 (ref :120-129); 5. one generate per chunk (ref :131-180)
+        for a, b in protocol.split_clip(clip.shape[0], initialized):
+            ts = clip_timestamps[a:b]
+            start, stop = ts[0], ts[-1] + self.frame_time_interval
+            response = self._turn(clip[a:b], "TCHW", start, stop, state, message, default_query, do_sample, repetition_penalty,
+                                  streaming_eos_base_threshold, streaming_eos_threshold_step, max_new_tokens, force_length, kwargs)
+            if hf_spaces:   # ref :176-178: the caller gets a light copy without the device-side state
+                yield (start, stop), response, {k: v for k, v in state.items() if k not in ("past_ids", "past_key_values")}
+            else:
+                yield (start, stop), response, state
 
     @torch.inference_mode()
-    def video_qa(self, query_len, state: dict, clip: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
-                 repetition_penalty: float = 1.05, max_new_tokens: int = 512, force_length: bool = False):
-        """Multi-turn QA with KV reuse (ref demo/infer.py:182-242): the first turn prefills the WHOLE clip in one shot
-        (up to 480 frames / 24k visual tokens), later turns are text only.  `query_len`: the query STRING in real-tokenizer
-        mode (the reference's `message`), or the number of synthetic query ids.  Returns (generated ids, state) -- with a
-        tokenizer, `self.decode(ids)` is the reference's `response`."""
-        turn = state.get("turn_index", 0)
-        past_ids = state.get("past_ids")
-        n_vid = 0
-        grid = None
-        if past_ids is None and clip is not None:       # "only use once" (infer.py:213-214)
-            grid = protocol.grid_of(clip.shape[0], *(clip.shape[2:] if frames_layout == "TCHW" else clip.shape[1:3]), self.cfg)
-            n_vid = protocol.num_video_tokens(grid, self.cfg)
-        if isinstance(query_len, str):
+    def live_cc_clip(self, clip: torch.Tensor, state: dict, frames_layout: str = "TCHW", do_sample: bool = False,
+                     repetition_penalty: float = 1.05, streaming_eos_base_threshold: float = None,
+                     streaming_eos_threshold_step: float = None, max_new_tokens: int = 16, force_length: bool = False,
+                     message: Optional[str] = None, default_query: str = "Please describe the video.", hf_spaces: bool = False,
+                     **gen_kw):
+        """Steps 4-5 of `live_cc` on frames that are already fetched and resized (`clip` uint8 [T,3,H,W] or THWC): the frames
+        continue the stream at state['last_timestamp'] + 0.5 s.  Yields ((start, stop), text, state) per chunk."""
+        initialized = state.get("last_timestamp", -1.0) >= 0
+        t0 = state.get("last_timestamp", -self.frame_time_interval) + self.frame_time_interval
+        for a, b in protocol.split_clip(clip.shape[0], initialized):
+            start = t0 + a * self.frame_time_interval
+            stop = t0 + b * self.frame_time_interval
+            text_out = self._turn(clip[a:b], frames_layout, start, stop, state, message, default_query, do_sample, repetition_penalty,
+                                  streaming_eos_base_threshold, streaming_eos_threshold_step, max_new_tokens, force_length, gen_kw)
+            state["last_timestamp"] = stop - self.frame_time_interval
+            if hf_spaces:
+                yield (start, stop), text_out, {k: v for k, v in state.items() if k not in ("past_ids", "past_key_values")}
+            else:
+                yield (start, stop), text_out, state
+
+    # --------------------------------------------------------------------------------------------------------------
+    # video_qa (ref demo/infer.py:182-242)
+    # --------------------------------------------------------------------------------------------------------------
+    def _fetch_video(self, video):
+        """`qwen_vl_utils.process_vision_info` -> `fetch_video` with the reference's 'decord+' backend (ref
+        video_process_patch.py:85-86): `_read_video_decord_plus(ele)` (smart_nframes + linspace), then the per-nframes pixel
+        budget + smart_resize + antialias bicubic resize -- the same arithmetic as `_spatial_resize_video`."""
+        clip, _ = V.read_video_decord_plus({"video": video}, device=self.model.device)
+        return V.spatial_resize_video(clip, device=self.model.device)
+
+    @torch.inference_mode()
+    def video_qa(self, message, history: list, state: dict, do_sample: bool = False, repetition_penalty: float = 1.05,
+                 hf_spaces: bool = False, **kwargs):
+        """The reference's signature.  First turn (no `past_ids`): the whole video named by state['video_path'] in ONE prefill
+        (up to 480 frames / 24k visual tokens) + `message`; later turns: text only on the carried KV.  `hf_spaces`: stateless --
+        the conversation is rebuilt from `history` ([{'role','content'}...]) and nothing is kept.  Returns (response, state).
+        `message` is the query string (tokenizer mode) or a synthetic query length (int)."""
+        max_new_tokens = int(kwargs.pop("max_new_tokens", 512))
+        force_length = bool(kwargs.pop("force_length", False))
+        video_path = state.get("video_path", None)
+        past_ids = state.get("past_ids", None)
+        use_video = video_path is not None and (hf_spaces or past_ids is None)      # "only use once" (ref :206, 214)
+        if hf_spaces:
+            past_ids = None
+            old = state.get("past_key_values")
+            if old is not None:
+                old.release()
+                state["past_key_values"] = None
+        clip = self._fetch_video(video_path) if use_video else None
+        grid = protocol.grid_of(clip.shape[0], clip.shape[2], clip.shape[3], self.cfg) if clip is not None else None
+        if isinstance(message, str):
             if self.text is None:
                 raise ValueError("a query string needs tokenizer files (pass text=TextFrontEnd(...) or a checkpoint directory)")
-            new_ids = self.text.encode(self.text.qa_text(query_len, continuing=past_ids is not None, with_video=grid is not None),
-                                       [grid] if grid is not None else [])
+            conversation = []
+            video_pending = clip is not None
+            if hf_spaces:                                                            # ref :202-210
+                for past_message in history or []:
+                    content = [{"type": "text", "text": past_message["content"]}]
+                    if video_pending:
+                        content.insert(0, {"type": "video", "video": None})
+                        video_pending = False
+                    conversation.append({"role": past_message["role"], "content": content})
+            content = [{"type": "text", "text": message}]
+            if video_pending:
+                content.insert(0, {"type": "video", "video": None})
+            conversation.append({"role": "user", "content": content})
+            text = self.text.apply_chat_template(conversation, add_generation_prompt=True)
+            if past_ids is not None:
+                text = "<|im_end|>\n" + text[self.text.system_prompt_offset:]        # ref :218-219
+            new_ids = self.text.encode(text, [grid] if grid is not None else [])
         else:
-            self.turn_builder.query_len = query_len
-            new_ids = self.turn_builder.turn_ids(turn, n_vid, with_query=True)
+            self.turn_builder.query_len = int(message)
+            new_ids = self.turn_builder.turn_ids(state.get("turn_index", 0), protocol.num_video_tokens(grid, self.cfg) if grid else 0,
+                                                 with_query=True)
         ids = new_ids if past_ids is None else np.concatenate([past_ids, new_ids])
         out = self.model.generate(
-            input_ids=torch.from_numpy(ids).view(1, -1), frames=clip if n_vid else None, frames_layout=frames_layout,
-            past_key_values=state.get("past_key_values"), return_dict_in_generate=True, do_sample=False,
+            input_ids=torch.from_numpy(ids).view(1, -1), frames=clip, frames_layout="TCHW",
+            past_key_values=None if hf_spaces else state.get("past_key_values"), return_dict_in_generate=True, do_sample=do_sample,
             repetition_penalty=repetition_penalty, max_new_tokens=max_new_tokens,
-            min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id)
+            min_new_tokens=max_new_tokens if force_length else None, pad_token_id=self.cfg.eos_token_id, **kwargs)
         seq = out.sequences[0].cpu().numpy()
-        state["past_key_values"] = out.past_key_values
-        state["past_ids"] = seq[:-1]
-        state["turn_index"] = turn + 1
-        return seq[len(ids):].tolist(), state
+        if hf_spaces:                                                                # ref :237-238
+            out.past_key_values.release()
+            state["past_key_values"], state["past_ids"] = None, None
+        else:
+            state["past_key_values"], state["past_ids"] = out.past_key_values, seq[:-1]
+        state["turn_index"] = state.get("turn_index", 0) + 1
+        new_tokens = seq[len(ids):].tolist()
+        state["last_new_tokens"] = new_tokens
+        return self.decode([t for t in new_tokens if t not in self.model.eos_token_ids]), state
 
+    # --------------------------------------------------------------------------------------------------------------
+    # prefill-only multiple-choice scoring (SURVEY 8f-3)
+    # --------------------------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def mcq_predict(self, clip: Optional[torch.Tensor], question: str, options: List[str], letters=("A", "B", "C", "D"),
                     frames_layout: str = "TCHW", question_prefix: str = "", question_postfix: str = "\nPlease select the correct answer.",
                     answer_prefix: str = "Answer:", abcd_previous_str: str = ": ", subtitles: Optional[str] = None):
-        """Prefill-only multiple-choice scoring (ref evaluation/distributed_mcq_predictor.py:33-105): one-shot
-        prefill of [video] + question + options + 'Answer:', logits of the LAST prompt position restricted to the option-letter
-        ids (`tokenizer(': A').input_ids[-1]`, ...), argmax.  Returns (index of the chosen option, restricted logits).
-        Needs tokenizer files (`self.text`)."""
+        """ref evaluation/distributed_mcq_predictor.py:33-105: one-shot prefill of [video] + question + options + 'Answer:',
+        logits of the LAST prompt position restricted to the option-letter ids (`tokenizer(': A').input_ids[-1]`, ...), argmax.
+        Returns (index of the chosen option, restricted logits).  Needs tokenizer files (`self.text`)."""
         if self.text is None:
             raise ValueError("mcq_predict needs tokenizer files (pass text=TextFrontEnd(...) or a checkpoint directory)")
         tok = self.text.tokenizer
@@ -193,7 +293,7 @@ class LiveCCDemoInfer:
             query = f"This video's subtitles are listed below:\n{subtitles}\nAccording to the video and subtitles, " + query
         grid = None
         if clip is not None:
-            grid = protocol.grid_of(clip.shape[0], *(clip.shape[2:] if frames_layout == "TCHW" else clip.shape[1:3]), self.cfg)
+            grid = protocol.grid_of(clip.shape[0], *_hw(clip, frames_layout), self.cfg)
         text = self.text.qa_text(query, continuing=False, with_video=grid is not None) + answer_prefix   # ref :56-57
         ids = self.text.encode(text, [grid] if grid is not None else [])
         out = self.model.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=clip, frames_layout=frames_layout,
@@ -203,15 +303,39 @@ class LiveCCDemoInfer:
         logits = out.logits[0].float().view(-1)[torch.as_tensor(letter_ids, device=out.logits.device)]
         return int(torch.argmax(logits)), logits.cpu()
 
+    # --------------------------------------------------------------------------------------------------------------
+    # offline replay of a whole clip (ref demo/infer.py:244-310)
+    # --------------------------------------------------------------------------------------------------------------
     @torch.inference_mode()
-    def live_cc_once_for_evaluation(self, clip: torch.Tensor, frames_layout: str = "TCHW", max_new_tokens: int = 32,
-                                    repetition_penalty: float = 1.05, video_start: float = 0.0, force_length: bool = False,
-                                    query: Optional[str] = None):
-        """Offline replay of a whole clip (ref infer.py:244-310): chunks 6,2,2,...; returns [[t0, t1, text], ...]."""
+    def live_cc_once_for_evaluation(self, query: str, video, video_start: float = 0, video_end: float = None,
+                                    remote_loader: callable = None, max_new_tokens: int = 32, repetition_penalty: float = 1.05,
+                                    **kwargs):
+        """The reference's signature.  `video`: a registered path / `DecodedVideo` (read with `_read_video_decord_plus`'s frame
+        selection for [video_start, video_end] and resized under `_spatial_resize_video`'s budget, ref :256-257), or an
+        already sampled + resized uint8 clip tensor [T,3,H,W] (`frames_layout='THWC'` for decoder order).  Chunks 6,2,2,...;
+        the query goes with the first turn only; do_sample is not passed, i.e. the checkpoint's generation_config decides
+        (ref :297-302).  Returns [[t0, t1, text], ...].  The KV slot lives in locals like the reference's (:303-304) and is
+        released before returning."""
+        frames_layout = kwargs.pop("frames_layout", "TCHW")
+        force_length = bool(kwargs.pop("force_length", False))
+        if isinstance(video, torch.Tensor):
+            clip = video
+        else:
+            clip, _ = V.read_video_decord_plus({"video": video, "video_start": video_start, "video_end": video_end,
+                                                "remote_loader": remote_loader}, device=self.model.device)
+            clip = V.spatial_resize_video(clip, device=self.model.device)
+            frames_layout = "TCHW"
         state: dict = {}
         responses = []
-        for (a, b), text, state in self.live_cc(clip, state, frames_layout=frames_layout, repetition_penalty=repetition_penalty,
-                                                max_new_tokens=max_new_tokens, force_length=force_length, message=query):
-            responses.append([video_start + a, video_start + b, text])
-        self.last_state = state
+        try:
+            stop = 0.0
+            for i, (a, b) in enumerate(protocol.split_clip(clip.shape[0])):
+                start, stop = (0.0, self.initial_time_interval) if i == 0 else (stop, stop + self.streaming_time_interval)   # ref :270-273
+                text = self._turn(clip[a:b], frames_layout, start, stop, state, query if i == 0 else None, None, None,
+                                  repetition_penalty, None, None, max_new_tokens, force_length, dict(kwargs))
+                responses.append([(video_start or 0) + start, (video_start or 0) + stop, text])
+        finally:
+            kv = state.pop("past_key_values", None)
+            if kv is not None:
+                kv.release()
         return responses

@@ -81,18 +81,36 @@ class _Cfg:
 class LiveCCForConditionalGeneration:
     main_input_name = "input_ids"
 
-    def __init__(self, cfg: LiveCCConfig, weights: WeightArena, device, max_streams: int = 1, max_kv_len: int = 32768,
-                 max_new_rows: int = 2048, max_patches: int = 8192, max_history: int = 64,
-                 text_offset_rule: str = "hf5"):
+    def __init__(self, cfg: LiveCCConfig, weights: WeightArena, device, max_streams: int = 1, max_kv_len: Optional[int] = None,
+                 max_new_rows: int = 4096, max_patches: int = 16384, max_history: int = 512,
+                 text_offset_rule: str = "hf4", eos_token_ids: Optional[Sequence[int]] = None):
+        """Capacity knobs (all served out of the box with the defaults, like the reference's flows):
+        max_history     = the largest max_new_tokens of one generate call (video_qa uses 512, ref demo/infer.py:236);
+        max_new_rows    = rows of ONE prefill launch sequence -- longer prompts (the one-shot 24k-token video_qa / MCQ prefill)
+                          are cut into pieces of at most this many rows over the carried KV (bit-identical to one pass);
+        max_patches     = ViT patches of ONE encode launch sequence -- longer clips are encoded in groups of temporal slices
+                          (slices never attend to each other, Q2VL vision_utils.py:60-65);
+        max_kv_len      = KV capacity per stream; default = the trained 32k window + max_history of generation headroom.
+        text_offset_rule: "hf4" = transformers-4.5x M-RoPE text offset after a vision block (what the released checkpoints
+        were trained with, ref README.md:30); "hf5" = the installed 5.15 oracle's rule.  Identical for every streaming chunk;
+        they differ for one-shot long clips (grid_t > max(h,w)/2)."""
         self.cfg, self.weights = cfg, weights
         self.config = _Cfg(cfg)
         self.device = torch.device(device)
+        if max_kv_len is None:
+            max_kv_len = cfg.max_position_embeddings + max_history
         self.engine = Engine(cfg, weights, self.device, max_slots=max_streams, max_kv_len=max_kv_len,
                              max_new_rows=max_new_rows, max_patches=max_patches, max_history=max_history)
         self._free_slots = list(range(max_streams - 1, -1, -1))
         self.text_offset_rule = text_offset_rule
         self.prepare_inputs_for_generation = None   # assignable, as ref demo/infer.py:50 does
         self.generation_config: dict = {}            # from_pretrained fills it from generation_config.json (do_sample / top_k ...)
+        # HF stops on ANY id of generation_config.eos_token_id ([<|im_end|>, <|endoftext|>] in the released checkpoints)
+        ids = [int(cfg.eos_token_id)] + [int(t) for t in (eos_token_ids or []) if int(t) != int(cfg.eos_token_id)]
+        if len(ids) > 2:
+            raise NotImplementedError(f"at most two EOS ids are supported, got {ids}")
+        self.eos_token_ids = ids
+        self.config.eos_token_id = ids[0] if len(ids) == 1 else list(ids)
 
     # ---- constructors ----
     @classmethod
@@ -103,14 +121,19 @@ class LiveCCForConditionalGeneration:
         device = device_map if isinstance(device_map, (str, torch.device)) and device_map not in ("auto",) else "cuda"
         if "cuda" not in str(device):
             raise RuntimeError("livecc_amd has no CPU path; use device_map='cuda[:i]' (the oracle under oracle/ is the CPU path)")
-        cfg = get_config(model_path)
-        arena = _arena_from_pretrained(model_path, cfg, device, llm_fp8=bool(kw.pop("llm_fp8", False)))
-        model = cls(cfg, arena, device, **kw)
         import json
         import os
+        cfg = get_config(model_path)
+        gen_cfg = {}
         gc = os.path.join(model_path, "generation_config.json")
         if os.path.exists(gc):
-            model.generation_config = json.load(open(gc))
+            gen_cfg = json.load(open(gc))
+        eos = gen_cfg.get("eos_token_id")
+        if eos is not None and "eos_token_ids" not in kw:
+            kw["eos_token_ids"] = list(eos) if isinstance(eos, (list, tuple)) else [eos]
+        arena = _arena_from_pretrained(model_path, cfg, device, llm_fp8=bool(kw.pop("llm_fp8", False)))
+        model = cls(cfg, arena, device, **kw)
+        model.generation_config = gen_cfg
         return model
 
     @classmethod
@@ -120,6 +143,9 @@ class LiveCCForConditionalGeneration:
 
     @classmethod
     def from_hf_model(cls, hf_model, cfg: LiveCCConfig, device="cuda", llm_fp8: bool = False, **kw):
+        """Weights of an instantiated HF model (the oracle-parity constructor): positions follow the INSTALLED transformers
+        (5.x text-offset rule) unless told otherwise, so that one-shot long clips compare equal to that oracle."""
+        kw.setdefault("text_offset_rule", "hf5")
         return cls(cfg, _arena_from_hf(hf_model, cfg, device, llm_fp8=llm_fp8), device, **kw)
 
     def eval(self):
@@ -154,48 +180,70 @@ class LiveCCForConditionalGeneration:
             st.rope_delta = 0
         return protocol.positions_with_cache(past_len, len(ids_new), st.rope_delta)
 
+    def _resolve_sampling(self, do_sample, kw) -> dict:
+        """HF semantics (generation/utils.py `_prepare_generation_config`): explicit arguments override the checkpoint's
+        generation_config.json, which overrides HF's defaults (do_sample False, temperature 1.0, top_k 50, top_p 1.0).
+        The reference's `live_cc` passes do_sample=True (ref demo/infer.py:68); `video_qa` / `live_cc_once_for_evaluation` pass
+        nothing, i.e. the checkpoint decides (ref :236-241, 297-302)."""
+        g = self.generation_config or {}
+        if do_sample is None:
+            do_sample = bool(g.get("do_sample", False))
+        if not do_sample:
+            return dict(do_sample=False)
+        def pick(name, default):
+            v = kw.get(name, g.get(name, default))
+            return default if v is None and name != "top_k" else v
+        temperature, top_k, top_p = pick("temperature", 1.0), pick("top_k", 50), pick("top_p", 1.0)
+        top_k = 0 if top_k is None else int(top_k)
+        if not (float(temperature) > 0):
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
+        if top_k < 0 or not (0 < float(top_p) <= 1.0):
+            raise ValueError(f"top_k must be >= 0 and top_p in (0, 1], got {top_k}, {top_p}")
+        return dict(do_sample=True, temperature=float(temperature), top_k=top_k, top_p=float(top_p), seed=int(kw.get("seed", g.get("seed", 0)) or 0))
+
     @torch.inference_mode()
     def generate(self, input_ids: torch.Tensor = None, pixel_values_videos: Optional[torch.Tensor] = None,
                  video_grid_thw: Optional[torch.Tensor] = None, mm_token_type_ids=None,
                  past_key_values: Optional[StreamState] = None, return_dict_in_generate: bool = True,
-                 do_sample: bool = False, repetition_penalty: float = 1.0, logits_processor=None,
+                 do_sample: Optional[bool] = None, repetition_penalty: float = 1.0, logits_processor=None,
                  max_new_tokens: int = 16, min_new_tokens: Optional[int] = None, pad_token_id: Optional[int] = None,
                  eos_token_id: Optional[int] = None, frames: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
                  output_logits: bool = False, output_scores: bool = False, attention_mask=None, **unused):
-        if do_sample:
-            # The reference's live_cc defaults to do_sample=True (ref demo/infer.py:68) with the checkpoints' generation_config
-            # (top_k = 1): the top-k warper leaves ONE finite score, so multinomial sampling is the argmax -- served by the
-            # greedy sampler.  Any other sampling configuration is not implemented.
-            top_k = unused.get("top_k", self.generation_config.get("top_k"))
-            if top_k != 1:
-                raise NotImplementedError("sampling is only supported in its degenerate top_k=1 form (the released "
-                                          "generation_config); pass do_sample=False or top_k=1")
+        sampling_kw = self._resolve_sampling(do_sample, unused)
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).all()):
             raise NotImplementedError("padding masks are not supported (the reference passes none, infer.py:156)")
         if input_ids.dim() != 2 or input_ids.shape[0] != 1:
             raise ValueError("generate() is single-stream like the reference (batch 1); use generate_batch for many streams")
         if min_new_tokens is not None and min_new_tokens not in (0, max_new_tokens):
             raise NotImplementedError("min_new_tokens must be None/0 or equal to max_new_tokens")
-        if max_new_tokens < 1 or max_new_tokens > self.engine.max_history:
-            raise ValueError(f"max_new_tokens must be in [1, {self.engine.max_history}] (engine max_history)")
         r = self.generate_batch([dict(
             input_ids=input_ids[0], pixel_values_videos=pixel_values_videos,
             video_grid_thw=video_grid_thw, frames=frames, frames_layout=frames_layout, state=past_key_values)],
             repetition_penalty=repetition_penalty, logits_processor=logits_processor, max_new_tokens=max_new_tokens,
             force_length=bool(min_new_tokens), eos_token_id=eos_token_id, output_logits=output_logits,
-            output_scores=output_scores)[0]
+            output_scores=output_scores, **sampling_kw)[0]
         return r if return_dict_in_generate else r.sequences
 
     @torch.inference_mode()
     def generate_batch(self, requests: Sequence[dict], repetition_penalty: float = 1.0, logits_processor=None,
-                       max_new_tokens: int = 16, force_length: bool = False, eos_token_id: Optional[int] = None,
-                       output_logits: bool = False, output_scores: bool = False) -> List[GenerateOutput]:
+                       max_new_tokens: int = 16, force_length: bool = False, eos_token_id=None,
+                       output_logits: bool = False, output_scores: bool = False, do_sample: bool = False, temperature: float = 1.0,
+                       top_k: int = 0, top_p: float = 1.0, seed: int = 0) -> List[GenerateOutput]:
         """Many streams, one call: the ViTs of all clips run as one batch, all prefills as one packed batch, and the
         decode steps advance every stream together (weights are streamed from HBM once per step for the whole batch).
         Each request: input_ids (1-D, full history like the reference's cat(past_ids, new_ids)), optional
         pixel_values_videos+video_grid_thw or uint8 frames, and `state` (StreamState or None)."""
         cfg, eng = self.cfg, self.engine
-        eos = cfg.eos_token_id if eos_token_id is None else int(eos_token_id)
+        if eos_token_id is None:
+            eos_ids = list(self.eos_token_ids)
+        else:
+            eos_ids = [int(t) for t in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])]
+            if len(eos_ids) > 2:
+                raise NotImplementedError("at most two EOS ids are supported")
+        eos, eos2 = eos_ids[0], (eos_ids[1] if len(eos_ids) > 1 else -1)
+        if max_new_tokens < 1 or max_new_tokens > eng.max_history:
+            raise ValueError(f"max_new_tokens={max_new_tokens} exceeds this model's max_history={eng.max_history}: construct the model "
+                             f"with max_history >= the largest max_new_tokens you generate (video_qa uses 512)")
         thr = self._threshold_params(logits_processor)
         n = len(requests)
         states, ids_new, pos3, clips, slots = [], [], [], [], []
@@ -234,13 +282,14 @@ class LiveCCForConditionalGeneration:
                                      f"{sum(protocol.num_video_tokens(g, cfg) for g in grids)}")
             pos3.append(self._positions(st, new, grids, past_len))
             states.append(st); ids_new.append(new); slots.append(st.slot); full_ids.append(ids_full)
-        vit = eng.vit_encode(clips) if clips else None
+        vit = self._vit_encode(clips) if clips else None
         V = cfg.vocab_size
         logits_buf = torch.empty(max_new_tokens, n, V, dtype=torch.bfloat16, device=self.device) if output_logits else None
         scores_buf = torch.empty(n, V, dtype=torch.float32, device=self.device) if output_scores else None
         sp = Sampling(repetition_penalty=repetition_penalty, eos_token=eos, suppress_eos=force_length,
-                      thr_token=thr[0] if thr else -1, thr_base=thr[1] if thr else None, thr_step=thr[2] if thr else 0.0)
-        eng.prefill(slots, ids_new, pos3, vit, sp, scores_out=scores_buf, logits_out=logits_buf)
+                      thr_token=thr[0] if thr else -1, thr_base=thr[1] if thr else None, thr_step=thr[2] if thr else 0.0,
+                      eos_token2=eos2, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
+        self._prefill(slots, ids_new, pos3, vit, sp, scores_buf, logits_buf)
         # decode: the device loop needs no host round trip per token (EOS freezes a slot on the device); long generations
         # (video_qa: max_new_tokens=512, ref demo/infer.py:236) are cut into chunks of 32 steps so that the host can stop
         # early once every stream has emitted EOS.
@@ -266,16 +315,84 @@ class LiveCCForConditionalGeneration:
                                        scores=scores_buf[b] if scores_buf is not None else None))
         return outs
 
+    # ---- long inputs: pieces that fit one launch sequence ----
+    def _vit_encode(self, clips: Sequence[dict]) -> torch.Tensor:
+        """ViT + merger over all clips; clips that exceed `max_patches` are encoded in groups of temporal slices (a slice only
+        attends to itself, so the concatenation is exact)."""
+        cfg, eng = self.cfg, self.engine
+        pieces: List[dict] = []
+        for c in clips:
+            if "frames" in c:
+                f, lay = c["frames"], c.get("layout", "THWC")
+                T = f.shape[0]
+                H, W = (f.shape[1], f.shape[2]) if lay == "THWC" else (f.shape[2], f.shape[3])
+                per_slice = (H // cfg.patch_size) * (W // cfg.patch_size)
+                slices = max(1, eng.max_patches // per_slice)
+                if per_slice > eng.max_patches:
+                    raise ValueError(f"one {H}x{W} frame pair is {per_slice} patches > max_patches {eng.max_patches}")
+                step = slices * cfg.temporal_patch_size
+                for a in range(0, T, step):
+                    pieces.append(dict(frames=f[a:a + step], layout=lay))
+            else:
+                t, h, w = (int(x) for x in c["grid"])
+                per_slice = h * w
+                slices = max(1, eng.max_patches // per_slice)
+                pv = c["pixel_values"]
+                for a in range(0, t, slices):
+                    b = min(t, a + slices)
+                    pieces.append(dict(pixel_values=pv[a * per_slice:b * per_slice], grid=(b - a, h, w)))
+        groups, cur, cur_p = [], [], 0
+        for pc in pieces:
+            if "frames" in pc:
+                f, lay = pc["frames"], pc["layout"]
+                H, W = (f.shape[1], f.shape[2]) if lay == "THWC" else (f.shape[2], f.shape[3])
+                n = ((f.shape[0] + 1) // 2) * (H // cfg.patch_size) * (W // cfg.patch_size)
+            else:
+                n = pc["grid"][0] * pc["grid"][1] * pc["grid"][2]
+            if cur and cur_p + n > eng.max_patches:
+                groups.append(cur); cur, cur_p = [], 0
+            cur.append(pc); cur_p += n
+        if cur:
+            groups.append(cur)
+        outs = [eng.vit_encode(g) for g in groups]
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def _prefill(self, slots, ids_new, pos3, vit, sp, scores_buf, logits_buf) -> None:
+        """One packed prefill when everything fits `max_new_rows`; otherwise every stream is prefilled alone in pieces of at
+        most `max_new_rows` rows over its carried KV (a prompt prefilled in one or in several calls gives bit-identical
+        logits: tests/test_gpu_fullsize.py).  Only the LAST piece's sampled token survives (each prefill call restarts the
+        history column), which is exactly the token of the un-split prefill."""
+        cfg, eng = self.cfg, self.engine
+        cap = eng.max_new_rows
+        if sum(len(x) for x in ids_new) <= cap:
+            eng.prefill(slots, ids_new, pos3, vit, sp, scores_out=scores_buf, logits_out=logits_buf)
+            return
+        if len(slots) > 1 and (scores_buf is not None or logits_buf is not None):
+            raise NotImplementedError("output_logits / output_scores with a multi-stream prompt longer than max_new_rows")
+        row0 = 0
+        for b, (slot, ids, pos) in enumerate(zip(slots, ids_new, pos3)):
+            is_vid = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
+            nv_before = 0
+            n_vid = int(is_vid.sum())
+            for a in range(0, len(ids), cap):
+                e = min(len(ids), a + cap)
+                k = int(is_vid[a:e].sum())
+                rows = vit[row0 + nv_before:row0 + nv_before + k] if (vit is not None and k) else None
+                nv_before += k
+                eng.prefill([slot], [ids[a:e]], [pos[:, a:e]], rows, sp,
+                            scores_out=scores_buf[b:b + 1] if scores_buf is not None else None, logits_out=logits_buf)
+            row0 += n_vid
+
     # ---- ViT only (frames/s benchmarks, parity tests) ----
     @torch.inference_mode()
     def get_video_features(self, pixel_values_videos: torch.Tensor = None, video_grid_thw=None, frames=None,
                            frames_layout: str = "TCHW") -> torch.Tensor:
         if frames is not None:
-            return self.engine.vit_encode([dict(frames=frames.to(self.device).contiguous(), layout=frames_layout)])
+            return self._vit_encode([dict(frames=frames.to(self.device).contiguous(), layout=frames_layout)])
         g = torch.as_tensor(video_grid_thw).reshape(-1, 3).tolist()
         pv = pixel_values_videos.to(self.device, dtype=torch.float32).contiguous()
         clips, off = [], 0
         for t, h, w in g:
             clips.append(dict(pixel_values=pv[off:off + t * h * w], grid=(t, h, w)))
             off += t * h * w
-        return self.engine.vit_encode(clips)
+        return self._vit_encode(clips)

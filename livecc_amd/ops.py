@@ -319,7 +319,7 @@ def attn_decode_fused(qkv_partial: torch.Tensor, bias: torch.Tensor, cos: torch.
 
 def sample_greedy(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor, repetition_penalty: float = 1.0,
                   thr_token: int = -1, thr_value: Optional[float] = None, eos_token: int = -1, suppress_eos: bool = False,
-                  want_scores: bool = False, two_stage: bool = False):
+                  want_scores: bool = False, two_stage: bool = False, eos_token2: int = -1, done: Optional[torch.Tensor] = None):
     B, V = logits.shape
     n_slots, words = seen.shape
     out = torch.zeros(n_slots, dtype=torch.int32, device=logits.device)
@@ -327,7 +327,28 @@ def sample_greedy(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor,
     ws = torch.empty(B * 256, dtype=torch.float32, device=logits.device) if two_stage else None
     _lib.check(_lib.load().lcc_sample_greedy(
         _chk(logits, torch.bfloat16, "logits"), V, B, V, _chk(seen, torch.int32, "seen"), words, _chk(slots, torch.int32, "slots"),
-        repetition_penalty, thr_token, 1 if thr_value is not None else 0, float(thr_value or 0.0), eos_token,
+        repetition_penalty, thr_token, 1 if thr_value is not None else 0, float(thr_value or 0.0), eos_token, eos_token2,
+        1 if suppress_eos else 0, _chk(done, torch.int32, "done") if done is not None else None, out.data_ptr(), None, 0, None,
+        scores.data_ptr() if scores is not None else None, ws.data_ptr() if ws is not None else None, _st(logits)), "lcc_sample_greedy")
+    return out, scores
+
+
+def sample_topk_topp(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor, temperature: float = 1.0, top_k: int = 0,
+                     top_p: float = 1.0, seed: int = 0, rng_ctr: Optional[torch.Tensor] = None, repetition_penalty: float = 1.0,
+                     thr_token: int = -1, thr_value: Optional[float] = None, eos_token: int = -1, eos_token2: int = -1,
+                     suppress_eos: bool = False, want_scores: bool = False):
+    """do_sample=True path: processors -> temperature -> top-k -> top-p -> one multinomial draw per stream.  Returns
+    (tokens int32 [n_slots], processed scores fp32 [B,V] or None).  `rng_ctr`: int32 [n_slots] draw counters (advanced in place)."""
+    B, V = logits.shape
+    n_slots, words = seen.shape
+    out = torch.zeros(n_slots, dtype=torch.int32, device=logits.device)
+    scores = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_scores else None
+    if rng_ctr is None:
+        rng_ctr = torch.zeros(n_slots, dtype=torch.int32, device=logits.device)
+    _lib.check(_lib.load().lcc_sample_topk_topp(
+        _chk(logits, torch.bfloat16, "logits"), V, B, V, _chk(seen, torch.int32, "seen"), words, _chk(slots, torch.int32, "slots"),
+        repetition_penalty, thr_token, 1 if thr_value is not None else 0, float(thr_value or 0.0), eos_token, eos_token2,
         1 if suppress_eos else 0, None, out.data_ptr(), None, 0, None, scores.data_ptr() if scores is not None else None,
-        ws.data_ptr() if ws is not None else None, _st(logits)), "lcc_sample_greedy")
+        float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _chk(rng_ctr, torch.int32, "rng_ctr"),
+        _st(logits)), "lcc_sample_topk_topp")
     return out, scores

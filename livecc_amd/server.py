@@ -97,6 +97,12 @@ class StreamServer:
         # ref :111-113: a chunk is due as soon as the video clock has passed its FIRST frame time; its second frame is fetched
         # with it (timestamps are padded to an even count, video_process_patch.py:134-135)
         if video_time <= start:
+            if start >= float(st.pts[-1]):
+                # The video clock is clamped to pts[-1], so a chunk whose first frame time is >= pts[-1] can never become due
+                # (pts[-1] on an exact half second, e.g. 121 frames at 30 fps: pts[-1] = 4.0 = last_timestamp + 0.5).  The
+                # reference has the same dead zone (ref demo/infer.py:96-111: neither `video_end` nor a chunk) and leaves it
+                # to its polling UI; a scheduler loop must terminate, so the stream ends here.
+                st.ended = True
             return None
         if self.lag_policy == "drop" and video_time - start > self.max_lag_s:
             skip = float(int((video_time - start) / (n * fti))) * n * fti      # skip stale pairs: restart at the newest due pair
@@ -107,8 +113,8 @@ class StreamServer:
     def due_time(self, sid) -> Optional[float]:
         """Wall-clock time at which the stream's next chunk becomes due (None when the stream has ended)."""
         st = self.streams[sid]
-        if st.ended or st.last_timestamp + protocol.FRAME_TIME_INTERVAL > st.pts[-1]:
-            st.ended = True
+        if st.ended or st.last_timestamp + protocol.FRAME_TIME_INTERVAL >= st.pts[-1]:
+            st.ended = True          # (>=: see the dead zone note in _next_chunk_timestamps)
             return None
         if st.last_timestamp < 0:
             return st.t_start
@@ -169,6 +175,7 @@ class StreamServer:
         out = []
         base = clock() if t0 is None else t0
         now = 0.0
+        stalls = 0
         while True:
             now = (clock() - base) if realtime else now
             res = self.step(now)
@@ -180,9 +187,27 @@ class StreamServer:
             if not dues or (until is not None and now >= until):
                 break
             nxt = min(dues)
-            if not res and nxt > now:
-                if realtime:
-                    sleep(min(nxt - now, 0.25))
+            if not res:
+                if nxt > now:
+                    if realtime:
+                        sleep(min(nxt - now, 0.25))
+                    else:
+                        now = nxt
                 else:
-                    now = nxt
+                    # Nothing ran although a stream claims to be due (it cannot happen with the end-of-video rules above; kept
+                    # as a guard): never spin -- wait a tick in real time, step the offline clock, and after a few fruitless
+                    # rounds end the streams that claim to be due.
+                    stalls += 1
+                    if stalls > 8:
+                        for sid in list(self.streams):
+                            d = self.due_time(sid)
+                            if d is not None and d <= now:
+                                self.streams[sid].ended = True
+                        stalls = 0
+                    elif realtime:
+                        sleep(0.01)
+                    else:
+                        now += protocol.FRAME_TIME_INTERVAL
+            else:
+                stalls = 0
         return out

@@ -59,10 +59,12 @@ class TextFrontEnd:
         self.tokenizer = tok = tokenizer_or_path
         self.video_token_id = tok.convert_tokens_to_ids(VIDEO_PAD)
         self.eos_token_id = tok.convert_tokens_to_ids(IM_END)
+        self.endoftext_token_id = tok.convert_tokens_to_ids("<|endoftext|>")
         if cfg is not None:
-            if cfg.video_token_id != self.video_token_id or cfg.eos_token_id != self.eos_token_id:
-                raise ValueError(f"tokenizer special ids (video_pad {self.video_token_id}, im_end {self.eos_token_id}) do not match the "
-                                 f"model config ({cfg.video_token_id}, {cfg.eos_token_id})")
+            # config.json's eos is <|im_end|> for the instruct checkpoints and <|endoftext|> for base-style ones
+            if cfg.video_token_id != self.video_token_id or cfg.eos_token_id not in (self.eos_token_id, self.endoftext_token_id):
+                raise ValueError(f"tokenizer special ids (video_pad {self.video_token_id}, im_end {self.eos_token_id}, endoftext "
+                                 f"{self.endoftext_token_id}) do not match the model config ({cfg.video_token_id}, {cfg.eos_token_id})")
         self.merge = 2 if cfg is None else cfg.spatial_merge_size
         self.streaming_eos_token_id = tok(" ...").input_ids[-1]                        # ref demo/infer.py:49
         probe = self.apply_chat_template([{"role": "user", "content": [{"type": "text", "text": "livecc"}]}], add_generation_prompt=False)

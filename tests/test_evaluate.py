@@ -20,9 +20,11 @@ class FakeInfer:
     def __init__(self):
         self.calls = []
 
-    def live_cc_once_for_evaluation(self, frames, query=None, video_start=0.0, max_new_tokens=32, repetition_penalty=1.15, **kw):
-        self.calls.append((frames, query, video_start, max_new_tokens, repetition_penalty))
-        return [[video_start, video_start + 3, f"clip{frames}"], [video_start + 3, video_start + 4, " ..."]]
+    def live_cc_once_for_evaluation(self, query, video, video_start=0, video_end=None, remote_loader=None, max_new_tokens=32,
+                                    repetition_penalty=1.05):
+        # the reference's signature (ref demo/infer.py:245-253)
+        self.calls.append((video, query, video_start, max_new_tokens, repetition_penalty))
+        return [[video_start, video_start + 3, f"clip{video}"], [video_start + 3, video_start + 4, " ..."]]
 
 
 def test_strided_sharding_resume_and_merge(tmp_path):

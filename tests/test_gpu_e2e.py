@@ -405,7 +405,7 @@ def test_demo_infer_with_real_tokenizer_text_in_text_out(dev, tmp_path):
     assert infer.streaming_eos_token_id == tk(" ...").input_ids[-1]
     frames = torch.from_numpy(protocol.synth_frames(10, 56, 84, seed=9, layout="TCHW"))
     state, outs, lens = {}, [], []
-    for (a, b), text, state in infer.live_cc(frames, state, message="what is happening now?", max_new_tokens=6, force_length=True):
+    for (a, b), text, state in infer.live_cc_clip(frames, state, message="what is happening now?", max_new_tokens=6, force_length=True):
         assert isinstance(text, str)
         outs.append(((a, b), text))
         lens.append(len(state["past_ids"]))
@@ -415,7 +415,7 @@ def test_demo_infer_with_real_tokenizer_text_in_text_out(dev, tmp_path):
     assert full.count("<|im_start|>system") == 1 and full.count("Time=3.0-4.0s") == 1 and full.count("<|im_start|>assistant\n") == 3
     # a changed query is appended to the next turn
     more = torch.from_numpy(protocol.synth_frames(2, 56, 84, seed=10, layout="TCHW"))
-    (_, _), _, state = next(iter(infer.live_cc(more, state, message="and now?", max_new_tokens=4, force_length=True)))
+    (_, _), _, state = next(iter(infer.live_cc_clip(more, state, message="and now?", max_new_tokens=4, force_length=True)))
     assert tk.decode(state["past_ids"].tolist(), skip_special_tokens=False).count("and now?") == 1
     state["past_key_values"].release()
     # the front end's ids through the HF oracle: same logits (teacher-forced along the native tokens)
@@ -536,14 +536,14 @@ def test_reference_entry_point_from_a_checkpoint_directory(dev, tmp_path):
     assert infer.text is not None and infer.model.generation_config["top_k"] == 1 and infer.cfg.video_token_id == cfg.video_token_id
     frames = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=3, layout="TCHW"))
     state, texts = {}, []
-    for _, text, state in infer.live_cc(frames, state, message="what is happening now?", do_sample=True, max_new_tokens=5, force_length=True):
+    for _, text, state in infer.live_cc_clip(frames, state, message="what is happening now?", do_sample=True, max_new_tokens=5, force_length=True):
         texts.append(text)
     ids_a = state["past_ids"].tolist()
     state["past_key_values"].release()
     ref = LiveCCDemoInfer(model=LiveCCForConditionalGeneration.from_hf_model(hf, cfg, dev, max_streams=1, max_kv_len=2048, max_new_rows=1024,
                                                                               max_patches=4096, max_history=16), text=TextFrontEnd(tk, cfg))
     state2 = {}
-    for _, text, state2 in ref.live_cc(frames, state2, message="what is happening now?", do_sample=False, max_new_tokens=5, force_length=True):
+    for _, text, state2 in ref.live_cc_clip(frames, state2, message="what is happening now?", do_sample=False, max_new_tokens=5, force_length=True):
         pass
     assert ids_a == state2["past_ids"].tolist() and len(texts) == 2
     state2["past_key_values"].release()

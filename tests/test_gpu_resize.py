@@ -69,12 +69,13 @@ def test_live_cc_from_video_paces_like_the_reference(dev):
     g = torch.Generator().manual_seed(5)
     video = torch.randint(0, 256, (180, 60, 90, 3), dtype=torch.uint8, generator=g).to(dev)      # 6 s at 30 fps
     pts = np.arange(180) / 30.0
-    state, seen = {}, []
+    from livecc_amd.video import DecodedVideo
+    state, seen = {"video_path": DecodedVideo(video, pts, 30.0)}, []
     for wall in (0.4, 3.2, 3.3, 4.1, 5.6, 6.0, 7.0, 8.0):
-        for (a, b), text, state in infer.live_cc_from_video(video, pts, state, wall, max_pixels=4 * 28 * 28, max_new_tokens=3,
-                                                            force_length=True):
+        state["video_timestamp"] = wall                                  # the reference's calling convention (ref demo/cli.py:13-19)
+        for (a, b), text, state in infer.live_cc(None, state, max_pixels=4 * 28 * 28, max_new_tokens=3, force_length=True,
+                                                 do_sample=False):
             seen.append((wall, a, b))
-    assert state["resized_hw"] == (56, 84) or state["resized_hw"][0] % 28 == 0
     # wall 0.4: the first call waits for initial_time_interval (3 s) of video -> frames 0..2.5 s (ref infer.py:107-110)
     assert seen[0][1:] == (0.0, 3.0) and seen[0][0] == 0.4
     spans = [s[1:] for s in seen]

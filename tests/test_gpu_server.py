@@ -30,9 +30,11 @@ def test_batched_streams_equal_each_stream_alone(dev, native):
     alone = {}
     for sid, (v, pts) in vids.items():
         inf1 = LiveCCDemoInfer(model=native)
-        state, outs = {}, []
+        from livecc_amd.video import DecodedVideo
+        state, outs = {"video_path": DecodedVideo(v, pts, 30.0)}, []
         for wall in np.arange(0.0, 9.0, 0.25):
-            for (a, b), text, state in inf1.live_cc_from_video(v, pts, state, wall, max_pixels=4 * 28 * 28, max_new_tokens=4, force_length=True):
+            state["video_timestamp"] = float(wall)
+            for (a, b), text, state in inf1.live_cc(None, state, max_pixels=4 * 28 * 28, max_new_tokens=4, force_length=True, do_sample=False):
                 outs.append(((a, b), text))
         state["past_key_values"].release()
         alone[sid] = outs

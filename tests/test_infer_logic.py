@@ -1,0 +1,161 @@
+"""Host logic of the `LiveCCDemoInfer` facade with the REFERENCE's signatures (ref demo/infer.py:61-310), on a stand-in model
+(no GPU): pacing from state['video_path'] / state['video_timestamp'], chunking, query-on-change, slot release, stateless
+hf_spaces mode.  The arithmetic behind `generate` is covered by the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+from livecc_amd import infer as I, protocol, resize as R, video as V
+from livecc_amd.config import tiny
+from livecc_amd.modeling import GenerateOutput, StreamState
+
+
+class _Engine:
+    max_slots, max_history = 1, 512
+
+    def __init__(self):
+        self.len = {0: 0}
+
+    def slot_length(self, slot):
+        return self.len[slot], 0
+
+
+class FakeModel:
+    def __init__(self):
+        self.cfg = tiny()
+        self.device = torch.device("cpu")
+        self.engine = _Engine()
+        self._free_slots = [0]
+        self.eos_token_ids = [self.cfg.eos_token_id]
+        self.generation_config = {}
+        self.calls = []
+
+    def new_stream(self):
+        if not self._free_slots:
+            raise RuntimeError("all 1 stream slots are in use (raise max_streams)")
+        st = StreamState(self, self._free_slots.pop())
+        self.engine.len[st.slot] = 0
+        return st
+
+    def generate(self, input_ids=None, frames=None, past_key_values=None, max_new_tokens=16, **kw):
+        st = past_key_values or self.new_stream()
+        assert input_ids.shape[1] > st.get_seq_length()
+        new = torch.arange(max_new_tokens) + 7
+        seq = torch.cat([input_ids[0], new])
+        self.engine.len[st.slot] = len(seq) - 1
+        self.calls.append(dict(n_in=input_ids.shape[1], frames=None if frames is None else tuple(frames.shape), kw=kw,
+                               max_new_tokens=max_new_tokens, had_state=past_key_values is not None))
+        return GenerateOutput(sequences=seq.view(1, -1), past_key_values=st)
+
+
+@pytest.fixture()
+def infer(monkeypatch):
+    def fake_clip(frames, h, w, ts, pts, index_from, layout="THWC"):
+        idxs, kept = R.select_clip_frames(ts, pts, index_from)
+        return (torch.zeros(len(idxs), 3, h, w, dtype=torch.uint8) if idxs else None), kept, idxs
+    monkeypatch.setattr(R, "get_smart_resized_clip", fake_clip)
+
+    def fake_resize(video, nframes=None, device=None):
+        n = nframes or video.shape[0]
+        h, w = V.spatial_resize_hw(int(video.shape[2]), int(video.shape[3]), int(n))
+        return torch.zeros(video.shape[0], 3, h, w, dtype=torch.uint8)
+    monkeypatch.setattr(V, "spatial_resize_video", fake_resize)
+    return I.LiveCCDemoInfer(model=FakeModel())
+
+
+def _video(n, fps=30.0, h=60, w=90):
+    return V.DecodedVideo(torch.zeros(n, h, w, 3, dtype=torch.uint8), np.arange(n) / fps, fps)
+
+
+def test_live_cc_runs_the_reference_cli_loop_unmodified(infer):
+    """ref demo/cli.py:10-24 verbatim, given a decoded video registered under the path."""
+    V.register_video("demo/sources/x.mp4", _video(300))            # 10 s
+    try:
+        state = {"video_path": "demo/sources/x.mp4"}
+        commentaries = []
+        for t in range(31):
+            state["video_timestamp"] = t
+            for (start_t, stop_t), response, state in infer.live_cc(
+                    message="Please describe the video.", state=state, max_pixels=4 * 28 * 28, repetition_penalty=1.05,
+                    streaming_eos_base_threshold=0.0, streaming_eos_threshold_step=0):
+                commentaries.append([start_t, stop_t, response])
+            if state.get("video_end", False):
+                break
+    finally:
+        V.unregister_video("demo/sources/x.mp4")
+    spans = [(a, b) for a, b, _ in commentaries]
+    assert spans[0] == (0.0, 3.0) and spans[1:] == [(3.0 + i, 4.0 + i) for i in range(len(spans) - 1)]
+    assert spans[-1][1] <= 10.0 and state.get("video_end")
+    calls = infer.model.calls
+    assert calls[0]["frames"][0] == 6 and all(c["frames"][0] == 2 for c in calls[1:])
+    assert calls[0]["kw"]["do_sample"] is True and calls[0]["max_new_tokens"] == 16          # ref defaults (:68, :170)
+    assert not calls[0]["had_state"] and all(c["had_state"] for c in calls[1:])
+    assert state["last_timestamp"] == pytest.approx(spans[-1][1] - 0.5)
+
+
+def test_live_cc_without_a_video_or_before_the_next_frame_yields_nothing(infer):
+    assert list(infer.live_cc("q", {})) == []
+    vid = _video(300)
+    state = {"video_path": vid, "video_timestamp": 0}
+    first = list(infer.live_cc("q", state))
+    assert [s for s, _, _ in first] == [(0.0, 3.0)]                 # the first call always takes the initial 3 s
+    state["video_timestamp"] = 3.0
+    assert list(infer.live_cc("q", state)) == []                    # video clock has not passed the next frame time yet
+    state["video_timestamp"] = 3.2
+    assert [s for s, _, _ in infer.live_cc("q", state)] == [(3.0, 4.0)]
+    light = list(infer.live_cc("q", dict(state, video_timestamp=4.7), hf_spaces=True))[0][2]
+    assert "past_key_values" not in light and "past_ids" not in light and "last_timestamp" in light
+
+
+def test_live_cc_once_for_evaluation_twice_on_one_slot(infer):
+    """the KV slot of an offline replay must be free again when the call returns -- the offline driver calls
+    it once per record on a max_streams=1 model."""
+    vid = _video(600)                                               # 20 s at 30 fps
+    r1 = infer.live_cc_once_for_evaluation(query="commentate", video=vid, video_start=2.0, video_end=9.0, max_new_tokens=5,
+                                           repetition_penalty=1.15)
+    assert infer.model._free_slots == [0]
+    r2 = infer.live_cc_once_for_evaluation(query="commentate", video=vid, video_start=0, video_end=None)
+    assert infer.model._free_slots == [0]
+    # 7 s at ~2 fps -> 14 frames -> chunks 6,2,2,2,2; times are offset by video_start (ref :305-308)
+    assert [(a, b) for a, b, _ in r1] == [(2.0, 5.0), (5.0, 6.0), (6.0, 7.0), (7.0, 8.0), (8.0, 9.0)]
+    assert r2[0][:2] == [0.0, 3.0] and len(r2) == 1 + (40 - 6) // 2
+    calls = infer.model.calls
+    assert calls[0]["max_new_tokens"] == 5 and calls[0]["kw"]["repetition_penalty"] == 1.15
+    assert calls[0]["kw"]["do_sample"] is None                       # not passed by the reference: generation_config decides
+    assert calls[len(r1)]["max_new_tokens"] == 32 and not calls[len(r1)]["had_state"]
+    # an exception inside the loop must not leak the slot either
+    def boom(*a, **k):
+        raise RuntimeError("x")
+    infer.model.generate = boom
+    with pytest.raises(RuntimeError):
+        infer.live_cc_once_for_evaluation(query="q", video=vid)
+    assert infer.model._free_slots == [0]
+
+
+def test_video_qa_reference_signature(infer):
+    vid = _video(300)
+    state = {"video_path": vid}
+    resp, state = infer.video_qa(5, [], state, max_new_tokens=4)     # synthetic mode: message = query length
+    c0 = infer.model.calls[0]
+    assert c0["frames"] is not None and c0["frames"][0] == 20 and c0["kw"]["do_sample"] is False
+    assert state["past_ids"] is not None and isinstance(resp, str)
+    resp2, state = infer.video_qa(3, [], state, max_new_tokens=4)
+    c1 = infer.model.calls[1]
+    assert c1["frames"] is None and c1["had_state"] and c1["n_in"] > c0["n_in"]
+    # default budget of the reference: 512 new tokens
+    infer.video_qa(3, [], state)
+    assert infer.model.calls[2]["max_new_tokens"] == 512
+    # stateless mode keeps nothing and frees the slot
+    st2 = {"video_path": vid}
+    state["past_key_values"].release()
+    _, st2 = infer.video_qa(4, [], st2, hf_spaces=True, max_new_tokens=2)
+    assert st2["past_key_values"] is None and st2["past_ids"] is None and infer.model._free_slots == [0]
+
+
+def test_clip_level_entry_point_keeps_the_stream_clock(infer):
+    state = {}
+    clip = torch.zeros(10, 3, 56, 84, dtype=torch.uint8)
+    spans = [s for s, _, _ in infer.live_cc_clip(clip, state, max_new_tokens=3)]
+    assert spans == [(0.0, 3.0), (3.0, 4.0), (4.0, 5.0)] and state["last_timestamp"] == 4.5
+    spans = [s for s, _, _ in infer.live_cc_clip(clip[:4], state, max_new_tokens=3)]
+    assert spans == [(5.0, 6.0), (6.0, 7.0)]

@@ -93,3 +93,30 @@ def test_catch_up_and_drop(srv):
         full.add_stream(i, *_video(60))
     with pytest.raises(RuntimeError):
         full.add_stream(9, *_video(60))
+
+
+@pytest.mark.parametrize("n_frames", [121, 91, 106, 151])
+@pytest.mark.timeout(20)
+def test_run_terminates_when_the_last_pts_sits_on_a_half_second(srv, n_frames):
+    """pts[-1] == last_timestamp + 0.5 exactly (121 frames at 30 fps -> 4.0 s) used to spin forever: the video clock is
+    clamped to pts[-1], the end test was a strict `>`, and the loop neither slept nor advanced."""
+    srv.add_stream("v", *_video(n_frames), t_start=0.0, max_pixels=4 * 28 * 28)
+    out = srv.run(realtime=False)
+    assert srv.streams["v"].ended
+    spans = [span for _, span, _, _ in out]
+    assert spans[0] == (0.0, 3.0) and all(b - a == 1.0 for a, b in spans[1:])
+    # every full 2-frame pair whose frames exist was served, nothing beyond the video
+    assert spans[-1][1] <= (n_frames - 1) / 30.0 + 1.0
+
+
+@pytest.mark.timeout(20)
+def test_run_realtime_never_spins(srv):
+    srv.add_stream("v", *_video(121), t_start=0.0, max_pixels=4 * 28 * 28)
+    t = [0.0]
+    sleeps = []
+
+    def sleep(dt):
+        sleeps.append(dt)
+        t[0] += dt
+    out = srv.run(realtime=True, clock=lambda: t[0], sleep=sleep, t0=0.0)
+    assert srv.streams["v"].ended and len(out) >= 1 and len(sleeps) < 200
