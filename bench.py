@@ -4,18 +4,28 @@
 Workload (BASELINE.json configs[1]): LiveCC-7B shapes, one video stream per GPU replayed back-to-back, 2 fps,
 60 frames at 392x728 (28x52 patch grid): one 6-frame turn + 27 two-frame turns, 16 greedy tokens per turn
 (min_new_tokens = max_new_tokens, repetition_penalty 1.05) -> 448 commentary tokens, KV grows to ~12k.
-Synthetic frames / prompt ids, random weights of the real architecture (no network: SURVEY 8d).
+Synthetic frames / prompt ids, seeded synthetic weights of the real architecture (no network: SURVEY 8d).
+`--streams-per-gpu 8 --gpus 8` is BASELINE.json configs[2] (64 streams data-parallel over 8 GPUs).
 
 A "step" = one complete replay of the stream(s) on every rank (frames already resident in HBM).  One JSON line on
-rank 0; `value` = commentary tokens/s summed over all streams of all GPUs.  `roofline` = the dominant kernel (decode
-gate/up weight-streaming GEMV, HBM-bound) timed live with HIP events on its launch stream inside the timed region;
-`cpu_baseline` = the HF CPU oracle (the reference's arithmetic) at the same 7B shapes on the host cores, one
-streaming turn (bounded sample).
+rank 0; `value` = commentary tokens/s summed over all streams of all GPUs.
+  `roofline`     = the dominant kernel (decode gate/up weight-streaming GEMV, HBM-bound) timed live with HIP events on its
+                   launch stream inside the timed region; `decode_step` next to it = whole decode steps (weights + KV bytes
+                   over the measured step time) against the same 8 TB/s;
+  `cpu_baseline` = the HF CPU path (the reference's arithmetic) at the same 7B shapes on the host cores through the same
+                   protocol: the 6-frame turn + one 2-frame turn on the carried KV (bounded sample), prefill / decode rates;
+  `parity`       = that CPU run teacher-forced along the native tokens with the SAME seeded weights: worst |dlogit| relative to
+                   the logit scale and the number of steps where the native token is the CPU path's own argmax.
+
+`--gpus N` with N > 1 launches N ranks by itself (python -m torch.distributed.run, one process per GPU over RCCL) when it is not
+already running under a launcher; under torchrun it asserts WORLD_SIZE == N.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -34,7 +44,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--height", type=int, default=392)
     ap.add_argument("--width", type=int, default=728)
-    ap.add_argument("--streams-per-gpu", type=int, default=1)
+    ap.add_argument("--streams-per-gpu", type=int, default=1, help="8 with --gpus 8 = BASELINE.json configs[2] (64 streams)")
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--fused-tails", type=int, default=None, choices=[0, 1],
                     help="debug A/B: fuse add+rmsnorm / rope+append into the decode GEMV tails (default: library default)")
@@ -46,13 +56,60 @@ def parse():
     ap.add_argument("--gemv-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemv_variant")
     ap.add_argument("--attn-variant", type=int, default=None, help="debug A/B: lcc_debug_set_attn_variant")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
+    ap.add_argument("--decode-path", type=int, default=None, help="debug A/B: lcc_debug_set_decode_path")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock budget of the CPU baseline leg, seconds")
-    a = ap.parse_args()
+    ap.add_argument("--parity", choices=["auto", "off", "bf16", "full"], default="auto",
+                    help="compare the native path with the CPU reference leg on the same seeded weights (auto: when the CPU leg runs "
+                         "at the benchmarked shapes); full also runs the fp32 truth for the error-ratio test")
+    ap.add_argument("--standin", action="store_true",
+                    help="launcher self-test: a stand-in model on CPU ranks over gloo (no GPU work, numbers meaningless)")
+    a = ap.parse_args(argv)
     if a.workload == "long480":
         a.frames, a.height, a.width, a.max_new_tokens = 480, 280, 280, 12
     return a
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N starts N ranks by itself (ref evaluation/livesports3kcc/distributed_generate_livecc.py:105-122 fans out
+# with local_mp; here one process per GPU under torch.distributed.run so that RCCL can broadcast the weights)
+# ------------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["LCC_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class StandInModel:
+    """Launcher self-test only (`--standin`): answers generate_batch with fixed tokens after a short sleep.  NOT a CPU path of the
+    product -- it computes nothing."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.engine = None
+
+    class _KV:
+        def release(self):
+            pass
+
+    def generate_batch(self, reqs, max_new_tokens=16, **kw):
+        time.sleep(0.002)
+        outs = []
+        for r in reqs:
+            seq = torch.cat([torch.as_tensor(r["input_ids"]).view(-1), torch.arange(max_new_tokens) + 5]).view(1, -1)
+            outs.append(type("O", (), {"sequences": seq, "past_key_values": r.get("state") or self._KV()})())
+        return outs
 
 
 def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod):
@@ -82,18 +139,34 @@ def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod)
     return tokens, n * nframes
 
 
-def cpu_baseline(cfg_name, args, budget_s=240.0):
-    """The reference's CPU path (HF generate, bf16, SDPA) on the host cores, one streaming turn at `cfg_name` shapes, run
-    by oracle/cpu_baseline.py in a subprocess under a wall-clock budget.  The child reports every generated token, so a
-    run cut by the budget still yields measured prefill time and decode rate (then the 16-token turn is extrapolated
-    and the `sample` string says so)."""
-    import subprocess
+def kv_lengths_of_decode_steps(cfg, nframes, height, width, max_new, protocol):
+    """KV length seen by every decode step of one stream replay (for the decode_step roofline's KV bytes)."""
+    b = protocol.TurnBuilder(cfg, seed=0)
+    kv, out = 0, []
+    for ti, (a, e) in enumerate(protocol.split_clip(nframes)):
+        grid = protocol.grid_of(e - a, height, width, cfg)
+        kv += len(b.turn_ids(ti, protocol.num_video_tokens(grid, cfg)))
+        for k in range(1, max_new):          # decode step k appends the k-th generated token and attends to kv + k keys
+            out.append(kv + k)
+        kv += max_new - 1                     # past_ids = sequences[:, :-1]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU reference leg (oracle/cpu_baseline.py in a subprocess under a wall-clock budget) + parity against it
+# ------------------------------------------------------------------------------------------------------------------------
+def run_cpu_leg(cfg_name, args, budget_s, turns, teacher=None, logits_out=None, dtype="bfloat16"):
+    import selectors
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", cfg_name, "--height", str(args.height),
-           "--width", str(args.width), "--max-new-tokens", str(args.max_new_tokens)]
+           "--width", str(args.width), "--max-new-tokens", str(args.max_new_tokens), "--turns", str(turns), "--dtype", dtype,
+           "--weights", "tiled:0", "--seed", "1234"]
+    if teacher is not None:
+        cmd += ["--teacher", teacher]
+    if logits_out is not None:
+        cmd += ["--logits-out", logits_out]
     t_start = time.perf_counter()
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     ev = []
-    import selectors
     sel = selectors.DefaultSelector()
     sel.register(p.stdout, selectors.EVENT_READ)
     cut = False
@@ -115,138 +188,268 @@ def cpu_baseline(cfg_name, args, budget_s=240.0):
             pass
         if ev and ev[-1].get("event") == "done":
             break
-    if p.poll() is None:
+    if p.poll() is None and (cut or not (ev and ev[-1].get("event") == "done")):
         p.kill()          # exactly the child we started
     p.wait()
+    return ev, cut
+
+
+def cpu_baseline(cfg_name, args, budget_s=240.0, turns=2, teacher=None, logits_out=None):
+    """The reference's CPU path (HF generate, bf16, SDPA) on the host cores through the benchmark's own protocol: the 6-frame
+    first turn and `turns - 1` two-frame turns on the carried KV.  The child reports every generated token, so a run cut by the
+    budget still yields measured prefill time and decode rate (then the remaining tokens are extrapolated and `sample` says so)."""
+    ev, cut = run_cpu_leg(cfg_name, args, budget_s, turns, teacher, logits_out)
     info = next((e for e in ev if e["event"] == "start"), {})
-    inputs = next((e for e in ev if e["event"] == "inputs"), {})
     built = next((e for e in ev if e["event"] == "built"), None)
-    toks = [e for e in ev if e["event"] == "token"]
-    done = next((e for e in ev if e["event"] == "done"), None)
     n = args.max_new_tokens
-    # `cores` = the threads the baseline actually used (torch's intra-op pool), not the logical CPU count of the box
     base = dict(unit="tokens/s/stream", cores=info.get("threads", info.get("cores", os.cpu_count())), logical_cpus=info.get("cores"),
                 kind="reference", cpu=info.get("cpu", ""), build_seconds=built["seconds"] if built else None)
-    what = (f"HF transformers CPU path (bf16, sdpa, {info.get('threads', '?')} threads) at {cfg_name} shapes: one streaming turn = "
-            f"ViT on 2 frames ({inputs.get('patches', '?')} patches) + {inputs.get('prompt_tokens', '?')}-token prefill + {n} greedy tokens")
-    if done is not None:
-        dt = done["t"]
-        return dict(base, value=round(n / dt, 4), frames_per_s=round(2 / dt, 4), seconds=dt, sample=what)
-    if len(toks) >= 2:
+    per_turn, total_t, total_tok, total_frames, notes = [], 0.0, 0, 0, []
+    for ti in range(turns):
+        inp = next((e for e in ev if e["event"] == "inputs" and e.get("turn") == ti), None)
+        toks = [e for e in ev if e["event"] == "token" and e.get("turn") == ti]
+        done = next((e for e in ev if e["event"] == "turn_done" and e.get("turn") == ti), None)
+        if inp is None or not toks:
+            break
         prefill = toks[0]["t"]
-        per_tok = (toks[-1]["t"] - toks[0]["t"]) / (len(toks) - 1)
-        dt = prefill + per_tok * n
-        return dict(base, value=round(n / dt, 4), frames_per_s=round(2 / dt, 4), seconds=round(dt, 2),
-                    sample=what + f"; cut by the {budget_s:.0f}s budget after {len(toks)} tokens: prefill {prefill:.1f}s measured, "
-                                  f"decode {per_tok:.2f}s/token measured, turn time extrapolated")
-    return dict(base, value=None, sample=what + f"; nothing measurable inside the {budget_s:.0f}s budget "
-                                                f"(built={built is not None}, tokens={len(toks)}, cut={cut}, events={ev[-3:]})")
+        if done is not None:
+            dt, per_tok = done["t"], (done["t"] - prefill) / max(1, n - 1)
+        elif len(toks) >= 2:
+            per_tok = (toks[-1]["t"] - toks[0]["t"]) / (len(toks) - 1)
+            dt = prefill + per_tok * (n - 1)
+            notes.append(f"turn {ti} cut by the {budget_s:.0f}s budget after {len(toks)} tokens (remaining decode steps extrapolated)")
+        else:
+            break
+        frames = 6 if ti == 0 else 2
+        per_turn.append(dict(turn=ti, frames=frames, patches=inp["patches"], prompt_tokens=inp["prompt_tokens"], kv_before=inp["kv_before"],
+                             prefill_s=round(prefill, 3), decode_s_per_token=round(per_tok, 4), turn_s=round(dt, 3)))
+        total_t += dt; total_tok += n; total_frames += frames
+    what = (f"HF transformers CPU path (bf16, sdpa, {info.get('threads', '?')} threads) at {cfg_name} shapes through the benchmark protocol: "
+            + "; ".join(f"turn {t['turn']}: ViT on {t['frames']} frames ({t['patches']} patches) + {t['prompt_tokens']}-token prefill on "
+                        f"{t['kv_before']} cached keys + {n} greedy tokens" for t in per_turn))
+    if not per_turn:
+        return dict(base, value=None, sample=what + f"; nothing measurable inside the {budget_s:.0f}s budget "
+                                                     f"(built={built is not None}, cut={cut}, events={ev[-3:]})")
+    return dict(base, value=round(total_tok / total_t, 4), frames_per_s=round(total_frames / total_t, 4), seconds=round(total_t, 2),
+                prefill_tokens_per_s=round(sum(t["prompt_tokens"] for t in per_turn) / sum(t["prefill_s"] for t in per_turn), 2),
+                decode_tokens_per_s=round(1.0 / (sum(t["decode_s_per_token"] for t in per_turn) / len(per_turn)), 4),
+                turns=per_turn, sample=what + ("; " + "; ".join(notes) if notes else ""))
+
+
+def native_parity_turns(model, cfg, args, protocol, turns, dev):
+    """The same `turns` of stream 0 on the MI355X with raw logits kept: (tokens [turns, N], logits [turns, N, V] fp32)."""
+    n_frames = 6 + 2 * (turns - 1)
+    frames = torch.from_numpy(protocol.synth_frames(n_frames, args.height, args.width, seed=1234)).to(dev)
+    builder = protocol.TurnBuilder(cfg, seed=1234)
+    state, past, toks, logits = None, None, [], []
+    for ti, (a, b) in enumerate(protocol.split_clip(n_frames)):
+        if ti >= turns:
+            break
+        grid = protocol.grid_of(b - a, args.height, args.width, cfg)
+        new = builder.turn_ids(ti, protocol.num_video_tokens(grid, cfg))
+        ids = new if past is None else np.concatenate([past, new])
+        r = model.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames[a:b], frames_layout="THWC", past_key_values=state,
+                           repetition_penalty=1.05, max_new_tokens=args.max_new_tokens, min_new_tokens=args.max_new_tokens,
+                           output_logits=True, do_sample=False)
+        state = r.past_key_values
+        seq = r.sequences[0].cpu().numpy()
+        past = seq[:-1]
+        toks.append(seq[len(ids):].tolist())
+        logits.append(r.logits.float().cpu().numpy())
+    state.release()
+    return np.asarray(toks), np.stack(logits)
+
+
+def parity_report(native_tokens, native_logits, ref, ref32=None):
+    """ref / ref32: npz of oracle/cpu_baseline.py (`logits` [turns, N, V], `own_argmax` [turns, N]).  Only complete turns count."""
+    lg, own = ref["logits"], ref["own_argmax"]
+    t = min(lg.shape[0], native_logits.shape[0])
+    nl, lg, own, nt = native_logits[:t], lg[:t], own[:t], native_tokens[:t]
+    scale = np.abs(lg).max(axis=-1)                                     # per step
+    d16 = np.abs(nl - lg).max(axis=-1)
+    out = dict(turns_compared=int(t), steps=int(d16.size), weights="identical seeded bf16 weights on both sides (tiled:0)",
+               rel_dlogit_vs_bf16=round(float((d16 / scale).max()), 5), mean_rel_dlogit_vs_bf16=round(float((d16 / scale).mean()), 5),
+               tokens_equal=int((nt == own).sum()), tokens_total=int(nt.size))
+    if ref32 is not None:
+        l32 = ref32["logits"][:t]
+        e_native = np.abs(nl - l32).max(axis=-1)
+        e_ref = np.abs(lg - l32).max(axis=-1)
+        s32 = np.abs(l32).max(axis=-1)
+        out["err_ratio_vs_fp32"] = round(float((e_native / np.maximum(e_ref, 1e-3 * s32)).max()), 4)
+        out["rel_err_native_vs_fp32"] = round(float((e_native / s32).max()), 5)
+        out["rel_err_reference_bf16_vs_fp32"] = round(float((e_ref / s32).max()), 5)
+        # a native token must be the fp32 argmax wherever the fp32 top-1/top-2 margin exceeds the bf16 reference's own error
+        srt = np.sort(l32, axis=-1)
+        margin = srt[..., -1] - srt[..., -2]
+        decided = margin > 2 * e_ref
+        out["tokens_decided_by_margin"] = int(decided.sum())
+        out["tokens_equal_where_decided"] = int(((nt == ref32["own_argmax"][:t]) & decided).sum())
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     from livecc_amd import distributed as D, protocol
     from livecc_amd.config import get_config
-    from livecc_amd.modeling import LiveCCForConditionalGeneration
-    from livecc_amd.weights import WeightArena
-    rank, local, world = D.init_from_env()
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(dev)
+    rank, local, world = D.init_from_env(backend="gloo" if args.standin else None)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: pass --gpus {world} or let "
+                         f"bench.py launch the ranks itself")
     cfg = get_config(args.config)
     spg = args.streams_per_gpu
-
-    # weights: generated on rank 0, broadcast once over RCCL/xGMI -- no collective afterwards
     fp8 = args.weights == "fp8"
-    arena = WeightArena(cfg, dev, llm_fp8=fp8)
-    if rank == 0:
-        arena.fill_random(seed=0)
-    bcast_s = D.broadcast_weights(arena.flat, src=0)
     n_tok_turn = (args.height // 28) * (args.width // 28)
-    kv_need = 32 * ((args.frames // 2 + 2) * (n_tok_turn + 64) // 32 + 4)
-    if args.fused_tails is not None:
-        from livecc_amd import _lib
-        _lib.load().lcc_debug_set_fused_tails(args.fused_tails)
-    if args.gemm_variant is not None:
-        from livecc_amd import ops
-        ops.set_gemm_variant(args.gemm_variant)
-    if args.attn_variant is not None:
-        from livecc_amd import ops
-        ops.set_attn_variant(args.attn_variant)
-    if args.gemv_variant is not None:
-        from livecc_amd import ops
-        ops.set_gemv_variant(args.gemv_variant)
-    model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
-                                           max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
-                                           max_history=max(16, args.max_new_tokens))
+    if args.standin:
+        dev = torch.device("cpu")
+        model, bcast_s, arena = StandInModel(cfg), 0.0, None
+        t = torch.zeros(4)
+        bcast_s = D.broadcast_weights(t if rank == 0 else t)      # exercises the broadcast path over gloo
+    else:
+        from livecc_amd.modeling import LiveCCForConditionalGeneration
+        from livecc_amd.weights import WeightArena
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        dev = torch.device(f"cuda:{local}")
+        torch.cuda.set_device(dev)
+        # weights: generated on rank 0, broadcast once over RCCL/xGMI (SURVEY 8e) -- no collective afterwards
+        arena = WeightArena(cfg, dev, llm_fp8=fp8)
+        if rank == 0:
+            arena.fill_tiled(seed=0)
+        bcast_s = D.broadcast_weights(arena.flat, src=0)
+        kv_need = 32 * ((args.frames // 2 + 2) * (n_tok_turn + 64) // 32 + 4)
+        from livecc_amd import _lib, ops
+        if args.fused_tails is not None:
+            _lib.load().lcc_debug_set_fused_tails(args.fused_tails)
+        if args.gemm_variant is not None:
+            ops.set_gemm_variant(args.gemm_variant)
+        if args.attn_variant is not None:
+            ops.set_attn_variant(args.attn_variant)
+        if args.gemv_variant is not None:
+            ops.set_gemv_variant(args.gemv_variant)
+        if args.decode_path is not None:
+            _lib.check(_lib.load().lcc_debug_set_decode_path(args.decode_path), "lcc_debug_set_decode_path")
+        model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
+                                               max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
+                                               max_history=max(16, args.max_new_tokens))
     frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + rank * spg + i)).to(dev)
               for i in range(spg)]
     seeds = [1234 + rank * spg + i for i in range(spg)]
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
 
     for _ in range(args.warmup):
         replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
-    model.engine.profile(True, 8192)
+    if model.engine is not None:
+        model.engine.profile(True, 16384)
     D.barrier(dev)
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     toks = nfr = 0
     for _ in range(args.steps):
         a, b = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
         toks += a
         nfr += b
-    torch.cuda.synchronize(dev)
+    sync()
+    my_dt = time.perf_counter() - t0
     D.barrier(dev)
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
-    model.engine.profile(False)
+    if model.engine is not None:
+        model.engine.profile(False)
     total_tokens = D.sum_over_ranks(float(toks), dev)
     total_frames = D.sum_over_ranks(float(nfr), dev)
+    per_rank = D.gather_floats(toks / my_dt, dev)
+    bcast_max = D.max_over_ranks(bcast_s, dev)
     if rank != 0:
         return
-    ms = model.engine.profile_read(8192)
-    # dominant kernel: gemv_skinny_kernel<2,2> (gate/up + SwiGLU), algorithmic bytes per launch:
-    # weights 2I*H*2 + activations in M*H*2 + out M*I*2, M = streams per GPU
     I, H = cfg.intermediate_size, cfg.hidden_size
-    alg_bytes = 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + spg * H * 2 + spg * I * 2   # fp8: 1 B/weight + row scales
-    roof = None
-    if len(ms):
-        avg_ms = float(np.mean(ms))
-        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tp):
-            try:   # the committed PMC pass measured the LiveCC-7B bf16 single-stream launch; other shapes have no counter data
-                if cfg.name == "livecc-7b" and spg == 1 and not fp8:
-                    traffic = json.load(open(tp)).get("gemv_gate_up_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = dict(bound="hbm", kernel=("gemv_w8_kernel<2,2>" if fp8 else "gemv_skinny_kernel<2,2>") + " (decode gate/up + SwiGLU)", achieved=round(ach, 1), peak=8000.0,
-                    unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic, avg_launch_us=round(avg_ms * 1e3, 2),
-                    launches_timed=int(len(ms)), algorithmic_bytes_per_launch=alg_bytes)
-    cpu = None
-    want_cpu = args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)
+    roof = step_roof = None
+    if model.engine is not None:
+        ms = model.engine.profile_read(16384)
+        # dominant kernel: the decode gate/up weight-streaming GEMV (+ SwiGLU); algorithmic bytes per launch (DESIGN.md):
+        # weights 2I*H*2 + activations in M*H*2 + out M*I*2, M = streams per GPU
+        alg_bytes = 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + spg * H * 2 + spg * I * 2   # fp8: 1 B/weight + row scales
+        if len(ms):
+            avg_ms = float(np.mean(ms))
+            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tp):
+                try:   # the committed PMC pass measured the LiveCC-7B bf16 single-stream launch; other shapes have no counter data
+                    if cfg.name == "livecc-7b" and spg == 1 and not fp8:
+                        traffic = json.load(open(tp)).get("gemv_gate_up_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = dict(bound="hbm", kernel=("fp8 " if fp8 else "") + "decode gate/up weight-streaming GEMV + SwiGLU", achieved=round(ach, 1),
+                        peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic, avg_launch_us=round(avg_ms * 1e3, 2),
+                        launches_timed=int(len(ms)), algorithmic_bytes_per_launch=alg_bytes)
+        st_ms = model.engine.profile_read_steps(16384)
+        if len(st_ms):
+            # whole decode step: every Linear weight of the 28 layers + lm_head once for the batch, plus each stream's KV read and
+            # its new KV row written, plus the logits (SURVEY 8d "decode step" formula)
+            wbytes = (cfg.decode_weight_bytes() // 2) if fp8 else cfg.decode_weight_bytes()
+            kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
+            kv_avg = float(np.mean(kv_list)) if kv_list else 0.0
+            step_bytes = wbytes + spg * (kv_avg * cfg.kv_bytes_per_token + cfg.kv_bytes_per_token + cfg.vocab_size * 4)
+            s_ms = float(np.mean(st_ms))
+            ach = step_bytes / (s_ms * 1e-3) / 1e9
+            step_roof = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(ach, 1), frac=round(ach / 8000.0, 4),
+                             avg_step_us=round(s_ms * 1e3, 1), steps_timed=int(len(st_ms)), algorithmic_bytes_per_step=int(step_bytes),
+                             weight_bytes=int(wbytes), mean_kv_len=round(kv_avg, 1),
+                             us_per_layer=round((s_ms * 1e3) / cfg.num_hidden_layers, 2))
+            if roof is not None:
+                roof["decode_step"] = step_roof
+    cpu = par = None
+    want_cpu = (args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)) and not args.standin
     if want_cpu:
+        cpu_cfg = args.cpu_config or args.config
+        do_par = args.parity != "off" and cpu_cfg == args.config and not fp8
+        tmp = tempfile.mkdtemp(prefix="lcc_parity_")
         try:
             torch.cuda.empty_cache()
-            cpu = cpu_baseline(args.cpu_config or args.config, args, args.cpu_budget)
-            if cpu.get("value") is None and (args.cpu_config or args.config) != "qwen2vl-2b":
+            teacher = out16 = None
+            if do_par:
+                ntok, nlog = native_parity_turns(model, cfg, args, protocol, 2, dev)
+                teacher, out16 = os.path.join(tmp, "teacher.npy"), os.path.join(tmp, "ref16.npz")
+                np.save(teacher, ntok)
+            cpu = cpu_baseline(cpu_cfg, args, args.cpu_budget, 2, teacher, out16)
+            if do_par and os.path.exists(out16):
+                ref32 = None
+                if args.parity == "full":
+                    out32 = os.path.join(tmp, "ref32.npz")
+                    run_cpu_leg(cpu_cfg, args, 4 * args.cpu_budget, 2, teacher, out32, dtype="float32")
+                    ref32 = np.load(out32) if os.path.exists(out32) else None
+                par = parity_report(ntok, nlog, np.load(out16), ref32)
+            elif do_par:
+                par = dict(note="the CPU leg was cut by its budget before it could write its logits", turns_compared=0)
+            if cpu.get("value") is None and cpu_cfg != "qwen2vl-2b":
                 # BASELINE.json configs[0]: the reference's own CPU-runnable case is Qwen2-VL-2B
-                cpu = cpu_baseline("qwen2vl-2b", args, args.cpu_budget / 2)
+                cpu = cpu_baseline("qwen2vl-2b", args, args.cpu_budget / 2, 2)
         except Exception as e:  # the baseline must never take the bench line down
-            cpu = dict(value=None, unit="tokens/s/stream", cores=os.cpu_count(), kind="reference", sample=f"failed: {e!r}")
+            cpu = cpu or dict(value=None, unit="tokens/s/stream", cores=os.cpu_count(), kind="reference", sample=f"failed: {e!r}")
+        finally:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
     n_streams = world * spg
+    tag = ""
+    if cfg.name == "livecc-7b" and args.frames == 60 and args.workload == "stream60" and not fp8:
+        tag = " (BASELINE.json configs[1])" if spg == 1 else (" (BASELINE.json configs[2])" if n_streams == 64 else "")
+    if args.workload == "long480" and cfg.name == "livecc-7b":
+        tag = " (BASELINE.json configs[3]: 24k visual tokens, KV to ~32k)"
+    if cfg.name == "qwen2vl-72b" and fp8:
+        tag = " (BASELINE.json configs[4])"
     out = {
         "metric": f"commentary tokens/s (all streams) + frames/s ingested, {'LiveCC-7B' if cfg.name == 'livecc-7b' else cfg.name} streaming", "value": round(total_tokens / dt, 3),
         "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (fp8 e4m3 LLM weights, bf16 MFMA)" if fp8 else "bf16", "data": "synthetic frames + synthetic prompt ids, random weights of the real architecture",
-        "config": {"workload": f"{cfg.name} single stream per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
-                               f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05"
-                               + (" (BASELINE.json configs[1])" if cfg.name == "livecc-7b" and args.frames == 60 and args.workload == "stream60" and spg == 1 and not fp8 else "")
-                               + (" (BASELINE.json configs[3]: 24k visual tokens, KV to ~32k)" if args.workload == "long480" and cfg.name == "livecc-7b" else "")
-                               + (" (BASELINE.json configs[4])" if cfg.name == "qwen2vl-72b" and fp8 else ""),
+        "dtype": "bf16 (fp8 e4m3 LLM weights, bf16 MFMA)" if fp8 else "bf16",
+        "data": "standin (launcher self-test, no GPU work)" if args.standin else "synthetic frames + synthetic prompt ids, seeded synthetic weights of the real architecture",
+        "config": {"workload": f"{cfg.name} {spg} stream(s) per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
+                               f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05" + tag,
                    "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)"},
         "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
-        "weight_broadcast_s": round(bcast_s, 3), "roofline": roof, "cpu_baseline": cpu,
+        "weight_broadcast_s": round(bcast_max, 3), "rccl_ranks": world, "launcher": "self" if os.environ.get("LCC_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single"),
+        "tokens_per_s_per_rank": [round(x, 2) for x in per_rank],
+        "roofline": roof, "cpu_baseline": cpu, "parity": par,
     }
     print(json.dumps(out), flush=True)
 

@@ -217,6 +217,9 @@ int lcc_engine_weights_ready(const lcc_engine* e, char* missing, int missing_len
  * stream around up to max_samples launches; read back (blocking) as milliseconds per launch. */
 int lcc_engine_profile(lcc_engine* e, int enable, int max_samples);
 int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, int* n_out);
+/* the same switch also brackets every WHOLE decode step (28 layers + final norm + lm_head + sampler) with an event pair:
+ * milliseconds per decode step, for the step-level roofline (weights + KV bytes / step time) */
+int lcc_engine_profile_read_steps(lcc_engine* e, float* ms_out, int max_n, int* n_out);
 
 /* stream (slot) state */
 int lcc_slot_reset(lcc_engine* e, int slot, void* stream);                 /* new video stream: empty KV, empty history */

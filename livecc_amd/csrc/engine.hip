@@ -128,6 +128,8 @@ struct lcc_engine {
   // optional live timing of the dominant kernel (decode gate/up GEMV): hipEvent pairs on the launch stream
   std::vector<hipEvent_t> prof_ev;   // 2 * capacity
   int prof_n = 0; bool prof_on = false;
+  std::vector<hipEvent_t> step_ev;   // whole decode steps (layers + lm_head + sampler), 2 * capacity
+  int step_n = 0;
   // host mirrors
   std::vector<int> h_kv_len, h_pos;
   std::vector<void*> h_kv_base;
@@ -189,6 +191,7 @@ extern "C" void lcc_engine_destroy(lcc_engine* e) {
   if (!e) return;
   for (int i = 0; i < META_RING; ++i) if (e->meta_ev[i]) (void)hipEventDestroy(e->meta_ev[i]);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->step_ev) (void)hipEventDestroy(ev);
   delete e;
 }
 extern "C" int lcc_engine_profile(lcc_engine* e, int enable, int max_samples) {
@@ -199,7 +202,12 @@ extern "C" int lcc_engine_profile(lcc_engine* e, int enable, int max_samples) {
       HIP_TRY(hipEventCreate(&ev));
       e->prof_ev.push_back(ev);
     }
-    e->prof_n = 0;
+    while ((int)e->step_ev.size() < 2 * max_samples) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      e->step_ev.push_back(ev);
+    }
+    e->prof_n = 0; e->step_n = 0;
   }
   e->prof_on = enable != 0;
   return 0;
@@ -210,6 +218,16 @@ extern "C" int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, 
   for (int i = 0; i < n; ++i) {
     HIP_TRY(hipEventSynchronize(e->prof_ev[2 * i + 1]));
     HIP_TRY(hipEventElapsedTime(&ms_out[i], e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+  }
+  *n_out = n;
+  return 0;
+}
+extern "C" int lcc_engine_profile_read_steps(lcc_engine* e, float* ms_out, int max_n, int* n_out) {
+  if (!e || !ms_out || !n_out) return fail(LCC_ERR_ARG, "null argument");
+  const int n = std::min(e->step_n, max_n);
+  for (int i = 0; i < n; ++i) {
+    HIP_TRY(hipEventSynchronize(e->step_ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms_out[i], e->step_ev[2 * i], e->step_ev[2 * i + 1]));
   }
   *n_out = n;
   return 0;
@@ -797,6 +815,8 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
   cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
   for (int step = 0; step < n_steps; ++step) {
+    const bool prof_step = e->prof_on && 2 * (e->step_n + 1) <= (int)e->step_ev.size();
+    if (prof_step) HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n], st));
     // the token sampled by the previous step (d_cur_tok[slot]) is embedded, appended at kv_len[slot], position pos[slot]
     LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
     LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
@@ -804,6 +824,7 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
     LCC_TRY(run_layers(e, bf, cx, st));
     LCC_TRY(advance_lengths(d_slots, e->d_kv_len, e->d_pos, n_streams, e->d_done, st));
     LCC_TRY(head_and_sample(e, bf, bf.xn, n_streams, d_slots, sp, first_step_index + step, st));
+    if (prof_step) { HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n + 1], st)); e->step_n++; }
   }
   for (int b = 0; b < n_streams; ++b) { e->h_kv_len[slots[b]] += n_steps; e->h_pos[slots[b]] += n_steps; }
   return check_launch("lcc_llm_decode");

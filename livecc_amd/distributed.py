@@ -72,6 +72,17 @@ def sum_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device=None) -> List[float]:
+    """[value of rank 0, ..., value of rank W-1] on every rank (end-of-run counters only: never in the data path)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    w = dist.get_world_size()
+    t = torch.zeros(w, dtype=torch.float64, device=device if device is not None else "cpu")
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
 def barrier(device=None) -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         if device is not None and torch.device(device).type == "cuda":

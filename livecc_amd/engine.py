@@ -235,6 +235,13 @@ class Engine:
         _lib.check(self.lib.lcc_engine_profile_read(self.h, buf.ctypes.data, max_n, C.byref(n)), "lcc_engine_profile_read")
         return buf[:n.value]
 
+    def profile_read_steps(self, max_n: int = 4096) -> np.ndarray:
+        """Milliseconds of every whole decode step recorded while profiling was on."""
+        buf = np.zeros(max_n, dtype=np.float32)
+        n = C.c_int()
+        _lib.check(self.lib.lcc_engine_profile_read_steps(self.h, buf.ctypes.data, max_n, C.byref(n)), "lcc_engine_profile_read_steps")
+        return buf[:n.value]
+
     def generated_count(self, slot: int) -> int:
         """Blocking: number of tokens the slot has generated in the current generate call (stops growing after EOS)."""
         buf = np.zeros(1, dtype=np.int32)

@@ -199,6 +199,16 @@ class WeightArena:
         return self
 
     @torch.no_grad()
+    def fill_tiled(self, seed: int = 0) -> "WeightArena":
+        """Seeded synthetic weights that a CPU process can reproduce bit for bit WITHOUT a large RNG run: every HF parameter
+        is a window of one seeded 4,194,301-element (prime) bf16 block (`tiled_param`).  bench.py uses it so that the CPU
+        reference leg (oracle/cpu_baseline.py, HF model filled by the same function) computes with the SAME weights as the
+        MI355X arena and the two can be compared logit by logit at the full 7B shapes."""
+        shapes = hf_param_shapes(self.cfg)
+        dev = self.device
+        return self.load_state_dict(lambda name: tiled_param(name, shapes[name], seed, dev))
+
+    @torch.no_grad()
     def load_state_dict(self, sd_get: Callable[[str], torch.Tensor]) -> "WeightArena":
         """Fill from an HF state dict accessor (tensor by HF name; any float dtype; CPU or GPU)."""
         cfg = self.cfg
@@ -229,6 +239,86 @@ class WeightArena:
         put("final_norm", sd_get("language_model.norm.weight"))
         put("lm_head", sd_get("language_model.embed_tokens.weight") if cfg.tie_word_embeddings else sd_get("lm_head.weight"))
         return self
+
+
+TILE_PERIOD = 4194301      # prime: gcd with every row length is 1, so no two rows of any weight matrix are equal
+_TILE_BLOCKS: Dict[Tuple[int, str], torch.Tensor] = {}
+
+
+def _tile_block(seed: int, device) -> torch.Tensor:
+    key = (int(seed), str(device))
+    if key not in _TILE_BLOCKS:
+        g = torch.Generator(device="cpu").manual_seed(1000003 * int(seed) + 17)      # CPU generator: identical on every machine
+        _TILE_BLOCKS[key] = torch.randn(TILE_PERIOD, generator=g, dtype=torch.float32).to(device)
+    return _TILE_BLOCKS[key]
+
+
+def tiled_param(name: str, shape, seed: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """Parameter `name` (normalised HF name: visual.* / language_model.* / lm_head.weight) of the seeded synthetic model:
+    flat[i] = f(block[(offset(name) + i) mod TILE_PERIOD]) with f = 0.02 x for matrices, 1 + 0.1 x for norm weights and
+    0.05 x for biases (the scales of `fill_random` / HF's initializer_range), rounded to bf16.  Built from slice copies."""
+    import zlib
+    blk = _tile_block(seed, device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    off = zlib.crc32(name.encode()) % TILE_PERIOD
+    out = torch.empty(n, dtype=torch.float32, device=device) if n <= (1 << 26) else None
+    if len(shape) >= 2:
+        scale, shift = 0.02, 0.0
+    elif name.endswith("bias"):
+        scale, shift = 0.05, 0.0
+    else:
+        scale, shift = 0.1, 1.0
+    res = torch.empty(n, dtype=dtype, device=device)
+    pos = 0
+    while pos < n:                      # windows of the block, transformed piecewise (bounded fp32 staging)
+        k = min(TILE_PERIOD - off, n - pos)
+        seg = blk[off:off + k]
+        res[pos:pos + k] = (seg * scale + shift) if shift else (seg * scale)
+        pos += k
+        off = 0
+    del out
+    return res.view(*[int(d) for d in shape])
+
+
+def hf_param_shapes(cfg: LiveCCConfig) -> Dict[str, Tuple[int, ...]]:
+    """Shapes of the HF `Qwen2VLForConditionalGeneration` parameters under the normalised names `load_state_dict` reads."""
+    E, H, I, M = cfg.vit_embed_dim, cfg.hidden_size, cfg.intermediate_size, cfg.vit_mlp_dim
+    out: Dict[str, Tuple[int, ...]] = {"visual.patch_embed.proj.weight": (E, cfg.in_channels, cfg.temporal_patch_size, cfg.patch_size, cfg.patch_size)}
+    for i in range(cfg.vit_depth):
+        p = f"visual.blocks.{i}."
+        out.update({p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
+                    p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,),
+                    p + "mlp.fc1.weight": (M, E), p + "mlp.fc1.bias": (M,), p + "mlp.fc2.weight": (E, M), p + "mlp.fc2.bias": (E,)})
+    out.update({"visual.merger.ln_q.weight": (E,), "visual.merger.ln_q.bias": (E,), "visual.merger.mlp.0.weight": (4 * E, 4 * E),
+                "visual.merger.mlp.0.bias": (4 * E,), "visual.merger.mlp.2.weight": (H, 4 * E), "visual.merger.mlp.2.bias": (H,),
+                "language_model.embed_tokens.weight": (cfg.vocab_size, H)})
+    for i in range(cfg.num_hidden_layers):
+        p = f"language_model.layers.{i}."
+        out.update({p + "input_layernorm.weight": (H,), p + "post_attention_layernorm.weight": (H,),
+                    p + "self_attn.q_proj.weight": (cfg.q_dim, H), p + "self_attn.q_proj.bias": (cfg.q_dim,),
+                    p + "self_attn.k_proj.weight": (cfg.kv_dim, H), p + "self_attn.k_proj.bias": (cfg.kv_dim,),
+                    p + "self_attn.v_proj.weight": (cfg.kv_dim, H), p + "self_attn.v_proj.bias": (cfg.kv_dim,),
+                    p + "self_attn.o_proj.weight": (H, cfg.q_dim), p + "mlp.gate_proj.weight": (I, H), p + "mlp.up_proj.weight": (I, H),
+                    p + "mlp.down_proj.weight": (H, I)})
+    out["language_model.norm.weight"] = (H,)
+    if not cfg.tie_word_embeddings:
+        out["lm_head.weight"] = (cfg.vocab_size, H)
+    return out
+
+
+def fill_hf_model_tiled(hf_model, cfg: LiveCCConfig, seed: int = 0) -> None:
+    """Fill an instantiated (possibly `to_empty`) HF model with the weights of `WeightArena.fill_tiled(seed)` -- used by the CPU
+    reference leg of bench.py and by the full-shape parity tests (test infrastructure calls this; the product never does)."""
+    shapes = hf_param_shapes(cfg)
+    with torch.no_grad():
+        for k, p_ in hf_model.named_parameters():
+            name = _normalise_hf_key(k)
+            if name not in shapes:
+                raise KeyError(f"unexpected HF parameter {k}")
+            assert tuple(p_.shape) == tuple(shapes[name]), (k, tuple(p_.shape), shapes[name])
+            p_.copy_(tiled_param(name, shapes[name], seed, p_.device, dtype=torch.bfloat16).to(p_.dtype))
 
 
 def _normalise_hf_key(k: str) -> str:

@@ -1,12 +1,20 @@
-"""ORACLE / TEST INFRASTRUCTURE: CPU baseline leg of bench.py (never imported by the product).
+"""ORACLE / TEST INFRASTRUCTURE: CPU reference leg of bench.py and of the full-shape parity tests (never imported by the product).
 
-Times the reference's arithmetic -- HF `Qwen2VLForConditionalGeneration.generate` (ref demo/infer.py:165-172), bf16,
-SDPA, on the host cores -- on ONE streaming turn: ViT over 2 frames + prompt prefill + N greedy tokens, at the given
-shapes.  Run as a subprocess; prints one JSON object per line as it progresses (build, every generated token) so that
-the parent can report a measured or a partially-extrapolated rate inside a fixed wall-clock budget.
+Runs the reference's arithmetic -- HF `Qwen2VLForConditionalGeneration.generate` (ref demo/infer.py:165-172), SDPA attention, on
+the host cores -- through the reference's streaming protocol at the given shapes:
 
-Weights are filled by tiling a 4M-element random bf16 block (CPU throughput is data independent; initialising 8.3 B
-parameters with a CPU RNG takes minutes).
+    turn 0 : 6 frames (ViT over 3 temporal slices) + first prompt + N greedy tokens          ref demo/infer.py:121-129
+    turn 1 : 2 frames + '<|im_end|>\\n...' continuation prompt on the CARRIED KV + N tokens    ref demo/infer.py:159-174
+    ...
+
+Run as a subprocess; prints one JSON object per line as it progresses (build, every generated token) so that the parent can
+report a measured or a partially extrapolated rate inside a fixed wall-clock budget.
+
+Weights: `--weights tiled:<seed>` = the seeded synthetic model of `livecc_amd.weights.fill_hf_model_tiled` -- bit-identical to
+`WeightArena.fill_tiled(seed)` on the GPU, so the logits of this process ARE the oracle for the native path at full shapes.
+Parity mode: `--teacher tokens.npy` teacher-forces the generation along the native tokens ([turns, N] int) and `--logits-out`
+receives the raw lm_head logits of every step ([turns, N, V] fp32) plus this model's own argmax before forcing.
+`--dtype float32` = the fp32 truth for the error-ratio test (same bf16-representable weights).
 """
 import argparse
 import json
@@ -31,13 +39,22 @@ def main():
     ap.add_argument("--height", type=int, default=392)
     ap.add_argument("--width", type=int, default=728)
     ap.add_argument("--max-new-tokens", type=int, default=16)
+    ap.add_argument("--turns", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=1234, help="frames / prompt ids seed (bench stream 0)")
+    ap.add_argument("--weights", default="tiled:0")
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--teacher", default=None)
+    ap.add_argument("--logits-out", default=None)
     a = ap.parse_args()
+    import numpy as np
     import torch
-    from transformers import LogitsProcessorList, Qwen2VLForConditionalGeneration
+    from transformers import Qwen2VLForConditionalGeneration
     from livecc_amd import protocol
     from livecc_amd.config import get_config
+    from livecc_amd.weights import fill_hf_model_tiled
     from oracle import hf_oracle as O
     cfg = get_config(a.config)
+    dtype = getattr(torch, a.dtype)
     cores = os.cpu_count() or 1
     emit(event="imported", seconds=round(time.perf_counter() - T_IMPORT, 2))
     cpu_model = ""
@@ -49,23 +66,14 @@ def main():
                     break
     except OSError:
         pass
-    emit(event="start", cores=cores, threads=torch.get_num_threads(), cpu=cpu_model, config=cfg.name)
+    emit(event="start", cores=cores, threads=torch.get_num_threads(), cpu=cpu_model, config=cfg.name, dtype=a.dtype)
     t0 = time.perf_counter()
     with torch.device("meta"):
-        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=torch.bfloat16)
-    emit(event="meta_model", seconds=round(time.perf_counter() - t0, 2))
+        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=dtype)
     m = m.to_empty(device="cpu")
-    emit(event="allocated", seconds=round(time.perf_counter() - t0, 2))
-    blk = (torch.randn(1 << 22) * 0.02).to(torch.bfloat16)
+    assert a.weights.startswith("tiled:"), "only the seeded tiled synthetic weights are supported offline"
+    fill_hf_model_tiled(m, cfg, int(a.weights.split(":")[1]))
     with torch.no_grad():
-        for name, p in m.named_parameters():
-            flat = p.data.view(-1)
-            if p.dim() == 1:
-                flat.fill_(1.0 if name.endswith("weight") else 0.0)
-                continue
-            for o in range(0, flat.numel(), blk.numel()):
-                k = min(blk.numel(), flat.numel() - o)
-                flat[o:o + k].copy_(blk[:k])
         for name, buf in m.named_buffers():
             if "inv_freq" in name:
                 dim = buf.numel() * 2
@@ -76,29 +84,33 @@ def main():
     m.generation_config.top_k = m.generation_config.top_p = m.generation_config.temperature = None
     emit(event="built", seconds=round(time.perf_counter() - t0, 2))
 
-    frames = torch.from_numpy(protocol.synth_frames(2, a.height, a.width, seed=1234, layout="TCHW"))
-    pv, grid = O.patchify_normalize_ref(frames, cfg)
-    ids = protocol.TurnBuilder(cfg, seed=1234).turn_ids(0, protocol.num_video_tokens(grid, cfg))
-    emit(event="inputs", patches=int(pv.shape[0]), prompt_tokens=int(len(ids)))
+    n_frames = 6 + 2 * (a.turns - 1)
+    frames = torch.from_numpy(protocol.synth_frames(n_frames, a.height, a.width, seed=a.seed, layout="TCHW"))
+    builder = protocol.TurnBuilder(cfg, seed=a.seed)
+    teacher = np.load(a.teacher) if a.teacher else None
+    stream = O.OracleStream(m, cfg)
+    logits_all, own_all, tok_all = [], [], []
+    t_run0 = time.perf_counter()
+    for ti, (fa, fb) in enumerate(protocol.split_clip(n_frames)):
+        if ti >= a.turns:
+            break
+        pv, grid = O.patchify_normalize_ref(frames[fa:fb], cfg)
+        ids = builder.turn_ids(ti, protocol.num_video_tokens(grid, cfg))
+        emit(event="inputs", turn=ti, patches=int(pv.shape[0]), prompt_tokens=int(len(ids)), kv_before=0 if stream.past_ids is None else int(stream.past_ids.shape[1]))
+        t_turn = time.perf_counter()
+        n_prompt = (0 if stream.past_ids is None else stream.past_ids.shape[1]) + len(ids)
 
-    class Tick:
-        def __init__(self):
-            self.t0 = None
-
-        def __call__(self, input_ids, scores):
-            emit(event="token", i=int(input_ids.shape[1] - len(ids)), t=round(time.perf_counter() - self.t0, 4))
-            return scores
-
-    tick = Tick()
-    input_ids = torch.as_tensor(ids).view(1, -1)
-    kw = dict(pixel_values_videos=pv, video_grid_thw=torch.as_tensor([list(grid)]),
-              mm_token_type_ids=torch.as_tensor(protocol.mm_token_type_ids(input_ids.numpy(), cfg)))
-    tick.t0 = time.perf_counter()
-    with torch.inference_mode():
-        m.generate(input_ids=input_ids, do_sample=False, repetition_penalty=1.05, logits_processor=LogitsProcessorList([tick]),
-                   max_new_tokens=a.max_new_tokens, min_new_tokens=a.max_new_tokens, pad_token_id=cfg.eos_token_id,
-                   eos_token_id=cfg.eos_token_id, **kw)
-    emit(event="done", t=round(time.perf_counter() - tick.t0, 4))
+        def tick(input_ids, scores, _t=t_turn, _ti=ti, _np=n_prompt):
+            emit(event="token", turn=_ti, i=int(input_ids.shape[1] - _np), t=round(time.perf_counter() - _t, 4))
+        r = stream.turn(ids, pv, grid, max_new_tokens=a.max_new_tokens, repetition_penalty=1.05, force_length=True,
+                        teacher_tokens=None if teacher is None else teacher[ti].tolist(), tick=tick)
+        emit(event="turn_done", turn=ti, t=round(time.perf_counter() - t_turn, 4), tokens=r["new_tokens"])
+        logits_all.append(torch.stack(r["logits"]).numpy())
+        own_all.append([int(s.argmax()) for s in r["scores"]])
+        tok_all.append(r["new_tokens"])
+    if a.logits_out:
+        np.savez(a.logits_out, logits=np.stack(logits_all), own_argmax=np.asarray(own_all), tokens=np.asarray(tok_all))
+    emit(event="done", t=round(time.perf_counter() - t_run0, 4), turns=len(tok_all))
 
 
 if __name__ == "__main__":

@@ -169,7 +169,7 @@ class OracleStream:
     @torch.inference_mode()
     def turn(self, new_ids: Sequence[int], pixel_values: Optional[torch.Tensor], grid_thw,
              max_new_tokens: int = 16, repetition_penalty: float = 1.05, force_length: bool = True,
-             streaming_eos: Optional[tuple] = None, teacher_tokens: Optional[Sequence[int]] = None):
+             streaming_eos: Optional[tuple] = None, teacher_tokens: Optional[Sequence[int]] = None, tick=None):
         """Run one turn.  Returns dict(sequences, new_tokens, logits[list of fp32 [V]], scores)."""
         cfg, model = self.cfg, self.model
         new_ids_t = torch.as_tensor(np.asarray(new_ids), dtype=torch.long).view(1, -1)
@@ -188,6 +188,14 @@ class OracleStream:
             from transformers import LogitsProcessorList
             force = _ForceTokens(list(teacher_tokens), input_ids.shape[1])
             procs = LogitsProcessorList(([procs[0]] if procs is not None else []) + [force])
+        if tick is not None:      # progress callback (input_ids, scores) -> None, called once per generated token (CPU baseline timing)
+            from transformers import LogitsProcessorList
+
+            class _Tick:
+                def __call__(self, input_ids, scores):
+                    tick(input_ids, scores)
+                    return scores
+            procs = LogitsProcessorList(list(procs or []) + [_Tick()])
         # restore this stream's rope_deltas (HF keeps it on the module: modeling_qwen2_vl.py:857)
         model.model.rope_deltas = self.rope_deltas
         t0 = time.perf_counter()

@@ -1,0 +1,60 @@
+"""bench.py's launcher and report logic without a GPU: `--gpus N` starts N ranks by itself (one process per GPU under
+torch.distributed.run; here gloo ranks with a stand-in model), refuses a launcher/--gpus mismatch, and the parity / roofline
+helpers compute what they say."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+SMALL = ["--standin", "--steps", "1", "--warmup", "0", "--config", "tiny", "--frames", "10", "--height", "56", "--width", "84"]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_self_launches_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["launcher"] == "self" and out["scaling"] == "weak"
+    assert out["config"]["streams"] == 2 and len(out["tokens_per_s_per_rank"]) == 2
+    # 10 frames = 1 + 2 turns of 16 tokens per stream, 2 streams, one step
+    assert out["value"] == pytest.approx(2 * 3 * 16 / (out["ms_per_step"] / 1e3), rel=1e-3)
+
+
+@pytest.mark.timeout(120)
+def test_launcher_world_size_mismatch_is_refused():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_parity_report_and_kv_schedule():
+    sys.path.insert(0, ROOT)
+    import bench
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    rng = np.random.RandomState(0)
+    l32 = rng.randn(2, 4, 64).astype(np.float32) * 3
+    l16 = l32 + rng.randn(2, 4, 64).astype(np.float32) * 0.02
+    nat = l32 + rng.randn(2, 4, 64).astype(np.float32) * 0.02
+    tok = l16.argmax(-1)
+    rep = bench.parity_report(tok, nat, dict(logits=l16, own_argmax=tok), dict(logits=l32, own_argmax=l32.argmax(-1)))
+    assert rep["tokens_equal"] == 8 and rep["tokens_total"] == 8 and rep["turns_compared"] == 2
+    assert 0 < rep["rel_dlogit_vs_bf16"] < 0.05 and 0.3 < rep["err_ratio_vs_fp32"] < 3.0
+    assert rep["tokens_equal_where_decided"] <= rep["tokens_decided_by_margin"] <= 8
+    cfg = tiny()
+    kv = bench.kv_lengths_of_decode_steps(cfg, 10, 56, 84, 4, protocol)
+    b = protocol.TurnBuilder(cfg, seed=0)
+    n0 = len(b.turn_ids(0, protocol.num_video_tokens(protocol.grid_of(6, 56, 84, cfg), cfg)))
+    assert kv[:3] == [n0 + 1, n0 + 2, n0 + 3] and len(kv) == 3 * 3
