@@ -68,6 +68,10 @@ int lcc_debug_set_attn_variant(int variant);
 /* 1: on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add + RMSNorm) run as the
  * TAIL of that GEMV in its last-arriving block (agent-scope release/acquire); 0 (default, measured faster): separate kernels */
 int lcc_debug_set_fused_tails(int on);
+/* decode launch sequence of the engine: 1 (default) = pipeline v2 where eligible (bf16 weights, the row-permuted decode copy
+ * "llm.<i>.qkv_w_dec" of every q|k|v weight set): RMSNorm / bias + M-RoPE + KV append / residual add run inside the weight-streaming
+ * GEMVs, 6 launches per layer; 0 = the round-1 sequence of 9 launches per layer (also used with fp8 weights) */
+int lcc_debug_set_decode_path(int path);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
  * [N/16][K/64][4 g][16 rows][16 k] (lane (g,row) owns 16 consecutive k), wscale = fp32 [N] per-output-row scale:

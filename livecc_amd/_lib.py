@@ -90,6 +90,7 @@ def load():
         "lcc_debug_set_gemm_variant": (i32, [i32]),
         "lcc_debug_set_attn_variant": (i32, [i32]),
         "lcc_debug_set_fused_tails": (i32, [i32]),
+        "lcc_debug_set_decode_path": (i32, [i32]),
         "lcc_gemv_num_splits": (i32, [i32, i32]),
         "lcc_debug_mfma_probe": (i32, [vp, vp, vp, vp]),
         "lcc_patchify_norm_u8": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp]),

@@ -1,0 +1,296 @@
+// Decode layer pipeline v2 (M <= 16 rows = one new token per stream): the 9-launch decoder layer of round 1
+//
+//     qkv GEMV -> rope_kv_append -> attn_decode -> combine -> o GEMV -> add_rmsnorm -> gate/up GEMV -> down GEMV -> add_rmsnorm
+//
+// becomes 6 launches by moving every elementwise stage into the GEMV that produces or consumes its data:
+//
+//     [RMSNorm] qkv GEMV [bias + M-RoPE + KV append] -> attn_decode -> combine -> o GEMV [residual add + sum of squares]
+//       -> [RMSNorm] gate/up GEMV [SwiGLU] -> down GEMV [residual add + sum of squares]
+//
+// Measured on MI355X (rocprofv3 kernel trace of the round-1 path, LiveCC-7B, one stream): the three removed launches
+// (rope_kv_append 4.7 us, add_rmsnorm 4.1 + 4.7 us) move < 100 KB each -- pure launch + dependent-round-trip latency, 13 % of a
+// 104-us layer.  What makes the fusion free of cross-block reductions:
+//   * o_proj and down_proj run WITHOUT an inter-block K split (8 waves per block split K inside the block and merge through
+//     LDS), so a block owns 16 finished rows of the residual stream: it adds the residual in place (HF rounding: Linear output
+//     -> bf16, residual + output -> bf16, Q2VL:594-612) and emits the sum of squares of its 16 new values.  The RMSNorm row
+//     statistic of the NEXT GEMV is then 224 floats (H/16) per row instead of a re-read of split-K slabs.
+//   * the consumer GEMV builds its activation fragments on the fly: x = bf16(w * bf16(h * rsqrt(mean(h^2) + eps))) (Q2VL:96-110)
+//     from the h and norm-weight fragments it needs for its own K range -- the normalised row is never written to memory.  The
+//     weight loads of the first pipeline stage are issued BEFORE that prologue, so its L2 round trips hide under the HBM latency.
+//   * q/k/v: one block owns a 16-row tile that holds BOTH rotation partners of 8 channels (rows d..d+7 and d+64..d+71 of one
+//     head: the decode copy of the qkv weight is row-permuted at load time, weights.py `qkv_w_dec`), so bias + M-RoPE (HF's bf16
+//     op sequence, Q2VL:180-222) + the in-place KV append (cache_utils.py:127-146) run in the epilogue from registers.
+// All of it is HBM-bound weight streaming (same packed fragment order, nontemporal 16-byte loads, 2-stage software pipeline as
+// gemv_skinny_kernel); MFMA is only the multiply unit.  Algorithmic bytes per layer are unchanged (466 MB at 7B).
+#include "common.h"
+#include "kernels.h"
+
+namespace lcc {
+
+__device__ unsigned int lcc_zero_page_v2[64];  // 256 zero bytes: activation operand of absent K chunks
+
+enum { DG_PRO_PLAIN = 0, DG_PRO_NORM = 1 };
+enum { DG_EPI_BF16 = 0, DG_EPI_SWIGLU = 1, DG_EPI_RESID = 2, DG_EPI_ROPE = 3 };
+
+// x fragment of 8 consecutive k for activation row m: PRO_NORM = bf16(w * bf16(h * r))
+LCC_DEVICE u32x4 norm_frag(u32x4 hv, u32x4 wv, float r) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a = lo2f(wv[e]) * rbf(lo2f(hv[e]) * r);
+    const float b = hi2f(wv[e]) * rbf(hi2f(hv[e]) * r);
+    o[e] = pack2(a, b);
+  }
+  return o;
+}
+
+template <int NTILE, int PRO, int EPI, int NW, int UNR>
+__global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
+  static_assert(EPI != DG_EPI_SWIGLU || NTILE == 2, "swiglu needs the gate and the up tile in one block");
+  static_assert(EPI == DG_EPI_SWIGLU || NTILE == 1, "one tile per block");
+  __shared__ f32x4 red[NW - 1][NTILE][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+  const int M = a.M, N = a.N, K = a.K;
+  const int n0 = blockIdx.x * (NTILE * 16);
+  const int nchunk = (K + 63) >> 6, K32 = (K + 31) >> 5;
+  const int xm = min(li, M - 1);
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_v2) + g * 8;
+  const bf16_t* xp = (PRO == DG_PRO_PLAIN ? a.X + (size_t)xm * a.ldx : a.H + (size_t)xm * K) + g * 8;
+  const bf16_t* np = PRO == DG_PRO_NORM ? a.norm_w + g * 8 : nullptr;
+  const bf16_t* wp[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) wp[t] = a.W + (size_t)((n0 >> 4) + t) * K32 * 512 + lane * 8;
+
+  f32x4 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  struct Stage { u32x4 w[UNR][2][NTILE]; u32x4 x[UNR][2]; u32x4 n[PRO == DG_PRO_NORM ? UNR : 1][2]; };
+  auto load_w = [&](int c0, Stage& s) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int cc = c0 + u * NW;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kbc = min(2 * cc + h, K32 - 1);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) s.w[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)kbc * 512));
+      }
+    }
+  };
+  auto load_x = [&](int c0, Stage& s) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int cc = c0 + u * NW;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kb = 2 * cc + h;
+        const bool ok = cc < nchunk && kb < K32;              // wave-uniform: an absent block multiplies by a zero activation
+        const int kbc = min(kb, K32 - 1);
+        s.x[u][h] = ld16(ok ? xp + kbc * 32 : zp);
+        if (PRO == DG_PRO_NORM) s.n[u][h] = ld16(np + kbc * 32);
+      }
+    }
+  };
+  float r = 1.f;   // PRO_NORM: rsqrt(mean(h^2) + eps) of this lane's activation row
+  auto mma = [&](const Stage& s) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32x4 xf = PRO == DG_PRO_NORM ? norm_frag(s.x[u][h], s.n[u][h], r) : s.x[u][h];
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(s.w[u][h][t]), as_bf16x8(xf), acc[t]);
+      }
+  };
+
+  constexpr int STEP = UNR * NW;
+  Stage sa, sb;
+  int c = wave;
+  load_w(c, sa);                 // the weight stream starts before anything that depends on the previous kernel's output is touched
+  load_w(c + STEP, sb);
+  if (PRO == DG_PRO_NORM) {      // row statistic from the per-tile sums of squares: lanes g = 0..3 of a row split the tiles
+    const float* sp = a.stats + (size_t)xm * a.n_stat;
+    float s = 0.f;
+    for (int i = g; i < (a.n_stat >> 2); i += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + 4 * i);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    r = rsqrtf(s / (float)K + a.eps);
+  }
+  load_x(c, sa);
+  load_x(c + STEP, sb);
+  for (; c < nchunk; c += 2 * STEP) {
+    mma(sa);
+    load_w(c + 2 * STEP, sa);
+    load_x(c + 2 * STEP, sa);
+    mma(sb);
+    load_w(c + 3 * STEP, sb);
+    load_x(c + 3 * STEP, sb);
+  }
+
+  // cross-wave reduction through LDS; wave 0 runs the epilogue.  D'[n][m]: lane (m = li, g) holds 4 consecutive n = g*4 ..
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) red[wave - 1][t][lane] = acc[t];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
+
+  if (EPI == DG_EPI_BF16) {
+    if (li >= M) return;
+    const int n = n0 + g * 4;
+    if (n >= N) return;
+    float v[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+    if (a.bias != nullptr) {
+      const u32x2 b = ld8(a.bias + n);
+      v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+    }
+    st8(a.C + (size_t)li * a.ldc + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+  } else if (EPI == DG_EPI_SWIGLU) {   // tile 0 = 16 gate rows, tile 1 = the 16 matching up rows (weights.py interleave_gate_up)
+    if (li >= M || n0 >= N) return;
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = silu_bf16(rbf(acc[0][q])) * rbf(acc[NTILE - 1][q]);
+    st8(a.C + (size_t)li * a.ldc + n0 / 2 + g * 4, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
+  } else if (EPI == DG_EPI_RESID) {
+    // h = bf16(h + bf16(Linear output)); stats_out[m][tile] = sum of squares of the 16 new values of this tile
+    const int n = n0 + g * 4;
+    float ss = 0.f;
+    if (li < M && n < N) {
+      bf16_t* hp = a.Hres + (size_t)li * N + n;
+      const u32x2 hv = ld8(hp);
+      const float v0 = rbf(lo2f(hv.x) + rbf(acc[0][0])), v1 = rbf(hi2f(hv.x) + rbf(acc[0][1]));
+      const float v2 = rbf(lo2f(hv.y) + rbf(acc[0][2])), v3 = rbf(hi2f(hv.y) + rbf(acc[0][3]));
+      st8(hp, (u32x2){pack2(v0, v1), pack2(v2, v3)});
+      ss = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (g == 0 && li < M) a.stats_out[(size_t)li * (N >> 4) + (n0 >> 4)] = ss;
+  } else {   // DG_EPI_ROPE: tile rows 0-7 = channels d0..d0+7 of a head, rows 8-15 = their rotation partners d0+64..
+    constexpr int D = 128;
+    const int tile = n0 >> 4, head = tile >> 3, j = tile & 7;
+    const int hkv = a.lay.n_kv_heads, nq = a.n_q_heads;
+    const int half = g >> 1;                          // 0: first half of the head (d < 64), 1: second half
+    const int dc = j * 8 + (g & 1) * 4;               // channel inside the half, 4 consecutive
+    const int d = half * 64 + dc;
+    float x[4], xo[4];
+    {
+      const u32x2 b = ld8(a.bias + head * D + d);   // HF: Linear output = bf16(acc + bias)
+      x[0] = rbf(acc[0][0] + lo2f(b.x)); x[1] = rbf(acc[0][1] + hi2f(b.x));
+      x[2] = rbf(acc[0][2] + lo2f(b.y)); x[3] = rbf(acc[0][3] + hi2f(b.y));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xo[q] = __shfl_xor(x[q], 32, 64);      // partner channel (d +- 64) of the same token row
+    if (li >= M) return;
+    const int strm = a.tok_stream[li];
+    const int pos = a.kv_len[strm];                  // the new token's cache index
+    bf16_t* base = a.kv_base[strm] + (size_t)a.layer * a.lay.layer_stride();
+    if (head < nq + hkv) {
+      const u32x2 cq = ld8(a.cs + (size_t)li * 64 + dc), sq = ld8(a.sn + (size_t)li * 64 + dc);
+      const float cv[4] = {lo2f(cq.x), hi2f(cq.x), lo2f(cq.y), hi2f(cq.y)};
+      const float sv[4] = {lo2f(sq.x), hi2f(sq.x), lo2f(sq.y), hi2f(sq.y)};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)   // out = bf16(bf16(x*cos) + bf16(rotate_half(x)*sin)); rotate_half = (-x2, x1)
+        o[q] = half == 0 ? rbf(x[q] * cv[q]) + rbf(-xo[q] * sv[q]) : rbf(x[q] * cv[q]) + rbf(xo[q] * sv[q]);
+      bf16_t* dst = head < nq ? a.q_out + ((size_t)li * nq + head) * D
+                              : base + (size_t)(head - nq) * a.lay.head_stride() + (size_t)pos * D;
+      st8(dst + d, (u32x2){pack2(o[0], o[1]), pack2(o[2], o[3])});
+    } else {     // V: no rotation; cache is blocked-transposed [Lmax/32][128][32]
+      const int hv = head - nq - hkv;
+      bf16_t* dst = base + a.lay.kv_stride() + (size_t)hv * a.lay.head_stride() + ((size_t)(pos >> 5) * D + d) * 32 + (pos & 31);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[q * 32] = f2bf(x[q]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// step prologue: one block per stream does what were four launches (seen_set, embed_gather, mrope_table_decode, and the
+// first layer's RMSNorm statistic): marks the consumed token in the stream's seen-id bitmap (repetition penalty), gathers its
+// embedding row into the residual stream with the per-tile sums of squares, and builds the cos/sin row of its position.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_step_begin_kernel(
+    const int32_t* __restrict__ slots, const int32_t* __restrict__ cur_tok, const int32_t* __restrict__ done, uint32_t* __restrict__ seen,
+    int words, const bf16_t* __restrict__ table, bf16_t* __restrict__ h, float* __restrict__ stats, int dim,
+    const int32_t* __restrict__ pos, const float* __restrict__ inv_freq, bf16_t* __restrict__ cs, bf16_t* __restrict__ sn) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int slot = slots[b];
+  const int id = cur_tok[slot];
+  if (t == 0 && !(done != nullptr && done[slot])) atomicOr(seen + (size_t)slot * words + (id >> 5), 1u << (id & 31));
+  if (t < 64) {
+    const float ang = inv_freq[t] * (float)pos[slot];
+    cs[b * 64 + t] = f2bf(cosf(ang));
+    sn[b * 64 + t] = f2bf(sinf(ang));
+  }
+  const bf16_t* src = table + (size_t)id * dim;
+  for (int c = t; c * 8 < dim; c += 256) {      // 8 channels per thread; a 16-channel tile = 2 neighbouring threads
+    const u32x4 q = ld16(src + c * 8);
+    st16(h + (size_t)b * dim + c * 8, q);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float lo = lo2f(q[e]), hi = hi2f(q[e]); s += lo * lo + hi * hi; }
+    s += __shfl_xor(s, 1, 64);
+    if ((c & 1) == 0) stats[(size_t)b * (dim >> 4) + (c >> 1)] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------
+int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_t* done, uint32_t* seen, int words, const bf16_t* table,
+                      bf16_t* h, float* stats, int dim, const int32_t* pos, const float* inv_freq, bf16_t* cs, bf16_t* sn, int B,
+                      hipStream_t st) {
+  if (B <= 0) return 0;
+  if (dim & 15) return LCC_ERR_SHAPE;
+  decode_step_begin_kernel<<<dim3(B), dim3(256), 0, st>>>(slots, cur_tok, done, seen, words, table, h, stats, dim, pos, inv_freq, cs, sn);
+  return 0;
+}
+
+static int dg_check(const DgArgs& a, int pro, int epi) {
+  if (a.M < 1 || a.M > 16 || (a.N & 15) || (a.K & 31) || a.W == nullptr) return LCC_ERR_SHAPE;
+  if (pro == DG_PRO_PLAIN && (a.X == nullptr || (a.ldx & 7))) return LCC_ERR_ARG;
+  if (pro == DG_PRO_NORM && (a.H == nullptr || a.stats == nullptr || a.norm_w == nullptr || a.n_stat != (a.K >> 4) || (a.n_stat & 3))) return LCC_ERR_ARG;
+  if (epi == DG_EPI_RESID && (a.Hres == nullptr || a.stats_out == nullptr)) return LCC_ERR_ARG;
+  if ((epi == DG_EPI_BF16 || epi == DG_EPI_SWIGLU) && a.C == nullptr) return LCC_ERR_ARG;
+  if (epi == DG_EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
+  if (epi == DG_EPI_ROPE && (a.bias == nullptr || a.cs == nullptr || a.sn == nullptr || a.tok_stream == nullptr || a.kv_len == nullptr ||
+                             a.kv_base == nullptr || a.q_out == nullptr || a.lay.head_dim != 128 || (a.lay.lmax & 31) ||
+                             a.N != (a.n_q_heads + 2 * a.lay.n_kv_heads) * 128)) return LCC_ERR_ARG;
+  return 0;
+}
+
+// [RMSNorm] q/k/v Linear [bias + M-RoPE + KV append]: W = the row-permuted decode copy of the fused q|k|v weight
+int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
+  if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_ROPE)) return rc;
+  dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 2><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
+  return 0;
+}
+// o_proj / down_proj: x plain, residual add in place + per-tile sums of squares
+int dgemv_resid(const DgArgs& a, hipStream_t st) {
+  if (int rc = dg_check(a, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
+  dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
+  return 0;
+}
+// [RMSNorm] gate/up Linear [SwiGLU]
+int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st) {
+  if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_SWIGLU)) return rc;
+  dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 1><<<dim3(a.N / 32), dim3(256), 0, st>>>(a);
+  return 0;
+}
+// [final RMSNorm] lm_head
+int dgemv_norm_bf16(const DgArgs& a, hipStream_t st) {
+  if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_BF16)) return rc;
+  dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 1><<<dim3(a.N / 16), dim3(256), 0, st>>>(a);
+  return 0;
+}
+
+}  // namespace lcc

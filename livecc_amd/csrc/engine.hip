@@ -75,6 +75,7 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct VitLayerW { const bf16_t *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
 struct LlmLayerW {
   const bf16_t *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gate_up_w, *down_w;
+  const bf16_t* qkv_w_dec;   // optional row-permuted decode copy of qkv_w (decode pipeline v2), nullptr when absent
   const float *qkv_s, *o_s, *gate_up_s, *down_s;   // fp8 weights: per-output-row scales (nullptr for bf16 weights)
 };
 
@@ -149,6 +150,7 @@ size_t lcc_engine::llm_ws_bytes() const {
   t += align_up(S * 64 * 2) * 2;             // cos, sin
   t += align_up(std::max((size_t)MAX_SPLIT * 16 * std::max<size_t>(qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H) * 4);  // split-K slabs
   t += align_up(B * H * 2) * 2;              // last_h, last_xn
+  t += align_up(16 * (H / 16 + 4) * 4);      // decode v2: per-tile sums of squares of the residual rows
   t += align_up(B * V * 2);                  // logits
   t += align_up(std::max<size_t>(B * c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * c.n_q_heads * 8) * 128 * 4) * 2;  // attention split partials (o, ml)
   if (c.llm_fp8) t += align_up(std::max<size_t>((size_t)qkvd * H, 2 * I * H) * 2);   // bf16 dequantisation scratch of the largest LLM weight
@@ -308,6 +310,7 @@ static int resolve_weights(lcc_engine* e, std::string* missing) {
     LlmLayerW& L = e->llm[i];
     L.in_norm = get(p + "in_norm"); L.qkv_w = get(p + "qkv_w"); L.qkv_b = get(p + "qkv_b"); L.o_w = get(p + "o_w");
     L.post_norm = get(p + "post_norm"); L.gate_up_w = get(p + "gate_up_w"); L.down_w = get(p + "down_w");
+    { auto it = e->w.find(p + "qkv_w_dec"); L.qkv_w_dec = it == e->w.end() ? nullptr : (const bf16_t*)it->second; }
     L.qkv_s = L.o_s = L.gate_up_s = L.down_s = nullptr;
     if (e->c.llm_fp8) {
       L.qkv_s = (const float*)get(p + "qkv_w.scale"); L.o_s = (const float*)get(p + "o_w.scale");
@@ -518,7 +521,7 @@ int g_fuse_tails = 0;   // 1: batch-1 decode runs rope/KV-append and residual+RM
                         // kernels (the slab write-through + ticket serialises the GEMV's tail), so it stays an opt-in variant.
 struct LlmBuffers {
   bf16_t *h, *xn, *qkv, *q, *attn, *act, *cos, *sin, *last_h, *last_xn, *logits, *dq;
-  float *partial, *ws_o, *ws_ml;
+  float *partial, *ws_o, *ws_ml, *stats;
 };
 int carve_llm(lcc_engine* e, LlmBuffers* b) {
   const size_t S = e->lim.max_new_rows, B = e->lim.max_slots, H = e->c.hidden_size, I = e->c.intermediate_size, V = e->c.vocab_size;
@@ -527,7 +530,9 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
   b->q = cv.take<bf16_t>(S * e->qd); b->attn = cv.take<bf16_t>(S * e->qd); b->act = cv.take<bf16_t>(S * I);
   b->cos = cv.take<bf16_t>(S * 64); b->sin = cv.take<bf16_t>(S * 64);
   b->partial = cv.take<float>(std::max((size_t)MAX_SPLIT * 16 * std::max<size_t>(e->qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H));
-  b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H); b->logits = cv.take<bf16_t>(B * V);
+  b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H);
+  b->stats = cv.take<float>(16 * (H / 16 + 4));
+  b->logits = cv.take<bf16_t>(B * V);
   const size_t nslot = std::max<size_t>(B * e->c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * e->c.n_q_heads * 8);
   b->ws_o = cv.take<float>(nslot * 128); b->ws_ml = cv.take<float>(nslot * 128);
   b->dq = e->c.llm_fp8 ? cv.take<bf16_t>(std::max<size_t>((size_t)e->qkvd * H, 2 * I * H)) : nullptr;
@@ -621,7 +626,9 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     // SwiGLU MLP
     g = GemmArgs(); set_w(g, L.gate_up_w, L.gate_up_s); g.A = b.xn; g.lda = H; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
     g.epilogue = LCC_EPI_SWIGLU;
-    const bool prof = e->prof_on && cx.skinny && cx.tok_pos == nullptr && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
+    // one sampled launch per decode step (the middle layer): an event pair opens a ~6 us bubble on the stream on each side, which
+    // at 28 pairs per step was 8 % of the round-1 step time
+    const bool prof = e->prof_on && cx.skinny && cx.tok_pos == nullptr && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
     if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
     LCC_TRY(gemm_bf16(g, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
@@ -647,14 +654,55 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
   return 0;
 }
 
+int g_decode_path = 1;   // 1: decode pipeline v2 (decode_v2.hip: 6 launches per layer) where eligible; 0: the round-1 launch sequence
+bool decode_v2_ok(const lcc_engine* e) {
+  if (g_decode_path != 1 || e->c.llm_fp8) return false;
+  if ((e->c.hidden_size & 63) || (e->c.intermediate_size & 31) || (e->qd & 31)) return false;
+  for (const LlmLayerW& L : e->llm) if (L.qkv_w_dec == nullptr) return false;
+  return true;
+}
+// the 28 decoder layers of ONE decode step over B rows, v2 launch sequence.  On entry b.h / b.stats / b.cos / b.sin come from
+// decode_step_begin; on exit b.h is the residual stream after the last layer and b.stats its per-tile sums of squares (the final
+// RMSNorm runs as the prologue of the lm_head GEMV).
+int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, hipStream_t st) {
+  const int H = e->c.hidden_size, I = e->c.intermediate_size;
+  const float eps = e->c.rms_eps;
+  for (int l = 0; l < e->c.n_layers; ++l) {
+    const LlmLayerW& L = e->llm[l];
+    DgArgs a;
+    a = DgArgs(); a.W = L.qkv_w_dec; a.M = B; a.N = e->qkvd; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.in_norm;
+    a.eps = eps; a.bias = L.qkv_b; a.cs = b.cos; a.sn = b.sin; a.tok_stream = d_slots; a.kv_len = e->d_kv_len; a.kv_base = e->d_kv_base;
+    a.lay = e->lay; a.layer = l; a.q_out = b.q; a.n_q_heads = e->c.n_q_heads;
+    LCC_TRY(dgemv_qkv_rope(a, st));
+    LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
+    a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
+    LCC_TRY(dgemv_resid(a, st));
+    a = DgArgs(); a.W = L.gate_up_w; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
+    a.eps = eps; a.C = b.act; a.ldc = I;
+    const bool prof = e->prof_on && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();   // one sample per step
+    if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
+    LCC_TRY(dgemv_norm_swiglu(a, st));
+    if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
+    a = DgArgs(); a.W = L.down_w; a.M = B; a.N = H; a.K = I; a.X = b.act; a.ldx = I; a.Hres = b.h; a.stats_out = b.stats;
+    LCC_TRY(dgemv_resid(a, st));
+  }
+  return 0;
+}
+
 int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, int B, const int32_t* d_slots, const lcc_sampling* sp,
                     int step_index, hipStream_t st) {
   const int H = e->c.hidden_size, V = e->c.vocab_size;
   bf16_t* logits = b.logits;
   if (sp && sp->logits_out) logits = (bf16_t*)sp->logits_out + (size_t)step_index * B * V;
-  GemmArgs g; g.w_packed = 1; g.A = xn_rows; g.lda = H; g.W = e->lm_head; g.ldw = H; g.C = logits; g.ldc = V; g.M = B; g.N = V; g.K = H;
-  if (e->lm_head_s != nullptr) { g.w_fp8 = 1; g.wscale = e->lm_head_s; }
-  LCC_TRY(gemm_bf16(g, st));
+  if (xn_rows == nullptr) {   // decode v2: final RMSNorm of b.h as the prologue of the lm_head GEMV
+    DgArgs a; a.W = e->lm_head; a.M = B; a.N = V; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = e->final_norm;
+    a.eps = e->c.rms_eps; a.C = logits; a.ldc = V;
+    LCC_TRY(dgemv_norm_bf16(a, st));
+  } else {
+    GemmArgs g; g.w_packed = 1; g.A = xn_rows; g.lda = H; g.W = e->lm_head; g.ldw = H; g.C = logits; g.ldc = V; g.M = B; g.N = V; g.K = H;
+    if (e->lm_head_s != nullptr) { g.w_fp8 = 1; g.wscale = e->lm_head_s; }
+    LCC_TRY(gemm_bf16(g, st));
+  }
   const float pen = sp ? sp->repetition_penalty : 1.0f;
   const int thr_tok = sp ? sp->thr_token : -1;
   const int use_thr = sp ? sp->use_thr : 0;
@@ -814,16 +862,23 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   cx.nsplit_attn = nsplit;
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
   cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
+  const bool v2 = decode_v2_ok(e);
   for (int step = 0; step < n_steps; ++step) {
-    const bool prof_step = e->prof_on && 2 * (e->step_n + 1) <= (int)e->step_ev.size();
+    const bool prof_step = e->prof_on && (step & 3) == 0 && 2 * (e->step_n + 1) <= (int)e->step_ev.size();   // every 4th step
     if (prof_step) HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n], st));
     // the token sampled by the previous step (d_cur_tok[slot]) is embedded, appended at kv_len[slot], position pos[slot]
-    LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
-    LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
-    LCC_TRY(mrope_table_decode(d_slots, e->d_pos, e->inv_freq, n_streams, bf.cos, bf.sin, st));
-    LCC_TRY(run_layers(e, bf, cx, st));
+    if (v2) {
+      LCC_TRY(decode_step_begin(d_slots, e->d_cur_tok, e->d_done, e->d_seen, e->words, e->embed, bf.h, bf.stats, e->c.hidden_size, e->d_pos,
+                                e->inv_freq, bf.cos, bf.sin, n_streams, st));
+      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, st));
+    } else {
+      LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
+      LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
+      LCC_TRY(mrope_table_decode(d_slots, e->d_pos, e->inv_freq, n_streams, bf.cos, bf.sin, st));
+      LCC_TRY(run_layers(e, bf, cx, st));
+    }
     LCC_TRY(advance_lengths(d_slots, e->d_kv_len, e->d_pos, n_streams, e->d_done, st));
-    LCC_TRY(head_and_sample(e, bf, bf.xn, n_streams, d_slots, sp, first_step_index + step, st));
+    LCC_TRY(head_and_sample(e, bf, v2 ? nullptr : bf.xn, n_streams, d_slots, sp, first_step_index + step, st));
     if (prof_step) { HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n + 1], st)); e->step_n++; }
   }
   for (int b = 0; b < n_streams; ++b) { e->h_kv_len[slots[b]] += n_steps; e->h_pos[slots[b]] += n_steps; }
@@ -831,6 +886,11 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
 }
 
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
+extern "C" int lcc_debug_set_decode_path(int path) {
+  if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
+  g_decode_path = path;
+  return 0;
+}
 // bit 0: engine uses the fused decode attention for batches of >= 16 (stream, KV head) pairs (default); bit 2: for every batch;
 // bit 1: its key splits are merged in-launch (ticket) instead of by a combine launch
 extern "C" int lcc_debug_set_fused_attn(int mode) {

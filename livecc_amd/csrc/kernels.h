@@ -115,4 +115,22 @@ int sample_topk_topp(const bf16_t* logits, int ld, int B, int V, uint32_t* seen,
                      float* scores_out, float temperature, int top_k, float top_p, uint64_t seed, uint32_t* rng_ctr, hipStream_t st);
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st);
 
+// ---- decode layer pipeline v2 (decode_v2.hip): elementwise stages fused into the weight-streaming GEMVs ----
+struct DgArgs {
+  const bf16_t* W = nullptr; int M = 0, N = 0, K = 0;
+  const bf16_t* X = nullptr; int ldx = 0;                                      // plain activation rows [M, K]
+  const bf16_t* H = nullptr; const float* stats = nullptr; int n_stat = 0; const bf16_t* norm_w = nullptr; float eps = 0.f;  // RMSNorm prologue
+  const bf16_t* bias = nullptr; bf16_t* C = nullptr; int ldc = 0;              // bf16 / SwiGLU epilogue
+  bf16_t* Hres = nullptr; float* stats_out = nullptr;                          // residual epilogue
+  const bf16_t* cs = nullptr; const bf16_t* sn = nullptr; const int32_t* tok_stream = nullptr; const int32_t* kv_len = nullptr;
+  bf16_t* const* kv_base = nullptr; KvLayout lay = {0, 0, 0, 0}; int layer = 0; bf16_t* q_out = nullptr; int n_q_heads = 0;   // rope epilogue
+};
+int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_t* done, uint32_t* seen, int words, const bf16_t* table,
+                      bf16_t* h, float* stats, int dim, const int32_t* pos, const float* inv_freq, bf16_t* cs, bf16_t* sn, int B,
+                      hipStream_t st);
+int dgemv_qkv_rope(const DgArgs& a, hipStream_t st);      // [RMSNorm] q|k|v Linear (row-permuted decode copy) [bias + M-RoPE + KV append]
+int dgemv_resid(const DgArgs& a, hipStream_t st);         // o_proj / down_proj [residual add in place + per-tile sums of squares]
+int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st);   // [RMSNorm] gate/up Linear [SwiGLU]
+int dgemv_norm_bf16(const DgArgs& a, hipStream_t st);     // [final RMSNorm] lm_head
+
 }  // namespace lcc

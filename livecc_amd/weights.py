@@ -25,7 +25,17 @@ import torch
 from .config import LiveCCConfig
 
 
-def weight_shapes(cfg: LiveCCConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+def qkv_decode_row_permutation(cfg: LiveCCConfig) -> torch.Tensor:
+    """Row order of the DECODE copy of the fused q|k|v weight (`llm.{i}.qkv_w_dec`): inside every 128-row head, stored row
+    j*16 + half*8 + i holds logical row half*64 + j*8 + i, i.e. each 16-row MFMA tile carries 8 channels and their 8 M-RoPE
+    rotation partners (d, d + 64) -- the decode GEMV then applies bias + RoPE + KV append from registers (csrc/decode_v2.hip)."""
+    heads = cfg.qkv_dim // 128
+    j, half, i = torch.meshgrid(torch.arange(8), torch.arange(2), torch.arange(8), indexing="ij")
+    inner = (half * 64 + j * 8 + i).reshape(-1)                     # stored position (j, half, i) -> logical channel
+    return (torch.arange(heads)[:, None] * 128 + inner[None, :]).reshape(-1)
+
+
+def weight_shapes(cfg: LiveCCConfig, decode_copies: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
     E, H, I = cfg.vit_embed_dim, cfg.hidden_size, cfg.intermediate_size
     M = cfg.vit_mlp_dim
     out: List[Tuple[str, Tuple[int, ...]]] = [("vit.patch_embed", (E, cfg.patch_dim))]
@@ -41,6 +51,8 @@ def weight_shapes(cfg: LiveCCConfig) -> List[Tuple[str, Tuple[int, ...]]]:
         out += [(p + "in_norm", (H,)), (p + "qkv_w", (cfg.qkv_dim, H)), (p + "qkv_b", (cfg.qkv_dim,)),
                 (p + "o_w", (H, cfg.q_dim)), (p + "post_norm", (H,)), (p + "gate_up_w", (2 * I, H)),
                 (p + "down_w", (H, I))]
+        if decode_copies:      # +7 % of a layer's bytes (33 MB of 466 MB at 7B) buys three launches per decode layer
+            out += [(p + "qkv_w_dec", (cfg.qkv_dim, H))]
     out += [("final_norm", (H,)), ("lm_head", (cfg.vocab_size, H))]   # tied checkpoints: a packed copy of `embed`
     return out
 
@@ -105,7 +117,7 @@ class WeightArena:
         """llm_fp8: the LLM Linear weights + lm_head are stored as OCP e4m3 bytes (PACKED8 order) followed by their fp32 row
         scales (`<name>.scale`) -- 1 byte per parameter instead of 2 (72B: 73 GB instead of 147 GB; BASELINE configs[4])."""
         self.cfg, self.device, self.llm_fp8 = cfg, torch.device(device), bool(llm_fp8)
-        self.shapes = weight_shapes(cfg)
+        self.shapes = weight_shapes(cfg, decode_copies=not llm_fp8)    # the fp8 decode path keeps the round-1 launch sequence
         self.fp8 = set(fp8_weight_names(cfg)) if llm_fp8 else set()
         offs, total = {}, 0          # offsets / sizes in bf16 (2-byte) units
         for name, shp in self.shapes:
@@ -190,6 +202,10 @@ class WeightArena:
                     q, s_ = quantize_fp8_rows(torch.randn((r1 - r0, K), generator=g, device=self.device, dtype=torch.float32).mul_(std))
                     pv[r0 // 16:r1 // 16].copy_(pack_weight_fp8(q).view((r1 - r0) // 16, K // 64, 4, 16, 16))
                     sc[r0:r1].copy_(s_)
+            elif name.endswith("qkv_w_dec"):   # the same matrix as qkv_w, rows permuted (both packed)
+                self.store(name, self.logical(name[:-4])[qkv_decode_row_permutation(self.cfg).to(self.device)])
+            elif name.endswith("qkv_w"):       # kept logical -> packed so that the decode copy can be derived from it
+                self.store(name, torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(std))
             elif len(shp) >= 2:   # i.i.d. values: the packed order of a random matrix is a random matrix
                 v.copy_(torch.randn(shp, generator=g, device=self.device, dtype=torch.float32).mul_(std))
             elif name.endswith("_b"):
@@ -230,7 +246,10 @@ class WeightArena:
         for i in range(cfg.num_hidden_layers):
             s, p = f"language_model.layers.{i}.", f"llm.{i}."
             put(p + "in_norm", sd_get(s + "input_layernorm.weight"))
-            put(p + "qkv_w", torch.cat([sd_get(s + f"self_attn.{x}_proj.weight") for x in "qkv"], dim=0))
+            qkv = torch.cat([sd_get(s + f"self_attn.{x}_proj.weight") for x in "qkv"], dim=0)
+            put(p + "qkv_w", qkv)
+            if (p + "qkv_w_dec") in self.offsets:
+                put(p + "qkv_w_dec", qkv[qkv_decode_row_permutation(cfg).to(qkv.device)])
             put(p + "qkv_b", torch.cat([sd_get(s + f"self_attn.{x}_proj.bias") for x in "qkv"], dim=0))
             put(p + "o_w", sd_get(s + "self_attn.o_proj.weight"))
             put(p + "post_norm", sd_get(s + "post_attention_layernorm.weight"))

@@ -284,13 +284,20 @@ def test_sampling_processed_distribution_matches_hf_warpers(dev, V, temperature,
             sc = TemperatureLogitsWarper(temperature)(None, sc)
         if top_k:
             sc = TopKLogitsWarper(top_k)(None, sc)
+        pre_top_p = sc[0].clone()
         if top_p < 1.0:
             sc = TopPLogitsWarper(top_p)(None, sc)
         got = scores[b].cpu()
         keep_ref, keep_got = torch.isfinite(sc[0]), torch.isfinite(got)
-        # the top-p cut is a comparison of a cumulative sum with 1 - top_p: an element whose cumulative mass sits within float
-        # rounding of the threshold may land on either side (at most one boundary element)
-        assert int((keep_ref != keep_got).sum()) <= 1, f"kept sets differ: {int(keep_ref.sum())} vs {int(keep_got.sum())}"
+        # The top-p cut falls INSIDE a group of equal scores whenever the boundary value is tied (bf16 logits: ~50 ids per distinct
+        # value at V = 152k).  HF then keeps whichever members of the group its (unstable) sort happened to place last; the kernel
+        # cuts by value and keeps the whole group -- the only difference allowed: ids of ONE tied value, all kept by the kernel.
+        diff = keep_ref != keep_got
+        if bool(diff.any()):
+            assert pre_top_p[diff].unique().numel() == 1, f"kept sets differ beyond one tie group: {int(keep_ref.sum())} vs {int(keep_got.sum())}"
+            assert bool(keep_got[diff].all()), "the kernel keeps the whole boundary tie group"
+            boundary = pre_top_p[diff][0]
+            assert bool((keep_ref & (pre_top_p == boundary)).any()) or int(diff.sum()) <= 1, "HF cut inside that tie group"
         both = keep_ref & keep_got
         assert torch.allclose(got[both], sc[0][both], rtol=1e-6, atol=1e-6)
         assert bool(keep_got[int(tok[b])]), "drawn token must be in the kept set"

@@ -32,12 +32,28 @@ def test_pack_weight_index_formula():
 
 def test_weight_shapes_cover_7b_param_count():
     n = 0
-    for name, shp in weight_shapes(livecc_7b()):
+    for name, shp in weight_shapes(livecc_7b(), decode_copies=False):
         k = 1
         for s in shp:
             k *= s
         n += k
     assert abs(n / 1e9 - 8.291) < 0.005          # 8.291 B parameters (7B: lm_head untied)
+    # the arena additionally holds the row-permuted decode copy of every q|k|v weight (decode pipeline v2): +0.462 B elements
+    extra = sum(shp[0] * shp[1] for name, shp in weight_shapes(livecc_7b()) if name.endswith("qkv_w_dec"))
+    assert extra == 28 * 4608 * 3584
+
+
+def test_decode_copy_is_the_row_permuted_qkv_weight():
+    from livecc_amd.weights import WeightArena, qkv_decode_row_permutation
+    cfg = tiny()
+    perm = qkv_decode_row_permutation(cfg)
+    assert sorted(perm.tolist()) == list(range(cfg.qkv_dim))
+    assert perm[:16].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 64, 65, 66, 67, 68, 69, 70, 71]      # one MFMA tile = 8 channels + partners
+    assert perm[128 + 16:128 + 24].tolist() == [128 + 8 + i for i in range(8)]
+    for arena in (WeightArena(cfg, "cpu").fill_tiled(2), WeightArena(cfg, "cpu").fill_random(2)):
+        for l in range(cfg.num_hidden_layers):
+            assert torch.equal(arena.logical(f"llm.{l}.qkv_w_dec"), arena.logical(f"llm.{l}.qkv_w")[perm])
+    assert not any(n.endswith("qkv_w_dec") for n in WeightArena(cfg, "cpu", llm_fp8=True).names())
 
 
 def test_arena_from_hf_state_dict_cpu():
