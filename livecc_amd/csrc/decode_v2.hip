@@ -49,6 +49,8 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   static_assert(EPI != DG_EPI_SWIGLU || NTILE == 2, "swiglu needs the gate and the up tile in one block");
   static_assert(EPI == DG_EPI_SWIGLU || NTILE == 1, "one tile per block");
   __shared__ f32x4 red[NW - 1][NTILE][64];
+  __shared__ float s_stat[PRO == DG_PRO_NORM ? 16 * 128 : 1];   // M <= 16 rows x (hidden <= 8192) / 64 pieces
+  __shared__ float s_r[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int M = a.M, N = a.N, K = a.K;
   const int n0 = blockIdx.x * (NTILE * 16);
@@ -107,28 +109,69 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   constexpr int STEP = UNR * NW;
   Stage sa, sb;
   int c = wave;
-  load_w(c, sa);                 // the weight stream starts before anything that depends on the previous kernel's output is touched
-  load_w(c + STEP, sb);
-  if (PRO == DG_PRO_NORM) {      // row statistic from the per-tile sums of squares: lanes g = 0..3 of a row split the tiles
-    const float* sp = a.stats + (size_t)xm * a.n_stat;
-    float s = 0.f;
-    for (int i = g; i < (a.n_stat >> 2); i += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sp + 4 * i);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
+
+  // ---- everything the kernel will need from the previous launch is requested up front, in ONE burst with the first two weight
+  //      stages: vmcnt retires loads in issue order, so a small load issued after the weight stream would only return behind it
+  //      (a 14-iteration dependent loop over the row statistics at this point cost 8 us per block in the first version) ----
+  // row statistics: the M x n_stat per-tile sums of squares are spread over ALL threads of the block (one or two 16-byte pieces
+  // each), summed per row through LDS in a fixed order (every block gets bit-identical statistics)
+  constexpr int T = NW * 64, PP = 2;
+  const int n4 = a.n_stat >> 2, total4 = PRO == DG_PRO_NORM ? M * n4 : 0;
+  f32x4 pv[PP];
+  if (PRO == DG_PRO_NORM) {
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+      const int p = (int)threadIdx.x + u * T;
+      pv[u] = *reinterpret_cast<const f32x4*>(a.stats + 4 * (size_t)(p < total4 ? p : 0));     // rows are contiguous: [M][n_stat]
     }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    r = rsqrtf(s / (float)K + a.eps);
   }
+  // epilogue operands of wave 0 (residual row / bias, cos, sin and the KV slot): in flight during the whole weight stream
+  u32x2 e_h = {0u, 0u}, e_b = {0u, 0u}, e_c = {0u, 0u}, e_s = {0u, 0u};
+  int e_pos = 0;
+  bf16_t* e_base = nullptr;
+  if (wave == 0) {
+    if (EPI == DG_EPI_RESID) {
+      const int n = n0 + g * 4;
+      if (li < M && n < N) e_h = ld8(a.Hres + (size_t)li * N + n);
+    } else if (EPI == DG_EPI_ROPE) {
+      const int tile = n0 >> 4, head = tile >> 3, j = tile & 7;
+      const int dc = j * 8 + (g & 1) * 4, d = (g >> 1) * 64 + dc;
+      e_b = ld8(a.bias + head * 128 + d);
+      e_c = ld8(a.cs + (size_t)xm * 64 + dc);
+      e_s = ld8(a.sn + (size_t)xm * 64 + dc);
+      const int strm = a.tok_stream[xm];
+      e_pos = a.kv_len[strm];
+      e_base = a.kv_base[strm];
+    }
+  }
+  load_w(c, sa);
+  load_w(c + STEP, sb);
   load_x(c, sa);
   load_x(c + STEP, sb);
+  if (PRO == DG_PRO_NORM) {
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+      const int p = (int)threadIdx.x + u * T;
+      if (p < total4) s_stat[p] = (pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3]);
+    }
+    for (int p = (int)threadIdx.x + PP * T; p < total4; p += T) {     // M * n_stat / 4 > 2 * threads: large batches of a 72B-size model
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.stats + 4 * (size_t)p);
+      s_stat[p] = (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < M) {
+      float s = 0.f;
+      for (int i = 0; i < n4; ++i) s += s_stat[(int)threadIdx.x * n4 + i];
+      s_r[threadIdx.x] = rsqrtf(s / (float)K + a.eps);
+    }
+    __syncthreads();
+    r = s_r[xm];
+  }
   for (; c < nchunk; c += 2 * STEP) {
     mma(sa);
-    load_w(c + 2 * STEP, sa);
-    load_x(c + 2 * STEP, sa);
-    mma(sb);
-    load_w(c + 3 * STEP, sb);
-    load_x(c + 3 * STEP, sb);
+    if (c + 2 * STEP < nchunk) { load_w(c + 2 * STEP, sa); load_x(c + 2 * STEP, sa); }   // wave-uniform: no loads past the last chunk
+    if (c + STEP < nchunk) mma(sb);
+    if (c + 3 * STEP < nchunk) { load_w(c + 3 * STEP, sb); load_x(c + 3 * STEP, sb); }
   }
 
   // cross-wave reduction through LDS; wave 0 runs the epilogue.  D'[n][m]: lane (m = li, g) holds 4 consecutive n = g*4 ..
@@ -165,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
     float ss = 0.f;
     if (li < M && n < N) {
       bf16_t* hp = a.Hres + (size_t)li * N + n;
-      const u32x2 hv = ld8(hp);
+      const u32x2 hv = e_h;
       const float v0 = rbf(lo2f(hv.x) + rbf(acc[0][0])), v1 = rbf(hi2f(hv.x) + rbf(acc[0][1]));
       const float v2 = rbf(lo2f(hv.y) + rbf(acc[0][2])), v3 = rbf(hi2f(hv.y) + rbf(acc[0][3]));
       st8(hp, (u32x2){pack2(v0, v1), pack2(v2, v3)});
@@ -183,18 +226,17 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
     const int d = half * 64 + dc;
     float x[4], xo[4];
     {
-      const u32x2 b = ld8(a.bias + head * D + d);   // HF: Linear output = bf16(acc + bias)
+      const u32x2 b = e_b;                           // HF: Linear output = bf16(acc + bias)
       x[0] = rbf(acc[0][0] + lo2f(b.x)); x[1] = rbf(acc[0][1] + hi2f(b.x));
       x[2] = rbf(acc[0][2] + lo2f(b.y)); x[3] = rbf(acc[0][3] + hi2f(b.y));
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) xo[q] = __shfl_xor(x[q], 32, 64);      // partner channel (d +- 64) of the same token row
     if (li >= M) return;
-    const int strm = a.tok_stream[li];
-    const int pos = a.kv_len[strm];                  // the new token's cache index
-    bf16_t* base = a.kv_base[strm] + (size_t)a.layer * a.lay.layer_stride();
+    const int pos = e_pos;                           // the new token's cache index
+    bf16_t* base = e_base + (size_t)a.layer * a.lay.layer_stride();
     if (head < nq + hkv) {
-      const u32x2 cq = ld8(a.cs + (size_t)li * 64 + dc), sq = ld8(a.sn + (size_t)li * 64 + dc);
+      const u32x2 cq = e_c, sq = e_s;
       const float cv[4] = {lo2f(cq.x), hi2f(cq.x), lo2f(cq.y), hi2f(cq.y)};
       const float sv[4] = {lo2f(sq.x), hi2f(sq.x), lo2f(sq.y), hi2f(sq.y)};
       float o[4];

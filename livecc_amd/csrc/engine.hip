@@ -657,7 +657,7 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
 int g_decode_path = 1;   // 1: decode pipeline v2 (decode_v2.hip: 6 launches per layer) where eligible; 0: the round-1 launch sequence
 bool decode_v2_ok(const lcc_engine* e) {
   if (g_decode_path != 1 || e->c.llm_fp8) return false;
-  if ((e->c.hidden_size & 63) || (e->c.intermediate_size & 31) || (e->qd & 31)) return false;
+  if ((e->c.hidden_size & 63) || e->c.hidden_size > 8192 || (e->c.intermediate_size & 31) || (e->qd & 31)) return false;
   for (const LlmLayerW& L : e->llm) if (L.qkv_w_dec == nullptr) return false;
   return true;
 }

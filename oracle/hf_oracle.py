@@ -159,9 +159,12 @@ class ThresholdLogitsProcessor:
 class OracleStream:
     """One video stream replayed through HF `generate` with the reference's protocol."""
 
-    def __init__(self, model, cfg: LiveCCConfig):
+    def __init__(self, model, cfg: LiveCCConfig, device=None, past_key_values=None):
+        """`device`: where the inputs go (the model's device; default CPU).  `past_key_values`: an HF `Cache` object to start
+        from (the plugin tests pass a `NativeKVCache`)."""
         self.model, self.cfg = model, cfg
-        self.past_key_values = None
+        self.device = torch.device(device) if device is not None else None
+        self.past_key_values = past_key_values
         self.past_ids: Optional[torch.Tensor] = None
         self.rope_deltas = None
         self.last_prefill_seconds = 0.0
@@ -179,6 +182,9 @@ class OracleStream:
             kwargs["pixel_values_videos"] = pixel_values
             kwargs["video_grid_thw"] = torch.as_tensor([list(grid_thw)], dtype=torch.long)
         kwargs["mm_token_type_ids"] = torch.as_tensor(protocol.mm_token_type_ids(input_ids.numpy(), cfg))
+        if self.device is not None:
+            input_ids = input_ids.to(self.device)
+            kwargs = {k: v.to(self.device) for k, v in kwargs.items()}
         procs = None
         if streaming_eos is not None:
             from transformers import LogitsProcessorList
@@ -208,11 +214,11 @@ class OracleStream:
         self.seconds = time.perf_counter() - t0
         self.rope_deltas = model.model.rope_deltas
         self.past_key_values = out.past_key_values
-        self.past_ids = out.sequences[:, :-1]
+        self.past_ids = out.sequences[:, :-1].cpu()
         n_in = input_ids.shape[1]
-        return dict(sequences=out.sequences[0].clone(), new_tokens=out.sequences[0, n_in:].tolist(),
-                    logits=[l[0].float().clone() for l in out.logits],
-                    scores=(force.pre if force is not None else [s[0].float().clone() for s in out.scores]), n_input=n_in)
+        return dict(sequences=out.sequences[0].cpu().clone(), new_tokens=out.sequences[0, n_in:].tolist(),
+                    logits=[l[0].float().cpu().clone() for l in out.logits],
+                    scores=(force.pre if force is not None else [s[0].float().cpu().clone() for s in out.scores]), n_input=n_in)
 
 
 class _ForceTokens:
@@ -224,7 +230,7 @@ class _ForceTokens:
         self.pre: List[torch.Tensor] = []      # processed scores before forcing (the oracle's own preference)
 
     def __call__(self, input_ids, scores):
-        self.pre.append(scores[0].float().clone())
+        self.pre.append(scores[0].float().cpu().clone())
         i = input_ids.shape[1] - self.n_prompt
         if i < len(self.tokens):
             scores = scores.clone()

@@ -589,3 +589,41 @@ def test_liger_style_plugin_patches_hf_modules(dev):
                           "plugin_layernorm", 1.0, 5e-3)
     finally:
         m.Qwen2VLRMSNorm, m.LayerNorm, m.Qwen2MLP = saved
+
+
+def test_unmodified_hf_model_on_the_gpu_with_every_plugin_matches_hf_cpu(dev):
+    """SURVEY 8b items 1-3 under the HF module graph: `apply_livecc_amd_kernel_to_qwen2_vl()` (RMSNorm, LayerNorm, SwiGLU,
+    apply_multimodal_rotary_pos_emb) + `attn_implementation="livecc_amd"` (AttentionInterface: ViT slices and causal GQA) +
+    `past_key_values=NativeKVCache(...)` (Cache.update appends in place) -- an UNMODIFIED HF Qwen2VLForConditionalGeneration placed
+    on the ROCm device runs the reference's two-turn streaming protocol through them; logits vs the same model on the CPU with
+    HF's own modules (bf16), teacher-forced along the GPU tokens."""
+    from livecc_amd import plugin, protocol
+    from livecc_amd.config import tiny
+    from oracle import hf_oracle as O
+    cfg = tiny()
+    hf_cpu = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=0, init_scale=2.0)
+    plugin.apply_livecc_amd_kernel_to_qwen2_vl()
+    try:
+        import transformers.models.qwen2_vl.modeling_qwen2_vl as m
+        hf_gpu = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=0, init_scale=2.0, attn_implementation=plugin.ATTN_NAME)
+        assert type(hf_gpu.model.language_model.norm).__name__ == "LccRMSNorm" and m.apply_multimodal_rotary_pos_emb is plugin.lcc_apply_multimodal_rotary_pos_emb
+        hf_gpu.load_state_dict(hf_cpu.state_dict())
+        hf_gpu = hf_gpu.to(dev)
+        cache = plugin.NativeKVCache(hf_gpu.config, 1024, dev)
+        frames = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=1234, layout="TCHW"))
+        builder = protocol.TurnBuilder(cfg, seed=1234)
+        s_gpu, s_cpu = O.OracleStream(hf_gpu, cfg, device=dev, past_key_values=cache), O.OracleStream(hf_cpu, cfg)
+        worst = 0.0
+        for ti, (a, b) in enumerate(protocol.split_clip(8)):
+            pv, grid = O.patchify_normalize_ref(frames[a:b], cfg)
+            ids = builder.turn_ids(ti, protocol.num_video_tokens(grid, cfg))
+            rg = s_gpu.turn(ids, pv, grid, max_new_tokens=4, repetition_penalty=1.05)
+            rc = s_cpu.turn(ids, pv, grid, max_new_tokens=4, repetition_penalty=1.05, teacher_tokens=rg["new_tokens"])
+            for k in range(4):
+                lg, lc = rg["logits"][k], rc["logits"][k]
+                worst = max(worst, ((lg - lc).abs().max() / lc.abs().max()).item())
+        assert s_gpu.past_key_values is cache and cache.get_seq_length() == s_gpu.past_ids.shape[1]
+        record("hf_model_with_plugins_vs_hf_cpu", dict(worst_rel_dlogit=worst))
+        assert worst <= 6e-2, f"HF-on-GPU with the native plugins differs from HF CPU by {worst:.3g} of the logit scale"
+    finally:
+        plugin.revert_livecc_amd_kernel_to_qwen2_vl()
