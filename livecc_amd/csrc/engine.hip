@@ -664,9 +664,12 @@ bool decode_v2_ok(const lcc_engine* e) {
 // the 28 decoder layers of ONE decode step over B rows, v2 launch sequence.  On entry b.h / b.stats / b.cos / b.sin come from
 // decode_step_begin; on exit b.h is the residual stream after the last layer and b.stats its per-tile sums of squares (the final
 // RMSNorm runs as the prologue of the lm_head GEMV).
-int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, hipStream_t st) {
+int g_decode_combine = 1;   // 1: batches of <= 2 streams merge the attention key splits inside the o_proj GEMV (no combine launch)
+int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, int ntile_max, hipStream_t st) {
   const int H = e->c.hidden_size, I = e->c.intermediate_size;
   const float eps = e->c.rms_eps;
+  const bool fuse_combine = g_decode_combine && B <= 2 && e->qd <= 8192 && (e->qd & 127) == 0;
+  const int ns_fused = std::max(1, std::min(16, (ntile_max + 11) / 12));      // >= 12 key tiles (3 per wave) per block
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     DgArgs a;
@@ -674,9 +677,16 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     a.eps = eps; a.bias = L.qkv_b; a.cs = b.cos; a.sn = b.sin; a.tok_stream = d_slots; a.kv_len = e->d_kv_len; a.kv_base = e->d_kv_base;
     a.lay = e->lay; a.layer = l; a.q_out = b.q; a.n_q_heads = e->c.n_q_heads;
     LCC_TRY(dgemv_qkv_rope(a, st));
-    LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
-    a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
-    LCC_TRY(dgemv_resid(a, st));
+    if (fuse_combine) {   // small batches: 4-wave attention blocks, <= 16 partials per head, merged in the o_proj GEMV's prologue
+      LCC_TRY(attn_decode_partials_bf16(b.q, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, ns_fused, b.ws_o, b.ws_ml, st));
+      a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.att_o = b.ws_o; a.att_ml = b.ws_ml; a.att_ns = ns_fused;
+      a.att_hkv = e->c.n_kv_heads; a.Hres = b.h; a.stats_out = b.stats;
+      LCC_TRY(dgemv_combine_resid(a, st));
+    } else {
+      LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
+      a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
+      LCC_TRY(dgemv_resid(a, st));
+    }
     a = DgArgs(); a.W = L.gate_up_w; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
     a.eps = eps; a.C = b.act; a.ldc = I;
     const bool prof = e->prof_on && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();   // one sample per step
@@ -862,7 +872,9 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   cx.nsplit_attn = nsplit;
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
   cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
-  const bool v2 = decode_v2_ok(e);
+  // v2 builds the normalised rows of the batch in LDS (M * hidden <= 16384 elements): batches of up to 4 streams at 7B / 2B shapes,
+  // 2 at 72B; larger batches keep the round-1 launch sequence (its per-layer launch latency is amortised over the batch)
+  const bool v2 = decode_v2_ok(e) && n_streams <= 4 && (long)n_streams * e->c.hidden_size <= 16384;
   for (int step = 0; step < n_steps; ++step) {
     const bool prof_step = e->prof_on && (step & 3) == 0 && 2 * (e->step_n + 1) <= (int)e->step_ev.size();   // every 4th step
     if (prof_step) HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n], st));
@@ -870,7 +882,7 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
     if (v2) {
       LCC_TRY(decode_step_begin(d_slots, e->d_cur_tok, e->d_done, e->d_seen, e->words, e->embed, bf.h, bf.stats, e->c.hidden_size, e->d_pos,
                                 e->inv_freq, bf.cos, bf.sin, n_streams, st));
-      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, st));
+      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, ntile, st));
     } else {
       LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
       LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
@@ -887,8 +899,9 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
 
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_path(int path) {
-  if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
-  g_decode_path = path;
+  if (path < 0 || path > 2) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence), 1 (v2) or 2 (v2 with a separate combine launch)");
+  g_decode_path = path ? 1 : 0;
+  g_decode_combine = path == 2 ? 0 : 1;
   return 0;
 }
 // bit 0: engine uses the fused decode attention for batches of >= 16 (stream, KV head) pairs (default); bit 2: for every batch;

@@ -257,12 +257,13 @@ def rope_kv_append(qkv: Optional[torch.Tensor], cos, sin, tok_stream, tok_pos, k
                    kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
     S = cos.shape[0]
     # n_q_heads == 0: append-only use (the HF Cache plugin): the kernel still wants a valid pointer
-    q = torch.empty(S, n_q_heads * 128, dtype=torch.bfloat16, device=cos.device) if n_q_heads > 0 else torch.empty(S, 8, dtype=torch.bfloat16, device=cos.device)[:, :0]
+    q = torch.empty(S, n_q_heads * 128, dtype=torch.bfloat16, device=cos.device)
+    dummy = torch.empty(16, dtype=torch.bfloat16, device=cos.device) if n_q_heads == 0 else None
     _lib.check(_lib.load().lcc_rope_kv_append_bf16(
         _chk(qkv, torch.bfloat16, "qkv"), _chk(partial, torch.float32, "partial"), partial.shape[0] if partial is not None else 0,
         _chk(bias, torch.bfloat16, "bias"), _chk(cos, torch.bfloat16, "cos"), _chk(sin, torch.bfloat16, "sin"),
         _chk(tok_stream, torch.int32, "tok_stream"), _chk(tok_pos, torch.int32, "tok_pos"), _chk(kv_len, torch.int32, "kv_len"),
-        kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr() if n_q_heads > 0 else q._base.data_ptr(), S, n_q_heads, _st(cos)),
+        kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr() if n_q_heads > 0 else dummy.data_ptr(), S, n_q_heads, _st(cos)),
         "lcc_rope_kv_append_bf16")
     return q
 
