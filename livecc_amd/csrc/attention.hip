@@ -599,70 +599,6 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
   }
 }
 
-// Multi-wave form of attn_decode_kernel for small batches (decode pipeline v2, M <= 2): a block = 4 waves that share ONE key
-// split of a (stream, KV head) and merge their (o, m, l) through LDS, so that a layer needs <= 32 partials per head instead of
-// 64 -- few enough for the o_proj GEMV to merge them in its own prologue (no combine launch).  q comes rotated from the q|k|v
-// GEMV's epilogue, which has also appended the new token's K/V.  grid = (nsplit, Hkv, B), 256 threads; partial layout as above.
-__global__ __launch_bounds__(256) void attn_decode_mw_kernel(
-    const bf16_t* __restrict__ q, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
-    bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int n_q_heads, int nsplit, float* __restrict__ ws_o,
-    float* __restrict__ ws_ml, float scale_log2e) {
-  constexpr int D = 128, KS = 4, NQ = 1, NW = 4;
-  __shared__ __attribute__((aligned(16))) float sm[NW][16][D + 4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
-  const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
-  const int hkv = lay.n_kv_heads, G = n_q_heads / hkv;
-  const int slot_id = slots[b];
-  const int n = kv_len[slot_id] + 1;
-  const int ntile = (n + 31) / 32;
-  const int per = (ntile + nsplit - 1) / nsplit;
-  const int t0 = split * per, t1 = min(ntile, t0 + per);
-  const int nt = max(t1 - t0, 0), pw = (nt + NW - 1) / NW;
-  const int w0 = t0 + wave * pw, w1 = min(t1, w0 + pw);
-
-  u32x4 qf[NQ][KS];
-  int key_limit[NQ] = {n};
-  {
-    const int hq = hk * G + min(li, G - 1);
-    const bf16_t* qp = q + ((size_t)b * n_q_heads + hq) * D;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[0][ks] = ld16(qp + ks * 32 + g * 8);
-  }
-  const bf16_t* base = kv_base[slot_id] + (size_t)layer * lay.layer_stride();
-  const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
-  const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
-  auto krow = [&](int key) { return kbase + (size_t)min(key, n - 1) * D; };
-  auto vblk = [&](int t) { return vbase + (size_t)t * (D * 32); };
-  AttnAcc<D, NQ> acc;
-  acc.init();
-  if (w0 < w1) attn_loop<D, NQ>(acc, krow, vblk, w0, w1, qf, li, g, key_limit, scale_log2e);
-  float l = acc.l[0];
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-#pragma unroll
-  for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4*>(&sm[wave][li][dt * 16 + g * 4]) = acc.o[dt][0];
-  if (g == 0) { sm[wave][li][D] = acc.m[0]; sm[wave][li][D + 1] = l; }
-  __syncthreads();
-  for (int item = threadIdx.x; item < G * 32; item += 256) {     // item = (query head j, 4 consecutive d)
-    const int j = item >> 5, d4 = (item & 31) * 4;
-    float M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j][D]);
-    float den = 0.f;
-    f32x4 num = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float m = sm[w][j][D];
-      const float wt = (m == -INFINITY) ? 0.f : exp2f(m - M);
-      den += wt * sm[w][j][D + 1];
-      num += *reinterpret_cast<const f32x4*>(&sm[w][j][d4]) * wt;
-    }
-    const size_t slot = (((size_t)b * hkv + hk) * nsplit + split) * 16 + j;
-    *reinterpret_cast<f32x4*>(ws_o + slot * D + d4) = num;
-    if ((item & 31) == 0) { ws_ml[slot * 2] = M; ws_ml[slot * 2 + 1] = den; }
-  }
-}
-
 // grid = (Hq, B), 256 threads = 8 split groups x 32 lanes (4 consecutive d each).  Group q merges splits q, q+8, ...
 // with all its loads in flight at once; the 8 partial (m, num, den) triples are merged through LDS.
 __global__ __launch_bounds__(256) void attn_decode_combine_kernel(
@@ -1040,16 +976,6 @@ int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const i
 }
 
 // 0: the last-arriving block of each (stream, KV head) merges the key splits in the same launch (ticket + acquire);
-// partials only (no combine launch): the consumer merges the `nsplit` (o, m, l) triples of every head (decode_v2.hip)
-int attn_decode_partials_bf16(const bf16_t* q, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay,
-                              int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st) {
-  if (B <= 0) return 0;
-  if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads / lay.n_kv_heads > 16 || nsplit < 1) return LCC_ERR_SHAPE;
-  attn_decode_mw_kernel<<<dim3(nsplit, lay.n_kv_heads, B), dim3(256), 0, st>>>(q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit,
-                                                                                ws_o, ws_ml, scale_l2e(128));
-  return 0;
-}
-
 // 1: plain partials + attn_decode_combine_kernel as a second launch
 static int g_attn_fused_tail = 1;
 void set_attn_fused_tail(int v) { g_attn_fused_tail = v; }

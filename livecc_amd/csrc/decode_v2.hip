@@ -29,7 +29,7 @@ namespace lcc {
 
 __device__ unsigned int lcc_zero_page_v2[64];  // 256 zero bytes: activation operand of absent K chunks
 
-enum { DG_PRO_PLAIN = 0, DG_PRO_NORM = 1, DG_PRO_COMBINE = 2 };
+enum { DG_PRO_PLAIN = 0, DG_PRO_NORM = 1 };
 enum { DG_EPI_BF16 = 0, DG_EPI_SWIGLU = 1, DG_EPI_RESID = 2, DG_EPI_ROPE = 3 };
 
 // x fragment of 8 consecutive k for activation row m: PRO_NORM = bf16(w * bf16(h * r))
@@ -49,12 +49,10 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   static_assert(EPI != DG_EPI_SWIGLU || NTILE == 2, "swiglu needs the gate and the up tile in one block");
   static_assert(EPI == DG_EPI_SWIGLU || NTILE == 1, "one tile per block");
   __shared__ f32x4 red[NW - 1][NTILE][64];
-  // PRO_NORM / PRO_COMBINE: the activation rows are built ONCE per block in LDS (M * K <= 16384 elements) and the MFMA fragments are
+  // PRO_NORM: the activation rows are built ONCE per block in LDS (M * K <= 16384 elements) and the MFMA fragments are
   // read from there.  (The first version normalised every fragment in registers: 16 lanes of a wave computed the same 8 values and
   // every one of the N/16 blocks repeated it -- +6.7 us on the gate/up GEMV, +24 us on lm_head.)
   constexpr bool XLDS = PRO != DG_PRO_PLAIN;
-  __shared__ float s_stat[PRO == DG_PRO_NORM ? 4 * 128 : 1];    // M <= 4 rows x (hidden <= 8192) / 64 pieces
-  __shared__ float s_r[16];
   extern __shared__ __attribute__((aligned(16))) bf16_t s_x[];   // XLDS: M * K bf16 (dynamic: 7 KB for one stream at 7B)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int M = a.M, N = a.N, K = a.K;
@@ -122,19 +120,22 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   // ---- everything the kernel will need from the previous launch is requested up front, in ONE burst with the first two weight
   //      stages: vmcnt retires loads in issue order, so a small load issued after the weight stream would only return behind it
   //      (a 14-iteration dependent loop over the row statistics at this point cost 8 us per block in the first version) ----
-  // PRO_NORM: the M x n_stat per-tile sums of squares are spread over all threads of the block (one 16-byte piece each for M <= 4),
-  // and so are the 8-element pieces of the residual rows and of the norm weight that the block normalises into LDS
-  constexpr int T = NW * 64, PP = 2, XP = 2;      // XP row pieces per thread are requested up front (all of them for one stream)
-  const int n4 = a.n_stat >> 2, total4 = PRO == DG_PRO_NORM ? M * n4 : 0;
+  // PRO_NORM: every wave reads the n_stat per-tile sums of squares of each row itself (n_stat / 4 <= 128 16-byte pieces: one or two
+  // per lane, summed by a butterfly -- the same fixed order in every wave of every block), and the block's threads share the
+  // 8-element pieces of the residual rows and of the norm weight that are normalised into LDS
+  constexpr int T = NW * 64, XP = 2;      // XP row pieces per thread are requested up front (all of them for one stream)
+  const int n4 = a.n_stat >> 2;
   const int kp = K >> 3, xpieces = PRO == DG_PRO_NORM ? M * kp : 0;
-  f32x4 pv[PRO == DG_PRO_NORM ? PP : 1];
+  f32x4 pv[PRO == DG_PRO_NORM ? 4 : 1][2];
   u32x4 hv[PRO == DG_PRO_NORM ? XP : 1], nv[PRO == DG_PRO_NORM ? XP : 1];
   if (PRO == DG_PRO_NORM) {
 #pragma unroll
-    for (int u = 0; u < PP; ++u) {
-      const int p = (int)threadIdx.x + u * T;
-      pv[u] = *reinterpret_cast<const f32x4*>(a.stats + 4 * (size_t)(p < total4 ? p : 0));     // rows are contiguous: [M][n_stat]
-    }
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = lane + 64 * u;
+        pv[m][u] = *reinterpret_cast<const f32x4*>(a.stats + (size_t)min(m, M - 1) * a.n_stat + 4 * (i < n4 ? i : 0));
+      }
 #pragma unroll
     for (int u = 0; u < XP; ++u) {
       const int p = (int)threadIdx.x + u * T, pc = p < xpieces ? p : 0;
@@ -166,62 +167,23 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   load_x(c, sa);
   load_x(c + STEP, sb);
   if (PRO == DG_PRO_NORM) {
+    float rr[4];
 #pragma unroll
-    for (int u = 0; u < PP; ++u) {
-      const int p = (int)threadIdx.x + u * T;
-      if (p < total4) s_stat[p] = (pv[u][0] + pv[u][1]) + (pv[u][2] + pv[u][3]);
-    }
-    __syncthreads();
-    for (int m = wave; m < M; m += NW) {       // one wave per row: strided partial sums, then a butterfly (fixed order, same in every block)
+    for (int m = 0; m < 4; ++m) {
       float sacc = 0.f;
-      for (int i = lane; i < n4; i += 64) sacc += s_stat[m * n4 + i];
-      sacc = wave_sum(sacc);
-      if (lane == 0) s_r[m] = rsqrtf(sacc / (float)K + a.eps);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < n4) sacc += (pv[m][u][0] + pv[m][u][1]) + (pv[m][u][2] + pv[m][u][3]);
+      rr[m] = rsqrtf(wave_sum(sacc) / (float)K + a.eps);
     }
-    __syncthreads();
+    auto row_r = [&](int m) { return m == 0 ? rr[0] : (m == 1 ? rr[1] : (m == 2 ? rr[2] : rr[3])); };
 #pragma unroll
     for (int u = 0; u < XP; ++u) {
       const int p = (int)threadIdx.x + u * T;
-      if (p < xpieces) *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(hv[u], nv[u], s_r[p / kp]);
+      if (p < xpieces) *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(hv[u], nv[u], row_r(p / kp));
     }
     for (int p = (int)threadIdx.x + XP * T; p < xpieces; p += T)       // batches of several streams: the remaining pieces
-      *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(ld16(a.H + (size_t)p * 8), ld16(a.norm_w + (size_t)(p % kp) * 8), s_r[p / kp]);
-    __syncthreads();
-  }
-  if (PRO == DG_PRO_COMBINE) {
-    // merge of the decode attention's key splits (the arithmetic of attn_decode_combine_kernel): item = (row, query head, 4
-    // consecutive d); 8 partials in flight per item; the merged bf16 row goes to LDS where the MFMA fragments are read from
-    const int Hq = K >> 7, G = Hq / a.att_hkv, NS = a.att_ns;
-    for (int item = threadIdx.x; item < M * Hq * 32; item += T) {
-      const int m = item / (Hq * 32), rem = item - m * (Hq * 32), hq = rem >> 5, d4 = (rem & 31) * 4;
-      const size_t slot0 = (((size_t)m * a.att_hkv + hq / G) * NS) * 16 + (hq % G);
-      float Mx = -INFINITY, den = 0.f;
-      f32x4 num = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int s0 = 0; s0 < NS; s0 += 8) {
-        float m8[8], l8[8];
-        f32x4 o8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const size_t slot = slot0 + (size_t)min(s0 + u, NS - 1) * 16;
-          m8[u] = a.att_ml[slot * 2];
-          l8[u] = a.att_ml[slot * 2 + 1];
-          o8[u] = *reinterpret_cast<const f32x4*>(a.att_o + slot * 128 + d4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (s0 + u < NS) {
-            const float Mn = fmaxf(Mx, m8[u]);
-            const float al = (Mx == -INFINITY) ? 0.f : exp2f(Mx - Mn);
-            const float wt = (m8[u] == -INFINITY) ? 0.f : exp2f(m8[u] - Mn);
-            num = num * al + o8[u] * wt;
-            den = den * al + wt * l8[u];
-            Mx = Mn;
-          }
-        }
-      }
-      const float inv = 1.f / den;
-      *reinterpret_cast<u32x2*>(s_x + (size_t)m * K + hq * 128 + d4) = (u32x2){pack2(num[0] * inv, num[1] * inv), pack2(num[2] * inv, num[3] * inv)};
-    }
+      *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(ld16(a.H + (size_t)p * 8), ld16(a.norm_w + (size_t)(p % kp) * 8), row_r(p / kp));
     __syncthreads();
   }
   for (; c < nchunk; c += 2 * STEP) {
@@ -358,7 +320,7 @@ static int dg_check(const DgArgs& a, int pro, int epi) {
   if (a.M < 1 || a.M > 16 || (a.N & 15) || (a.K & 31) || a.W == nullptr) return LCC_ERR_SHAPE;
   if (pro == DG_PRO_PLAIN && (a.X == nullptr || (a.ldx & 7))) return LCC_ERR_ARG;
   if (pro == DG_PRO_NORM && (a.H == nullptr || a.stats == nullptr || a.norm_w == nullptr || a.n_stat != (a.K >> 4) || (a.n_stat & 3) ||
-                             a.M > 4 || a.M * a.K > 16384 || a.M * a.n_stat > 4 * 2 * 256)) return LCC_ERR_ARG;
+                             a.M > 4 || a.M * a.K > 16384 || a.n_stat > 512)) return LCC_ERR_ARG;
   if (epi == DG_EPI_RESID && (a.Hres == nullptr || a.stats_out == nullptr)) return LCC_ERR_ARG;
   if ((epi == DG_EPI_BF16 || epi == DG_EPI_SWIGLU) && a.C == nullptr) return LCC_ERR_ARG;
   if (epi == DG_EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
@@ -378,13 +340,6 @@ int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
 int dgemv_resid(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
   dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
-  return 0;
-}
-// [merge of the decode attention's key-split partials] o_proj [residual add + sums of squares]; M <= 2
-int dgemv_combine_resid(const DgArgs& a, hipStream_t st) {
-  if (a.M < 1 || a.M > 2 || (a.N & 15) || (a.K & 127) || a.K > 8192 || a.W == nullptr || a.att_o == nullptr || a.att_ml == nullptr ||
-      a.att_ns < 1 || a.att_hkv < 1 || ((a.K >> 7) % a.att_hkv) || a.Hres == nullptr || a.stats_out == nullptr) return LCC_ERR_ARG;
-  dgemv_kernel<1, DG_PRO_COMBINE, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
 }
 // [RMSNorm] gate/up Linear [SwiGLU]

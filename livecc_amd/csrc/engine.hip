@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -152,7 +153,7 @@ size_t lcc_engine::llm_ws_bytes() const {
   t += align_up(B * H * 2) * 2;              // last_h, last_xn
   t += align_up(16 * (H / 16 + 4) * 4);      // decode v2: per-tile sums of squares of the residual rows
   t += align_up(B * V * 2);                  // logits
-  t += align_up(std::max<size_t>(B * c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * c.n_q_heads * 8) * 128 * 4) * 2;  // attention split partials (o, ml)
+  t += align_up(std::max<size_t>(B * c.n_kv_heads * 128 * 16, std::min<size_t>(S, 1024) * c.n_q_heads * 8) * 128 * 4) * 2;  // attention split partials (o, ml)
   if (c.llm_fp8) t += align_up(std::max<size_t>((size_t)qkvd * H, 2 * I * H) * 2);   // bf16 dequantisation scratch of the largest LLM weight
   return t + 4096;
 }
@@ -533,7 +534,7 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
   b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H);
   b->stats = cv.take<float>(16 * (H / 16 + 4));
   b->logits = cv.take<bf16_t>(B * V);
-  const size_t nslot = std::max<size_t>(B * e->c.n_kv_heads * 64 * 16, std::min<size_t>(S, 1024) * e->c.n_q_heads * 8);
+  const size_t nslot = std::max<size_t>(B * e->c.n_kv_heads * 128 * 16, std::min<size_t>(S, 1024) * e->c.n_q_heads * 8);
   b->ws_o = cv.take<float>(nslot * 128); b->ws_ml = cv.take<float>(nslot * 128);
   b->dq = e->c.llm_fp8 ? cv.take<bf16_t>(std::max<size_t>((size_t)e->qkvd * H, 2 * I * H)) : nullptr;
   if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small");
@@ -664,12 +665,9 @@ bool decode_v2_ok(const lcc_engine* e) {
 // the 28 decoder layers of ONE decode step over B rows, v2 launch sequence.  On entry b.h / b.stats / b.cos / b.sin come from
 // decode_step_begin; on exit b.h is the residual stream after the last layer and b.stats its per-tile sums of squares (the final
 // RMSNorm runs as the prologue of the lm_head GEMV).
-int g_decode_combine = 1;   // 1: batches of <= 2 streams merge the attention key splits inside the o_proj GEMV (no combine launch)
-int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, int ntile_max, hipStream_t st) {
+int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, hipStream_t st) {
   const int H = e->c.hidden_size, I = e->c.intermediate_size;
   const float eps = e->c.rms_eps;
-  const bool fuse_combine = g_decode_combine && B <= 2 && e->qd <= 8192 && (e->qd & 127) == 0;
-  const int ns_fused = std::max(1, std::min(16, (ntile_max + 11) / 12));      // >= 12 key tiles (3 per wave) per block
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     DgArgs a;
@@ -677,16 +675,9 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     a.eps = eps; a.bias = L.qkv_b; a.cs = b.cos; a.sn = b.sin; a.tok_stream = d_slots; a.kv_len = e->d_kv_len; a.kv_base = e->d_kv_base;
     a.lay = e->lay; a.layer = l; a.q_out = b.q; a.n_q_heads = e->c.n_q_heads;
     LCC_TRY(dgemv_qkv_rope(a, st));
-    if (fuse_combine) {   // small batches: 4-wave attention blocks, <= 16 partials per head, merged in the o_proj GEMV's prologue
-      LCC_TRY(attn_decode_partials_bf16(b.q, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, ns_fused, b.ws_o, b.ws_ml, st));
-      a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.att_o = b.ws_o; a.att_ml = b.ws_ml; a.att_ns = ns_fused;
-      a.att_hkv = e->c.n_kv_heads; a.Hres = b.h; a.stats_out = b.stats;
-      LCC_TRY(dgemv_combine_resid(a, st));
-    } else {
-      LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
-      a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
-      LCC_TRY(dgemv_resid(a, st));
-    }
+    LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
+    a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
+    LCC_TRY(dgemv_resid(a, st));
     a = DgArgs(); a.W = L.gate_up_w; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
     a.eps = eps; a.C = b.act; a.ldc = I;
     const bool prof = e->prof_on && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();   // one sample per step
@@ -865,7 +856,10 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   if (!mw.put(slots, n_streams, &d_slots)) return fail(LCC_ERR_STATE, "meta ring slot too small");
   LCC_TRY(meta_commit(&mw, st));
   const int ntile = (max_len + 31) / 32;
-  const int nsplit = std::max(1, std::min(64, (ntile + 3) / 4));
+  // key tiles per split of the per-wave decode attention (tuning knob LCC_ATTN_TPS, default 4) and the split cap (LCC_ATTN_MAXSPLIT, 64)
+  static const int tps = [] { const char* v = getenv("LCC_ATTN_TPS"); return v ? std::max(1, atoi(v)) : 4; }();
+  static const int maxsplit = [] { const char* v = getenv("LCC_ATTN_MAXSPLIT"); return v ? std::max(1, std::min(128, atoi(v))) : 64; }();
+  const int nsplit = std::max(1, std::min(maxsplit, (ntile + tps - 1) / tps));
 
   LayerCtx cx{};
   cx.S = n_streams; cx.skinny = true; cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
@@ -882,7 +876,7 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
     if (v2) {
       LCC_TRY(decode_step_begin(d_slots, e->d_cur_tok, e->d_done, e->d_seen, e->words, e->embed, bf.h, bf.stats, e->c.hidden_size, e->d_pos,
                                 e->inv_freq, bf.cos, bf.sin, n_streams, st));
-      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, ntile, st));
+      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, st));
     } else {
       LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
       LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
@@ -899,9 +893,8 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
 
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_path(int path) {
-  if (path < 0 || path > 2) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence), 1 (v2) or 2 (v2 with a separate combine launch)");
-  g_decode_path = path ? 1 : 0;
-  g_decode_combine = path == 2 ? 0 : 1;
+  if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
+  g_decode_path = path;
   return 0;
 }
 // bit 0: engine uses the fused decode attention for batches of >= 16 (stream, KV head) pairs (default); bit 2: for every batch;

@@ -124,17 +124,12 @@ struct DgArgs {
   bf16_t* Hres = nullptr; float* stats_out = nullptr;                          // residual epilogue
   const bf16_t* cs = nullptr; const bf16_t* sn = nullptr; const int32_t* tok_stream = nullptr; const int32_t* kv_len = nullptr;
   bf16_t* const* kv_base = nullptr; KvLayout lay = {0, 0, 0, 0}; int layer = 0; bf16_t* q_out = nullptr; int n_q_heads = 0;   // rope epilogue
-  // attention-combine prologue (M <= 2): x = merged attention output of the `att_ns` key-split partials of attn_decode_partials_bf16
-  const float* att_o = nullptr; const float* att_ml = nullptr; int att_ns = 0; int att_hkv = 0;
 };
 int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_t* done, uint32_t* seen, int words, const bf16_t* table,
                       bf16_t* h, float* stats, int dim, const int32_t* pos, const float* inv_freq, bf16_t* cs, bf16_t* sn, int B,
                       hipStream_t st);
 int dgemv_qkv_rope(const DgArgs& a, hipStream_t st);      // [RMSNorm] q|k|v Linear (row-permuted decode copy) [bias + M-RoPE + KV append]
 int dgemv_resid(const DgArgs& a, hipStream_t st);         // o_proj / down_proj [residual add in place + per-tile sums of squares]
-int dgemv_combine_resid(const DgArgs& a, hipStream_t st); // [merge of the decode-attention key splits] o_proj [residual add + sums of squares]
-int attn_decode_partials_bf16(const bf16_t* q, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base, KvLayout lay,
-                              int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
 int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st);   // [RMSNorm] gate/up Linear [SwiGLU]
 int dgemv_norm_bf16(const DgArgs& a, hipStream_t st);     // [final RMSNorm] lm_head
 
