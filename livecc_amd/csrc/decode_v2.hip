@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int i = lane + 64 * u;
+        const int i = lane + 64 * u;           // unconditional (clamped) loads: a branch here would serialise them
         pv[m][u] = *reinterpret_cast<const f32x4*>(a.stats + (size_t)min(m, M - 1) * a.n_stat + 4 * (i < n4 ? i : 0));
       }
 #pragma unroll
@@ -162,10 +162,14 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
       e_base = a.kv_base[strm];
     }
   }
+  // keep the small loads AHEAD of the weight stream in the memory queue (vmcnt retires in issue order): the compiler otherwise
+  // sinks some of them behind the weight loads and then has to wait for the whole first stage before the prologue can run
+  __builtin_amdgcn_sched_barrier(0);
   load_w(c, sa);
   load_w(c + STEP, sb);
   load_x(c, sa);
   load_x(c + STEP, sb);
+  __builtin_amdgcn_sched_barrier(0);
   if (PRO == DG_PRO_NORM) {
     float rr[4];
 #pragma unroll

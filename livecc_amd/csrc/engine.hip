@@ -866,9 +866,9 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   cx.nsplit_attn = nsplit;
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
   cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
-  // v2 builds the normalised rows of the batch in LDS (M * hidden <= 16384 elements): batches of up to 4 streams at 7B / 2B shapes,
-  // 2 at 72B; larger batches keep the round-1 launch sequence (its per-layer launch latency is amortised over the batch)
-  const bool v2 = decode_v2_ok(e) && n_streams <= 4 && (long)n_streams * e->c.hidden_size <= 16384;
+  // v2 serves batches of one or two streams (measured on MI355X at 7B shapes: 246 vs 242 tokens/s for one stream, 414 vs 410 for
+  // two, but 640 vs 655 for four: with more rows the per-block normalisation prologue outweighs the saved launches)
+  const bool v2 = decode_v2_ok(e) && n_streams <= 2 && (long)n_streams * e->c.hidden_size <= 16384;
   for (int step = 0; step < n_steps; ++step) {
     const bool prof_step = e->prof_on && (step & 3) == 0 && 2 * (e->step_n + 1) <= (int)e->step_ev.size();   // every 4th step
     if (prof_step) HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n], st));

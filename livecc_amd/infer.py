@@ -85,6 +85,7 @@ class LiveCCDemoInfer:
             self.streaming_eos_token_id = streaming_eos_token_id
             self.system_prompt_offset = None
         self._cached_video_readers_with_hw = {}
+        self.last_generated: list = []      # per generate call of the most recent flows: span, new prompt ids, generated ids
 
     # --------------------------------------------------------------------------------------------------------------
     # one generate call per chunk (ref demo/infer.py:132-180, step 5)
@@ -119,6 +120,7 @@ class LiveCCDemoInfer:
         state["past_ids"] = seq[:-1]                      # ref infer.py:174
         state["turn_index"] = turn + 1
         new_tokens = seq[len(ids):].tolist()
+        self.last_generated.append(dict(span=(start, stop), prompt_ids=new_ids, tokens=new_tokens))   # diagnostics / parity tests
         return self.decode([t for t in new_tokens if t not in self.model.eos_token_ids])
 
     # --------------------------------------------------------------------------------------------------------------
@@ -271,7 +273,7 @@ class LiveCCDemoInfer:
             state["past_key_values"], state["past_ids"] = out.past_key_values, seq[:-1]
         state["turn_index"] = state.get("turn_index", 0) + 1
         new_tokens = seq[len(ids):].tolist()
-        state["last_new_tokens"] = new_tokens
+        self.last_generated.append(dict(span=None, prompt_ids=new_ids, tokens=new_tokens))
         return self.decode([t for t in new_tokens if t not in self.model.eos_token_ids]), state
 
     # --------------------------------------------------------------------------------------------------------------

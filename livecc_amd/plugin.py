@@ -37,8 +37,12 @@ def lcc_apply_multimodal_rotary_pos_emb(q, k, cos, sin, mrope_section, unsqueeze
     """Same signature as HF's function (Q2VL:180-222): q [B,Hq,S,128], k [B,Hkv,S,128], cos/sin [3,B,S,128] in the model dtype.
     The per-axis channel selection is index bookkeeping (host-side views); the rotation itself -- HF's bf16 op sequence
     bf16(bf16(x*cos) + bf16(rotate_half(x)*sin)) -- runs in the M-RoPE kernel (bit-exact vs HF, tests/test_gpu_ops.py)."""
-    if unsqueeze_dim != 1 or q.dtype != torch.bfloat16 or not q.is_cuda or q.shape[-1] != 128:
-        raise ValueError("livecc_amd M-RoPE: bf16 GPU tensors [B, heads, S, 128] expected")
+    if not q.is_cuda:
+        # a module-level function rebinding is process-wide (as liger's is): tensors of models that do not live on the GPU are not
+        # this library's business and go to HF's own function
+        return _SAVED["apply_multimodal_rotary_pos_emb"](q, k, cos, sin, mrope_section, unsqueeze_dim)
+    if unsqueeze_dim != 1 or q.dtype != torch.bfloat16 or q.shape[-1] != 128:
+        raise ValueError("livecc_amd M-RoPE: bf16 tensors [B, heads, S, 128] expected")
     sec = list(mrope_section) * 2
     cs = torch.cat([m[i % 3] for i, m in enumerate(cos.split(sec, dim=-1))], dim=-1)      # [B,S,128], halves identical
     sn = torch.cat([m[i % 3] for i, m in enumerate(sin.split(sec, dim=-1))], dim=-1)
