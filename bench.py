@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--attn-variant", type=int, default=None, help="debug A/B: lcc_debug_set_attn_variant")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--decode-path", type=int, default=None, help="debug A/B: lcc_debug_set_decode_path")
+    ap.add_argument("--no-prefetch", action="store_true", help="A/B: do not overlap the next turn's vision tower with this turn's decode steps")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="wall-clock budget of the CPU baseline leg, seconds")
@@ -112,15 +113,18 @@ class StandInModel:
         return outs
 
 
-def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod):
-    """One back-to-back replay of all local streams, batched turn by turn.  Returns (tokens, frames)."""
+def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod, prefetch=True):
+    """One back-to-back replay of all local streams, batched turn by turn.  Returns (tokens, frames).  `prefetch`: the frames are
+    resident, so every turn hands the NEXT turn's clips to generate_batch, whose vision tower then runs on a side stream under this
+    turn's decode steps (same work, same results, overlapped)."""
     n = len(frames_list)
     builders = [protocol.TurnBuilder(cfg, seed=s) for s in builders_seed]
     states = [None] * n
     past = [None] * n
     tokens = 0
     nframes = frames_list[0].shape[0]
-    for ti, (a, b) in enumerate(protocol.split_clip(nframes)):
+    chunks = protocol.split_clip(nframes)
+    for ti, (a, b) in enumerate(chunks):
         reqs = []
         for i in range(n):
             clip = frames_list[i][a:b]
@@ -128,7 +132,11 @@ def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod)
             new = builders[i].turn_ids(ti, protocol.num_video_tokens(grid, cfg))
             ids = new if past[i] is None else np.concatenate([past[i], new])
             reqs.append(dict(input_ids=torch_mod.from_numpy(ids), frames=clip, frames_layout="THWC", state=states[i]))
-        outs = model.generate_batch(reqs, repetition_penalty=1.05, max_new_tokens=max_new, force_length=True)
+        nxt = None
+        if prefetch and ti + 1 < len(chunks):
+            na, nb = chunks[ti + 1]
+            nxt = [dict(frames=frames_list[i][na:nb], frames_layout="THWC") for i in range(n)]
+        outs = model.generate_batch(reqs, repetition_penalty=1.05, max_new_tokens=max_new, force_length=True, **({"prefetch": nxt} if nxt else {}))
         for i, o in enumerate(outs):
             states[i] = o.past_key_values
             seq = o.sequences[0].cpu().numpy()
@@ -337,8 +345,9 @@ def main():
     seeds = [1234 + rank * spg + i for i in range(spg)]
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
 
+    pf = not args.no_prefetch
     for _ in range(args.warmup):
-        replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
+        replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, pf)
     if model.engine is not None:
         model.engine.profile(True, 16384)
     D.barrier(dev)
@@ -346,7 +355,7 @@ def main():
     t0 = time.perf_counter()
     toks = nfr = 0
     for _ in range(args.steps):
-        a, b = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
+        a, b = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, pf)
         toks += a
         nfr += b
     sync()

@@ -215,6 +215,13 @@ size_t lcc_engine_meta_bytes(const lcc_engine* e);
 int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* state_dev, size_t state_bytes,
                             void* meta_dev, void* meta_host_pinned, size_t meta_bytes);
 int lcc_engine_bind_kv(lcc_engine* e, int slot, void* kv_dev, size_t bytes);   /* zero-initialised arena */
+/* optional: a PRIVATE activation workspace and meta ring (device + pinned host) for lcc_vit_encode.  Without them the ViT shares the
+ * engine workspace with the LLM (one stream).  With them lcc_vit_encode may be issued on a second HIP stream and overlap LLM calls:
+ * the vision tower of the NEXT turn's frames (compute-bound MFMA work) runs under the current turn's decode steps (HBM-bound weight
+ * streaming) -- the caller orders consumers behind it with events. */
+size_t lcc_engine_vit_workspace_bytes(const lcc_engine* e);
+size_t lcc_engine_vit_meta_bytes(const lcc_engine* e);
+int lcc_engine_bind_vit_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* meta_dev, void* meta_host_pinned, size_t meta_bytes);
 /* weights by name, borrowed device pointers (bf16 unless stated):  see INTEGRATION.md for the name table */
 int lcc_engine_set_weight(lcc_engine* e, const char* name, const void* dev, int64_t numel);
 int lcc_engine_weights_ready(const lcc_engine* e, char* missing, int missing_len);

@@ -119,6 +119,13 @@ struct lcc_engine {
   int meta_next = 0;
   hipEvent_t meta_ev[META_RING] = {};
   bool meta_ev_used[META_RING] = {};
+  // optional private workspace + meta ring of the ViT, so that lcc_vit_encode may run on a SECOND stream concurrently with the LLM
+  // (the next turn's frames are encoded under the current turn's decode steps); slot events are recorded after the LAST ViT kernel
+  char* ws_vit = nullptr; size_t ws_vit_bytes = 0;
+  char *vmeta_dev = nullptr, *vmeta_host = nullptr; size_t vmeta_slot_bytes = 0;
+  int vmeta_next = 0;
+  hipEvent_t vmeta_ev[2] = {};
+  bool vmeta_ev_used[2] = {};
 
   // device state (inside `state`)
   int32_t *d_kv_len = nullptr, *d_pos = nullptr, *d_hist_col = nullptr, *d_cur_tok = nullptr, *d_done = nullptr, *d_history = nullptr;
@@ -193,6 +200,7 @@ extern "C" lcc_engine* lcc_engine_create(const lcc_model_config* cfg, const lcc_
 extern "C" void lcc_engine_destroy(lcc_engine* e) {
   if (!e) return;
   for (int i = 0; i < META_RING; ++i) if (e->meta_ev[i]) (void)hipEventDestroy(e->meta_ev[i]);
+  for (int i = 0; i < 2; ++i) if (e->vmeta_ev[i]) (void)hipEventDestroy(e->vmeta_ev[i]);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->step_ev) (void)hipEventDestroy(ev);
   delete e;
@@ -267,6 +275,23 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
   e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
   HIP_TRY(hipMemset(e->state, 0, state_bytes));
   for (int i = 0; i < META_RING; ++i) if (!e->meta_ev[i]) HIP_TRY(hipEventCreateWithFlags(&e->meta_ev[i], hipEventDisableTiming));
+  return 0;
+}
+
+extern "C" size_t lcc_engine_vit_workspace_bytes(const lcc_engine* e) { return e->vit_ws_bytes(); }
+extern "C" size_t lcc_engine_vit_meta_bytes(const lcc_engine* e) {
+  const size_t P = e->lim.max_patches;
+  return align_up((P + 7 * (P / 16 + 64) + 64) * 4 + 4096, 4096) * 2;
+}
+extern "C" int lcc_engine_bind_vit_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* meta_dev, void* meta_host_pinned,
+                                           size_t meta_bytes) {
+  if (!e || !workspace_dev || !meta_dev || !meta_host_pinned) return fail(LCC_ERR_ARG, "null buffer");
+  if (ws_bytes < e->vit_ws_bytes() || meta_bytes < lcc_engine_vit_meta_bytes(e))
+    return fail(LCC_ERR_STATE, "ViT buffer too small: ws %zu/%zu meta %zu/%zu", ws_bytes, e->vit_ws_bytes(), meta_bytes, lcc_engine_vit_meta_bytes(e));
+  if (((uintptr_t)workspace_dev | (uintptr_t)meta_dev) & 255) return fail(LCC_ERR_ALIGN, "buffers must be 256-byte aligned");
+  e->ws_vit = (char*)workspace_dev; e->ws_vit_bytes = ws_bytes;
+  e->vmeta_dev = (char*)meta_dev; e->vmeta_host = (char*)meta_host_pinned; e->vmeta_slot_bytes = lcc_engine_vit_meta_bytes(e) / 2;
+  for (int i = 0; i < 2; ++i) if (!e->vmeta_ev[i]) HIP_TRY(hipEventCreateWithFlags(&e->vmeta_ev[i], hipEventDisableTiming));
   return 0;
 }
 
@@ -446,7 +471,8 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   if (P > e->lim.max_patches) return fail(LCC_ERR_STATE, "%d patches > max_patches %d", P, e->lim.max_patches);
   const int n_tiles = (int)tile_seg.size(), n_seg = (int)seg_start.size(), n_groups = (int)grp_seg.size();
 
-  Carver cv; cv.base = e->ws;
+  const bool own = e->ws_vit != nullptr;     // private buffers: this call may overlap LLM work on another stream
+  Carver cv; cv.base = own ? e->ws_vit : e->ws;
   bf16_t* patches = cv.take<bf16_t>((size_t)P * PD);
   bf16_t* x = cv.take<bf16_t>((size_t)P * E);
   bf16_t* xn = cv.take<bf16_t>((size_t)P * E);
@@ -455,16 +481,26 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   bf16_t* mlp = cv.take<bf16_t>((size_t)P * MLP);
   bf16_t* vt = cv.take<bf16_t>((size_t)heads * blocks * 80 * 32);
   bf16_t* mg = cv.take<bf16_t>((size_t)(P / 4) * 4 * E);
-  if (cv.off > e->ws_bytes) return fail(LCC_ERR_STATE, "workspace too small for %d patches", P);
+  if (cv.off > (own ? e->ws_vit_bytes : e->ws_bytes)) return fail(LCC_ERR_STATE, "workspace too small for %d patches", P);
 
-  MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
+  MetaWriter mw;
+  int vslot = -1;
+  if (own) {   // private 2-slot ring; a slot is reused only after the ViT call that used it has completely finished
+    vslot = e->vmeta_next; e->vmeta_next ^= 1;
+    if (e->vmeta_ev_used[vslot]) HIP_TRY(hipEventSynchronize(e->vmeta_ev[vslot]));
+    mw.e = e; mw.slot = vslot; mw.host = e->vmeta_host + (size_t)vslot * e->vmeta_slot_bytes; mw.dev = e->vmeta_dev + (size_t)vslot * e->vmeta_slot_bytes;
+    mw.off = 0; mw.cap = e->vmeta_slot_bytes;
+  } else {
+    LCC_TRY(meta_begin(e, &mw));
+  }
   int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0, *d_grp_seg, *d_grp_q0;
   if (!mw.put(seg_start.data(), n_seg, &d_seg_start) || !mw.put(seg_len.data(), n_seg, &d_seg_len) ||
       !mw.put(seg_blk.data(), n_seg, &d_seg_blk) || !mw.put(seg_of_patch.data(), P, &d_seg_of_patch) ||
       !mw.put(tile_seg.data(), n_tiles, &d_tile_seg) || !mw.put(tile_q0.data(), n_tiles, &d_tile_q0) ||
       !mw.put(grp_seg.data(), n_groups, &d_grp_seg) || !mw.put(grp_q0.data(), n_groups, &d_grp_q0))
     return fail(LCC_ERR_STATE, "meta ring slot too small");
-  LCC_TRY(meta_commit(&mw, st));
+  if (own) HIP_TRY(hipMemcpyAsync(mw.dev, mw.host, mw.off, hipMemcpyHostToDevice, st));
+  else LCC_TRY(meta_commit(&mw, st));
 
   // K1: patches
   {
@@ -509,6 +545,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   g = GemmArgs(); g.w_packed = 1; g.A = mg; g.lda = 4 * E; g.W = e->mg_fc2_w; g.ldw = 4 * E; g.bias = e->mg_fc2_b; g.C = (bf16_t*)out_embeds; g.ldc = H;
   g.M = P / 4; g.N = H; g.K = 4 * E;
   LCC_TRY(gemm_bf16(g, st));
+  if (own) { HIP_TRY(hipEventRecord(e->vmeta_ev[vslot], st)); e->vmeta_ev_used[vslot] = true; }
   return check_launch("lcc_vit_encode");
 }
 

@@ -108,6 +108,14 @@ class Engine:
         _lib.check(lib.lcc_engine_bind_buffers(h, self._ws.data_ptr(), self._ws.numel(), self._state.data_ptr(),
                                                self._state.numel(), self._meta_dev.data_ptr(), self._meta_host.data_ptr(), mb),
                    "lcc_engine_bind_buffers")
+        # private ViT workspace + meta ring: the vision tower of the NEXT turn's frames may then run on a second stream under the
+        # current turn's decode steps (modeling.generate_batch(prefetch=...))
+        self._ws_vit = torch.empty(lib.lcc_engine_vit_workspace_bytes(h), dtype=torch.uint8, device=self.device)
+        vmb = lib.lcc_engine_vit_meta_bytes(h)
+        self._vmeta_dev = torch.empty(vmb, dtype=torch.uint8, device=self.device)
+        self._vmeta_host = torch.empty(vmb, dtype=torch.uint8).pin_memory()
+        _lib.check(lib.lcc_engine_bind_vit_buffers(h, self._ws_vit.data_ptr(), self._ws_vit.numel(), self._vmeta_dev.data_ptr(),
+                                                   self._vmeta_host.data_ptr(), vmb), "lcc_engine_bind_vit_buffers")
         kvb = lib.lcc_engine_kv_bytes_per_slot(h)
         self.kv_bytes_per_slot = kvb
         self._kv = [torch.zeros(kvb, dtype=torch.uint8, device=self.device) for _ in range(max_slots)]
@@ -156,9 +164,10 @@ class Engine:
             self._rope_cache[key] = (c.to(self.device), s.to(self.device))
         return self._rope_cache[key]
 
-    def vit_encode(self, clips: Sequence[dict]) -> torch.Tensor:
+    def vit_encode(self, clips: Sequence[dict], stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
         """clips: dicts with either {'frames': uint8 device tensor, 'layout': 'THWC'|'TCHW'} or
-        {'pixel_values': fp32 device [P,1176], 'grid': (t,h,w)}.  Returns bf16 [sum P/4, hidden]."""
+        {'pixel_values': fp32 device [P,1176], 'grid': (t,h,w)}.  Returns bf16 [sum P/4, hidden].  `stream`: launch on that stream
+        (the ViT has its own workspace; the caller orders consumers and later ViT calls with events)."""
         cfg = self.cfg
         arr = (_lib.Clip * len(clips))()
         grids, keep = [], []
@@ -187,9 +196,15 @@ class Engine:
                 keep.append(pv)
         P = sum(t * h * w for t, h, w in grids)
         cos, sin = self._rope(grids)
-        out = torch.empty(P // 4, cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        if stream is None:
+            out = torch.empty(P // 4, cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+            st = self._stream()
+        else:
+            with torch.cuda.stream(stream):
+                out = torch.empty(P // 4, cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+            st = stream.cuda_stream
         _lib.check(self.lib.lcc_vit_encode(self.h, len(clips), arr, self._mean, self._std, cos.data_ptr(), sin.data_ptr(),
-                                           out.data_ptr(), self._stream()), "lcc_vit_encode")
+                                           out.data_ptr(), st), "lcc_vit_encode")
         return out
 
     def prefill(self, slots: Sequence[int], ids: Sequence[np.ndarray], pos3: Sequence[np.ndarray],

@@ -111,6 +111,10 @@ class LiveCCForConditionalGeneration:
             raise NotImplementedError(f"at most two EOS ids are supported, got {ids}")
         self.eos_token_ids = ids
         self.config.eos_token_id = ids[0] if len(ids) == 1 else list(ids)
+        # vision-tower prefetch (generate_batch(prefetch=...)): side stream, results keyed by the clip's storage
+        self._side: Optional[torch.cuda.Stream] = None
+        self._vit_cache: dict = {}
+        self._vit_last_event: Optional[torch.cuda.Event] = None
 
     # ---- constructors ----
     @classmethod
@@ -228,11 +232,15 @@ class LiveCCForConditionalGeneration:
     def generate_batch(self, requests: Sequence[dict], repetition_penalty: float = 1.0, logits_processor=None,
                        max_new_tokens: int = 16, force_length: bool = False, eos_token_id=None,
                        output_logits: bool = False, output_scores: bool = False, do_sample: bool = False, temperature: float = 1.0,
-                       top_k: int = 0, top_p: float = 1.0, seed: int = 0) -> List[GenerateOutput]:
+                       top_k: int = 0, top_p: float = 1.0, seed: int = 0, prefetch: Optional[Sequence[dict]] = None) -> List[GenerateOutput]:
         """Many streams, one call: the ViTs of all clips run as one batch, all prefills as one packed batch, and the
         decode steps advance every stream together (weights are streamed from HBM once per step for the whole batch).
         Each request: input_ids (1-D, full history like the reference's cat(past_ids, new_ids)), optional
-        pixel_values_videos+video_grid_thw or uint8 frames, and `state` (StreamState or None)."""
+        pixel_values_videos+video_grid_thw or uint8 frames, and `state` (StreamState or None).
+        `prefetch`: clips ({'frames': uint8 GPU tensor, 'frames_layout': ...}) that a LATER call will pass as `frames`: their vision
+        tower (compute-bound) is launched on a low-priority side stream right after this call's prefill and runs under its decode
+        steps (HBM-bound weight streaming); the later call picks the embeddings up by the clip's storage (pointer, shape, layout).
+        The frames must not be modified in between.  Results are bit-identical to the un-prefetched call."""
         cfg, eng = self.cfg, self.engine
         if eos_token_id is None:
             eos_ids = list(self.eos_token_ids)
@@ -266,7 +274,7 @@ class LiveCCForConditionalGeneration:
                     f = f.contiguous()
                     T, H, W = (f.shape[0], f.shape[2], f.shape[3]) if lay == "TCHW" else (f.shape[0], f.shape[1], f.shape[2])
                     grids = [protocol.grid_of(T, H, W, cfg)]
-                    clips.append(dict(frames=f, layout=lay))
+                    clips.append(dict(frames=f, layout=lay, key=self._clip_key(f, lay)))
                 elif rq.get("pixel_values_videos") is not None:
                     g = torch.as_tensor(rq["video_grid_thw"]).reshape(-1, 3).tolist()
                     pv = rq["pixel_values_videos"].to(self.device, dtype=torch.float32).contiguous()
@@ -282,7 +290,7 @@ class LiveCCForConditionalGeneration:
                                      f"{sum(protocol.num_video_tokens(g, cfg) for g in grids)}")
             pos3.append(self._positions(st, new, grids, past_len))
             states.append(st); ids_new.append(new); slots.append(st.slot); full_ids.append(ids_full)
-        vit = self._vit_encode(clips) if clips else None
+        vit = self._vit_for(clips) if clips else None
         V = cfg.vocab_size
         logits_buf = torch.empty(max_new_tokens, n, V, dtype=torch.bfloat16, device=self.device) if output_logits else None
         scores_buf = torch.empty(n, V, dtype=torch.float32, device=self.device) if output_scores else None
@@ -290,6 +298,8 @@ class LiveCCForConditionalGeneration:
                       thr_token=thr[0] if thr else -1, thr_base=thr[1] if thr else None, thr_step=thr[2] if thr else 0.0,
                       eos_token2=eos2, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
         self._prefill(slots, ids_new, pos3, vit, sp, scores_buf, logits_buf)
+        if prefetch:
+            self._prefetch_vit(prefetch)
         # decode: the device loop needs no host round trip per token (EOS freezes a slot on the device); long generations
         # (video_qa: max_new_tokens=512, ref demo/infer.py:236) are cut into chunks of 32 steps so that the host can stop
         # early once every stream has emitted EOS.
@@ -315,8 +325,79 @@ class LiveCCForConditionalGeneration:
                                        scores=scores_buf[b] if scores_buf is not None else None))
         return outs
 
+    # ---- vision-tower prefetch on a side stream ----
+    @staticmethod
+    def _clip_key(f: torch.Tensor, lay: str):
+        return (f.data_ptr(), tuple(f.shape), lay)
+
+    def _side_stream(self) -> torch.cuda.Stream:
+        if self._side is None:
+            prio = 0
+            try:   # numerically greatest = lowest priority: decode kernels win the arbitration for CUs
+                prio = max(torch.cuda.Stream.priority_range())
+            except Exception:
+                pass
+            self._side = torch.cuda.Stream(device=self.device, priority=prio)
+        return self._side
+
+    def _prefetch_vit(self, prefetch: Sequence[dict]) -> None:
+        main = torch.cuda.current_stream(self.device)
+        side = self._side_stream()
+        todo = []
+        for c in prefetch:
+            f, lay = c["frames"], c.get("frames_layout", c.get("layout", "TCHW"))
+            if not f.is_cuda or not f.is_contiguous():
+                continue
+            k = self._clip_key(f, lay)
+            if k not in self._vit_cache:
+                todo.append((k, dict(frames=f, layout=lay)))
+        if not todo:
+            return
+        side.wait_stream(main)      # the ViT workspace is free and this turn's prefill is enqueued: start under the decode steps
+        with torch.cuda.stream(side):
+            for k, clip in todo:    # one launch sequence per clip keeps the embeddings separable per stream
+                emb = self._vit_encode([clip], stream=side)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self._vit_cache[k] = (emb, ev, clip["frames"])
+                self._vit_last_event = ev
+        while len(self._vit_cache) > 64:        # unclaimed prefetches do not accumulate
+            self._vit_cache.pop(next(iter(self._vit_cache)))
+
+    def _vit_for(self, clips: Sequence[dict]) -> torch.Tensor:
+        """Embeddings of this call's clips in request order: prefetched ones are claimed (after their event), the rest is encoded now."""
+        main = torch.cuda.current_stream(self.device)
+        hits = {i: self._vit_cache.pop(c["key"]) for i, c in enumerate(clips) if c.get("key") in self._vit_cache}
+        miss = [i for i in range(len(clips)) if i not in hits]
+        if self._vit_last_event is not None and (miss or hits):
+            main.wait_event(self._vit_last_event)          # ViT calls share one workspace: never two in flight
+            if not self._vit_cache:
+                self._vit_last_event = None
+        if not hits:
+            return self._vit_encode(clips)
+        parts: dict = {}
+        for i, (emb, ev, _keep) in hits.items():
+            main.wait_event(ev)
+            emb.record_stream(main)
+            parts[i] = emb
+        if miss:
+            cfg = self.cfg
+            got = self._vit_encode([clips[i] for i in miss])
+            off = 0
+            for i in miss:
+                c = clips[i]
+                if "frames" in c:
+                    f, lay = c["frames"], c.get("layout", "THWC")
+                    H, W = (f.shape[1], f.shape[2]) if lay == "THWC" else (f.shape[2], f.shape[3])
+                    n = ((f.shape[0] + 1) // 2) * (H // cfg.patch_size) * (W // cfg.patch_size) // 4
+                else:
+                    n = c["grid"][0] * c["grid"][1] * c["grid"][2] // 4
+                parts[i] = got[off:off + n]
+                off += n
+        return parts[0] if len(parts) == 1 else torch.cat([parts[i] for i in range(len(clips))], dim=0)
+
     # ---- long inputs: pieces that fit one launch sequence ----
-    def _vit_encode(self, clips: Sequence[dict]) -> torch.Tensor:
+    def _vit_encode(self, clips: Sequence[dict], stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
         """ViT + merger over all clips; clips that exceed `max_patches` are encoded in groups of temporal slices (a slice only
         attends to itself, so the concatenation is exact)."""
         cfg, eng = self.cfg, self.engine
@@ -354,7 +435,7 @@ class LiveCCForConditionalGeneration:
             cur.append(pc); cur_p += n
         if cur:
             groups.append(cur)
-        outs = [eng.vit_encode(g) for g in groups]
+        outs = [eng.vit_encode(g, stream=stream) for g in groups]
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def _prefill(self, slots, ids_new, pos3, vit, sp, scores_buf, logits_buf) -> None:

@@ -621,3 +621,43 @@ def test_decode_pipeline_v2_matches_the_round1_launch_sequence(dev, shape):
                     break      # histories diverged on a sub-margin token: later steps are not comparable
         record(f"decode_v2_vs_round1[{shape},{n_streams}]", dict(worst_rel_dlogit=worst))
         assert worst <= 3e-2, f"v2 vs round-1 decode logits differ by {worst:.3g} of the logit scale"
+
+
+def test_vision_tower_prefetch_on_a_side_stream_is_bit_identical(dev, tiny_models):
+    """generate_batch(prefetch=next clips): the next turn's ViT runs on a low-priority side stream under this turn's decode steps
+    (own workspace + meta ring in the engine).  Same kernels, same inputs -> bit-identical logits and tokens, for one stream and a
+    two-stream batch, including a turn whose clip was NOT prefetched (cache miss next to hits)."""
+    from livecc_amd import protocol
+    cfg, hf16, hf32, native = tiny_models
+    frames = [torch.from_numpy(protocol.synth_frames(12, 56, 84, seed=70 + i, layout="TCHW")).to(dev) for i in range(2)]
+
+    def run(n, prefetch):
+        builders = [protocol.TurnBuilder(cfg, seed=70 + i) for i in range(n)]
+        states, past, out = [None] * n, [None] * n, []
+        chunks = protocol.split_clip(12)
+        for ti, (a, b) in enumerate(chunks):
+            reqs = []
+            for i in range(n):
+                grid = protocol.grid_of(b - a, 56, 84, cfg)
+                new = builders[i].turn_ids(ti, protocol.num_video_tokens(grid, cfg))
+                ids = new if past[i] is None else np.concatenate([past[i], new])
+                reqs.append(dict(input_ids=torch.from_numpy(ids), frames=frames[i][a:b], frames_layout="TCHW", state=states[i]))
+            nxt = None
+            if prefetch and ti + 1 < len(chunks):
+                na, nb = chunks[ti + 1]
+                nxt = [dict(frames=frames[i][na:nb], frames_layout="TCHW") for i in range(n) if not (ti == 1 and i == 1)]   # one miss
+            res = native.generate_batch(reqs, repetition_penalty=1.05, max_new_tokens=4, force_length=True, output_logits=True, prefetch=nxt)
+            for i, o in enumerate(res):
+                states[i] = o.past_key_values
+                seq = o.sequences[0].cpu().numpy()
+                past[i] = seq[:-1]
+                out.append((seq[-4:].tolist(), o.logits.float().cpu()))
+        for s in states:
+            s.release()
+        return out
+
+    for n in (1, 2):
+        a, b = run(n, True), run(n, False)
+        assert len(native._vit_cache) == 0, "every prefetched clip was claimed"
+        for (ta, la), (tb, lb) in zip(a, b):
+            assert ta == tb and torch.equal(la, lb)
