@@ -332,6 +332,23 @@ class LiveCCForConditionalGeneration:
 
     def _side_stream(self) -> torch.cuda.Stream:
         if self._side is None:
+            import os
+            n_cu = int(os.environ.get("LCC_VIT_CUS", "0") or 0)
+            if n_cu > 0:
+                # Restrict the prefetch stream to `n_cu` compute units (hipExtStreamCreateWithCUMask): the vision tower's 8-wave GEMM
+                # blocks take a whole CU's LDS, and the HBM-bound decode kernels lose every CU they sit on; with a mask the ViT runs
+                # longer but on fewer CUs, still inside the decode window.
+                import ctypes as C
+                from . import _lib
+                hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+                words = (C.c_uint32 * 8)(*[(0xFFFFFFFF if n_cu >= 32 * (w + 1) else ((1 << max(0, n_cu - 32 * w)) - 1)) for w in range(8)])
+                h = C.c_void_p()
+                torch.cuda.set_device(self.device)
+                rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(8), words)
+                if rc != 0 or not h.value:
+                    raise _lib.LccError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+                self._side = torch.cuda.ExternalStream(h.value, device=self.device)
+                return self._side
             prio = 0
             try:   # numerically greatest = lowest priority: decode kernels win the arbitration for CUs
                 prio = max(torch.cuda.Stream.priority_range())
@@ -354,13 +371,19 @@ class LiveCCForConditionalGeneration:
         if not todo:
             return
         side.wait_stream(main)      # the ViT workspace is free and this turn's prefill is enqueued: start under the decode steps
+        cfg = self.cfg
         with torch.cuda.stream(side):
-            for k, clip in todo:    # one launch sequence per clip keeps the embeddings separable per stream
-                emb = self._vit_encode([clip], stream=side)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                self._vit_cache[k] = (emb, ev, clip["frames"])
-                self._vit_last_event = ev
+            emb = self._vit_encode([c for _, c in todo], stream=side)     # ONE batched launch sequence (large-M GEMMs), sliced per clip
+            ev = torch.cuda.Event()
+            ev.record(side)
+            off = 0
+            for k, clip in todo:
+                f, lay = clip["frames"], clip["layout"]
+                H, W = (f.shape[1], f.shape[2]) if lay == "THWC" else (f.shape[2], f.shape[3])
+                n = ((f.shape[0] + 1) // 2) * (H // cfg.patch_size) * (W // cfg.patch_size) // 4
+                self._vit_cache[k] = (emb[off:off + n], ev, (clip["frames"], emb))
+                off += n
+            self._vit_last_event = ev
         while len(self._vit_cache) > 64:        # unclaimed prefetches do not accumulate
             self._vit_cache.pop(next(iter(self._vit_cache)))
 
@@ -376,9 +399,9 @@ class LiveCCForConditionalGeneration:
         if not hits:
             return self._vit_encode(clips)
         parts: dict = {}
-        for i, (emb, ev, _keep) in hits.items():
+        for i, (emb, ev, keep) in hits.items():
             main.wait_event(ev)
-            emb.record_stream(main)
+            keep[1].record_stream(main)       # the batched embedding tensor the slice belongs to
             parts[i] = emb
         if miss:
             cfg = self.cfg
