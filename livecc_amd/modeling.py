@@ -332,23 +332,8 @@ class LiveCCForConditionalGeneration:
 
     def _side_stream(self) -> torch.cuda.Stream:
         if self._side is None:
-            import os
-            n_cu = int(os.environ.get("LCC_VIT_CUS", "0") or 0)
-            if n_cu > 0:
-                # Restrict the prefetch stream to `n_cu` compute units (hipExtStreamCreateWithCUMask): the vision tower's 8-wave GEMM
-                # blocks take a whole CU's LDS, and the HBM-bound decode kernels lose every CU they sit on; with a mask the ViT runs
-                # longer but on fewer CUs, still inside the decode window.
-                import ctypes as C
-                from . import _lib
-                hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-                words = (C.c_uint32 * 8)(*[(0xFFFFFFFF if n_cu >= 32 * (w + 1) else ((1 << max(0, n_cu - 32 * w)) - 1)) for w in range(8)])
-                h = C.c_void_p()
-                torch.cuda.set_device(self.device)
-                rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(8), words)
-                if rc != 0 or not h.value:
-                    raise _lib.LccError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-                self._side = torch.cuda.ExternalStream(h.value, device=self.device)
-                return self._side
+            # (A CU-masked stream -- hipExtStreamCreateWithCUMask, 48..176 CUs for the ViT -- was measured much slower: 150-182
+            # tokens/s instead of 256: the decode kernels on the main stream slowed to 150 us per layer for every mask size.)
             prio = 0
             try:   # numerically greatest = lowest priority: decode kernels win the arbitration for CUs
                 prio = max(torch.cuda.Stream.priority_range())
