@@ -1104,6 +1104,37 @@ extern "C" int lcc_debug_bench_attn_decode(int variant, int iters, const float* 
   if (rc != 0) return fail(rc, "lcc_debug_bench_attn_decode: invalid arguments (%d)", rc);
   return check_launch("lcc_debug_bench_attn_decode");
 }
+// ---- decode pipeline v2 operators (decode_v2.hip) ----
+extern "C" int lcc_decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_t* done, uint32_t* seen, int words_per_stream,
+                                     const void* embed_table, void* h, float* stats, int dim, const int32_t* pos, const float* inv_freq,
+                                     void* cos, void* sin, int B, void* stream) {
+  if (!slots || !cur_tok || !seen || !embed_table || !h || !stats || !pos || !inv_freq || !cos || !sin) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(decode_step_begin(slots, cur_tok, done, seen, words_per_stream, (const bf16_t*)embed_table, (bf16_t*)h, stats, dim, pos, inv_freq,
+                           (bf16_t*)cos, (bf16_t*)sin, B, (hipStream_t)stream), "lcc_decode_step_begin");
+}
+extern "C" int lcc_dgemv_norm_linear(const void* W_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
+                                     void* C, int ldc, int M, int N, int K, int swiglu, void* stream) {
+  if (!W_packed || !h || !stats || !norm_w || !C) return fail(LCC_ERR_ARG, "null pointer");
+  DgArgs a; a.W = (const bf16_t*)W_packed; a.M = M; a.N = N; a.K = K; a.H = (const bf16_t*)h; a.stats = stats; a.n_stat = K / 16;
+  a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)C; a.ldc = ldc;
+  if (swiglu) OP_RET(dgemv_norm_swiglu(a, (hipStream_t)stream), "lcc_dgemv_norm_linear");
+  OP_RET(dgemv_norm_bf16(a, (hipStream_t)stream), "lcc_dgemv_norm_linear");
+}
+extern "C" int lcc_dgemv_resid(const void* W_packed, const void* x, int ldx, void* h, float* stats_out, int M, int N, int K, void* stream) {
+  if (!W_packed || !x || !h || !stats_out) return fail(LCC_ERR_ARG, "null pointer");
+  DgArgs a; a.W = (const bf16_t*)W_packed; a.M = M; a.N = N; a.K = K; a.X = (const bf16_t*)x; a.ldx = ldx; a.Hres = (bf16_t*)h; a.stats_out = stats_out;
+  OP_RET(dgemv_resid(a, (hipStream_t)stream), "lcc_dgemv_resid");
+}
+extern "C" int lcc_dgemv_qkv_rope(const void* W_dec_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
+                                  const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* kv_len, void* const* kv_base,
+                                  lcc_kv_layout lay, int layer, void* q_out, int n_q_heads, int M, int K, void* stream) {
+  if (!W_dec_packed || !h || !stats || !norm_w || !bias || !cos || !sin || !tok_stream || !kv_len || !kv_base || !q_out) return fail(LCC_ERR_ARG, "null pointer");
+  DgArgs a; a.W = (const bf16_t*)W_dec_packed; a.M = M; a.N = (n_q_heads + 2 * lay.n_kv_heads) * 128; a.K = K; a.H = (const bf16_t*)h; a.stats = stats;
+  a.n_stat = K / 16; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.bias = (const bf16_t*)bias; a.cs = (const bf16_t*)cos; a.sn = (const bf16_t*)sin;
+  a.tok_stream = tok_stream; a.kv_len = kv_len; a.kv_base = (bf16_t* const*)kv_base; a.lay = to_lay(lay); a.layer = layer; a.q_out = (bf16_t*)q_out;
+  a.n_q_heads = n_q_heads;
+  OP_RET(dgemv_qkv_rope(a, (hipStream_t)stream), "lcc_dgemv_qkv_rope");
+}
 extern "C" int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
                                      const void* vit_rows, void* out, int S, int dim, void* stream) {
   if (!ids || !table || !out) return fail(LCC_ERR_ARG, "null pointer");

@@ -355,3 +355,44 @@ def sample_topk_topp(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tens
         float(temperature), int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF, _chk(rng_ctr, torch.int32, "rng_ctr"),
         _st(logits)), "lcc_sample_topk_topp")
     return out, scores
+
+
+# ---- decode pipeline v2 operators (csrc/decode_v2.hip) ----
+def tile_stats(h: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, K/16]: sums of squares of every 16-channel tile of the bf16 rows (what the residual epilogues emit)."""
+    M, K = h.shape
+    return h.float().pow(2).view(M, K // 16, 16).sum(-1).contiguous()
+
+
+def dgemv_norm_linear(w_packed: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, norm_w: torch.Tensor, eps: float, shape: Tuple[int, int],
+                      bias: Optional[torch.Tensor] = None, swiglu: bool = False) -> torch.Tensor:
+    N, K = shape
+    M = h.shape[0]
+    out = torch.empty(M, N // 2 if swiglu else N, dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.load().lcc_dgemv_norm_linear(_chk(w_packed, torch.bfloat16, "w"), _chk(h, torch.bfloat16, "h"), _chk(stats, torch.float32, "stats"),
+                                                 _chk(norm_w, torch.bfloat16, "norm_w"), float(eps), _chk(bias, torch.bfloat16, "bias"),
+                                                 out.data_ptr(), out.shape[1], M, N, K, 1 if swiglu else 0, _st(h)), "lcc_dgemv_norm_linear")
+    return out
+
+
+def dgemv_resid_(w_packed: torch.Tensor, x: torch.Tensor, h: torch.Tensor, shape: Tuple[int, int]) -> torch.Tensor:
+    """h += Linear(x) in place; returns the per-tile sums of squares of the new h."""
+    N, K = shape
+    M = x.shape[0]
+    stats = torch.empty(M, N // 16, dtype=torch.float32, device=h.device)
+    _lib.check(_lib.load().lcc_dgemv_resid(_chk(w_packed, torch.bfloat16, "w"), _chk(x, torch.bfloat16, "x"), x.shape[1], _chk(h, torch.bfloat16, "h"),
+                                           stats.data_ptr(), M, N, K, _st(h)), "lcc_dgemv_resid")
+    return stats
+
+
+def dgemv_qkv_rope(w_dec_packed: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, norm_w: torch.Tensor, eps: float, bias: torch.Tensor,
+                   cos: torch.Tensor, sin: torch.Tensor, tok_stream: torch.Tensor, kv_len: torch.Tensor, kv: "KvArena", layer: int,
+                   n_q_heads: int) -> torch.Tensor:
+    M, K = h.shape
+    q = torch.empty(M, n_q_heads * 128, dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.load().lcc_dgemv_qkv_rope(
+        _chk(w_dec_packed, torch.bfloat16, "w"), _chk(h, torch.bfloat16, "h"), _chk(stats, torch.float32, "stats"), _chk(norm_w, torch.bfloat16, "norm_w"),
+        float(eps), _chk(bias, torch.bfloat16, "bias"), _chk(cos, torch.bfloat16, "cos"), _chk(sin, torch.bfloat16, "sin"),
+        _chk(tok_stream, torch.int32, "tok_stream"), _chk(kv_len, torch.int32, "kv_len"), kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr(),
+        n_q_heads, M, K, _st(h)), "lcc_dgemv_qkv_rope")
+    return q

@@ -51,13 +51,14 @@ class _Stream:
     sent_query: Optional[str] = None
     ended: bool = False
     dropped_s: float = 0.0
+    ahead: Optional[dict] = None         # the chunk after the current one, fetched + resized ahead (its ViT runs under this step's decode)
 
 
 class StreamServer:
     def __init__(self, infer: LiveCCDemoInfer, max_new_tokens: int = 16, repetition_penalty: float = 1.05,
                  streaming_eos_base_threshold: Optional[float] = None, streaming_eos_threshold_step: float = 0.0,
                  default_query: str = "Please describe the video.", max_lag_s: float = 4.0, lag_policy: str = "catch_up",
-                 force_length: bool = False):
+                 force_length: bool = False, prefetch: bool = True):
         if lag_policy not in ("catch_up", "drop"):
             raise ValueError(lag_policy)
         self.infer, self.model, self.cfg = infer, infer.model, infer.cfg
@@ -65,6 +66,9 @@ class StreamServer:
         self.thr = (streaming_eos_base_threshold, streaming_eos_threshold_step)
         self.default_query, self.max_lag_s, self.lag_policy, self.force_length = default_query, max_lag_s, lag_policy, force_length
         self.streams: Dict[object, _Stream] = {}
+        # prefetch: when the frames of a stream's NEXT chunk are already in its buffer, they are fetched + resized now and their
+        # vision tower runs on the model's side stream under this step's decode steps (modeling.generate_batch(prefetch=...))
+        self.prefetch = prefetch
 
     # ---- stream management ----
     def add_stream(self, sid, video_frames: torch.Tensor, video_pts, query: Optional[str] = None, t_start: float = 0.0,
@@ -130,8 +134,12 @@ class StreamServer:
             ts = self._next_chunk_timestamps(st, now)
             if ts is None:
                 continue
-            clip, clip_ts, idxs = R.get_smart_resized_clip(st.frames, st.resized_hw[0], st.resized_hw[1], ts, st.pts, st.last_pts_index + 1,
-                                                           st.layout)
+            if st.ahead is not None and st.ahead["ts"] == ts and st.ahead["index_from"] == st.last_pts_index + 1:
+                clip, clip_ts, idxs = st.ahead["clip"], st.ahead["clip_ts"], st.ahead["idxs"]      # the clip whose ViT was prefetched
+            else:
+                clip, clip_ts, idxs = R.get_smart_resized_clip(st.frames, st.resized_hw[0], st.resized_hw[1], ts, st.pts, st.last_pts_index + 1,
+                                                               st.layout)
+            st.ahead = None
             if len(idxs) == 0:
                 st.ended = True
                 continue
@@ -152,8 +160,20 @@ class StreamServer:
         procs = None
         if self.thr[0] is not None and self.infer.streaming_eos_token_id is not None:
             procs = [ThresholdLogitsProcessor(self.infer.streaming_eos_token_id, self.thr[0], self.thr[1] or 0.0)]
+        ahead = []
+        if self.prefetch:
+            fti = protocol.FRAME_TIME_INTERVAL
+            for (st, start, stop, n_in, last_idx, last_ts) in metas:
+                nts = [last_ts + fti + i * fti for i in range(protocol.STREAMING_FPS_FRAMES)]
+                if nts[-1] > float(st.pts[-1]):
+                    continue                                   # the next pair is not (completely) in the buffer yet
+                clip, clip_ts, idxs = R.get_smart_resized_clip(st.frames, st.resized_hw[0], st.resized_hw[1], nts, st.pts, last_idx + 1, st.layout)
+                if len(idxs) == protocol.STREAMING_FPS_FRAMES:
+                    st.ahead = dict(ts=nts, index_from=last_idx + 1, clip=clip, clip_ts=clip_ts, idxs=idxs)
+                    ahead.append(dict(frames=clip, frames_layout="TCHW"))
         outs = self.model.generate_batch(reqs, repetition_penalty=self.repetition_penalty, logits_processor=procs,
-                                         max_new_tokens=self.max_new_tokens, force_length=self.force_length)
+                                         max_new_tokens=self.max_new_tokens, force_length=self.force_length,
+                                         **({"prefetch": ahead} if ahead else {}))
         results = []
         for (st, start, stop, n_in, last_idx, last_ts), o in zip(metas, outs):
             seq = o.sequences[0].cpu().numpy()

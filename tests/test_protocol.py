@@ -90,3 +90,45 @@ def test_config_round_trip_through_hf():
     for f in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
               "num_key_value_heads", "vit_depth", "vit_embed_dim", "vit_num_heads", "video_token_id", "eos_token_id"):
         assert getattr(cfg, f) == getattr(back, f), f
+
+
+def test_long_one_shot_clip_positions_under_the_two_text_offset_rules():
+    """SURVEY 8c-3 / ADVICE r1: a one-shot 480-frame 280x280 clip (grid 240 x 20 x 20 -> 24,000 video tokens): the released
+    checkpoints were trained with transformers 4.5x, where the text after a vision block continues at max(position so far) + 1
+    ("hf4", the default of from_pretrained); transformers 5.15 (the oracle) advances by max(h, w) // merge instead ("hf5").
+    The rules agree for every streaming chunk (grid_t <= max(h,w)/2) and differ here."""
+    from livecc_amd.config import livecc_7b
+    cfg = livecc_7b()
+    grid = (240, 20, 20)
+    n_vid = protocol.num_video_tokens(grid, cfg)
+    assert n_vid == 24000
+    ids = np.asarray([1, 2, 3, cfg.vision_start_token_id] + [cfg.video_token_id] * n_vid + [cfg.vision_end_token_id, 4, 5, 6], dtype=np.int64)
+    p4, d4 = protocol.rope_index_first_turn(ids, [grid], cfg, "hf4")
+    p5, d5 = protocol.rope_index_first_turn(ids, [grid], cfg, "hf5")
+    # identical up to the end of the vision block: text 0..3, then (t, h, w) indices offset by 4
+    assert np.array_equal(p4[:, :4 + n_vid], p5[:, :4 + n_vid])
+    assert p4[0, 4 + n_vid - 1] == 4 + 239 and p4[1, 4 + n_vid - 1] == 4 + 9 and p4[2, 4 + n_vid - 1] == 4 + 9
+    # hf4: the next text token sits right after the largest position used so far (temporal axis: 4 + 239)
+    assert p4[:, 4 + n_vid].tolist() == [244, 244, 244] and p4[:, -1].tolist() == [247, 247, 247]
+    # hf5: it restarts max(h, w) // 2 = 10 after the block's start
+    assert p5[:, 4 + n_vid].tolist() == [14, 14, 14]
+    # rope_delta = max position + 1 - length; under hf4 the last prompt row holds the maximum, so the in-call decode position
+    # (last row + 1) equals the next call's kv_len + rope_delta -- the two generation paths agree (they do not under hf5)
+    S = len(ids)
+    assert d4 == 248 - S and d5 == 244 - S
+    assert int(p4[:, -1].max()) + 1 == S + d4
+    assert int(p5[:, -1].max()) + 1 != S + d5
+    # a streaming chunk: no difference
+    g2 = (1, 28, 52)
+    ids2 = np.asarray([1, cfg.vision_start_token_id] + [cfg.video_token_id] * protocol.num_video_tokens(g2, cfg) + [cfg.vision_end_token_id, 7], dtype=np.int64)
+    a, da = protocol.rope_index_first_turn(ids2, [g2], cfg, "hf4")
+    b, db = protocol.rope_index_first_turn(ids2, [g2], cfg, "hf5")
+    assert np.array_equal(a, b) and da == db
+
+
+def test_model_constructors_pick_the_documented_text_offset_rule():
+    import inspect
+    from livecc_amd.modeling import LiveCCForConditionalGeneration as M
+    assert inspect.signature(M.__init__).parameters["text_offset_rule"].default == "hf4"     # released checkpoints (4.5x training)
+    src = inspect.getsource(M.from_hf_model)
+    assert 'setdefault("text_offset_rule", "hf5")' in src                                    # oracle parity = the installed transformers

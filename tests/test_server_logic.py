@@ -22,6 +22,9 @@ class FakeModel:
 
     def generate_batch(self, reqs, **kw):
         self.batches.append(len(reqs))
+        self.prefetched = getattr(self, "prefetched", []) + [len(kw.get("prefetch") or [])]
+        self.req_clips = getattr(self, "req_clips", []) + [[id(r["frames"]) for r in reqs]]
+        self.pf_clips = getattr(self, "pf_clips", []) + [[id(c["frames"]) for c in (kw.get("prefetch") or [])]]
         outs = []
         for r in reqs:
             seq = torch.cat([r["input_ids"].view(-1), torch.tensor([7, 8, 9])]).view(1, -1)
@@ -120,3 +123,19 @@ def test_run_realtime_never_spins(srv):
         t[0] += dt
     out = srv.run(realtime=True, clock=lambda: t[0], sleep=sleep, t0=0.0)
     assert srv.streams["v"].ended and len(out) >= 1 and len(sleeps) < 200
+
+
+def test_next_chunk_is_fetched_ahead_and_reused(srv):
+    """The chunk after the current one is fetched + resized while the current one is generated (its ViT is handed to
+    generate_batch(prefetch=...)); the next step passes the SAME clip object, so the model finds the prefetched embeddings."""
+    srv.add_stream("a", *_video(240), t_start=0.0, max_pixels=4 * 28 * 28)      # 8 s
+    out = srv.run(realtime=False)
+    m = srv.model
+    assert [span for _, span, _, _ in out] == [(0.0, 3.0)] + [(3.0 + i, 4.0 + i) for i in range(5)]
+    assert m.prefetched[:-1] == [1] * (len(m.prefetched) - 1) and m.prefetched[-1] == 0      # nothing to fetch ahead of the last chunk
+    for k in range(1, len(m.req_clips)):
+        assert m.req_clips[k] == m.pf_clips[k - 1], "the prefetched clip object is the one generated next"
+    quiet = server.StreamServer(FakeInfer(), max_new_tokens=3, prefetch=False)
+    quiet.add_stream("a", *_video(240), t_start=0.0, max_pixels=4 * 28 * 28)
+    assert [span for _, span, _, _ in quiet.run(realtime=False)] == [span for _, span, _, _ in out]
+    assert set(quiet.model.prefetched) == {0}

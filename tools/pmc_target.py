@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Target of the rocprofv3 PMC passes (tools/run_profiles.sh): launches ONLY the dominant kernel of the bench -- the decode
-gate/up weight-streaming GEMV at LiveCC-7B shapes (packed weights, M = 1) -- a few times over rotating weight buffers
+gate/up weight-streaming GEMV at LiveCC-7B shapes (packed weights, M = 1; the v2 kernel with the RMSNorm prologue, then the round-1
+kernel) -- a few times over rotating weight buffers
 (> 256 MiB Infinity Cache in total), so that the per-dispatch FETCH_SIZE / WRITE_SIZE counters can be read per launch."""
 import os
 import sys
@@ -24,7 +25,11 @@ if "--gemm" in sys.argv:
     sys.exit(0)
 ws = [(torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
 x = torch.randn(1, H, device=dev).to(torch.bfloat16)
-for i in range(12):
+nw = torch.ones(H, device=dev, dtype=torch.bfloat16)
+stats = ops.tile_stats(x)
+for i in range(12):   # the shipped decode path (v2): [RMSNorm] gate/up GEMV [SwiGLU] = dgemv_kernel<2,1,1,4,1>
+    ops.dgemv_norm_linear(ws[i % 3], x, stats, nw, 1e-6, (2 * I, H), swiglu=True)
+for i in range(12):   # and the round-1 kernel for comparison (gemv_skinny_kernel<2,2,...>)
     ops.linear(x, ws[i % 3], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
 torch.cuda.synchronize()
 print("ok")

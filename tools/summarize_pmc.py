@@ -14,14 +14,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
     for f in glob.glob(os.path.join(out, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gemv_skinny_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == c:
+            if "dgemv_kernel<2" in r.get("Kernel_Name", "") and r.get("Counter_Name") == c:
                 vals.append(float(r["Counter_Value"]))
     vals = vals[2:] if len(vals) > 4 else vals          # drop warm-up launches
     res[c] = dict(n=len(vals), mean_raw=sum(vals) / len(vals) if vals else None)
 fetch = res["FETCH_SIZE"]["mean_raw"]
 write = res["WRITE_SIZE"]["mean_raw"]
 alg = 2 * 18944 * 3584 * 2 + 3584 * 2 + 18944 * 2
-d = dict(kernel="gemv_skinny_kernel<2,2,packed> M=1 N=37888 K=3584", algorithmic_bytes_per_launch=alg,
+d = dict(kernel="dgemv_kernel<2,NORM,SWIGLU,4,1> ([RMSNorm] gate/up GEMV [SwiGLU]) M=1 N=37888 K=3584", algorithmic_bytes_per_launch=alg,
          fetch_size_kib_raw=fetch, write_size_kib_raw=write,
          gemv_gate_up_hbm_bytes_per_launch=(fetch * 1024 * 2 + (write or 0) * 1024) if fetch else None,
          note="FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024 (uncalibrated)", passes=res)
