@@ -291,7 +291,10 @@ typedef struct {
 int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slots, const int32_t* n_new, const int32_t* ids,
                     const int32_t* vit_index, const void* vit_embeds, const int32_t* pos3, const lcc_sampling* sp,
                     void* stream);
-/* n_steps further decode steps for the same streams without any host round trip. */
+/* n_steps further decode steps for the same streams without any host round trip.  n_streams <= LCC_MAX_DECODE_BATCH (and
+ * <= max_new_rows): up to 16 streams are one MFMA column tile of the weight-streaming GEMVs; 17..64 go through the 64-row GEMM
+ * tiles (the weights are still streamed once per step for the whole batch).  Larger batches: call once per group. */
+#define LCC_MAX_DECODE_BATCH 64
 int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots, int n_steps, int first_step_index,
                    const lcc_sampling* sp, void* stream);
 /* blocking: copy the ids generated by the last generate call of a slot to the host (at most max_n), report how many

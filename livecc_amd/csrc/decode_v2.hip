@@ -44,8 +44,17 @@ LCC_DEVICE u32x4 norm_frag(u32x4 hv, u32x4 wv, float r) {
   return o;
 }
 
-template <int NTILE, int PRO, int EPI, int NW, int UNR>
-__global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
+// Occupancy decides whether the whole grid is resident at once (one round) or a few blocks start a second round that pays the
+// prologue latency again behind an almost idle memory system (7B shapes): gate/up = 1184 blocks of 4 waves need 5 blocks per CU
+// (<= 96 VGPRs; at 97 the kernel ran 1024 + 160); q/k/v = 288 blocks of 8 waves need 2 per CU (<= 128 VGPRs; at 140: 256 + 32).
+// MR = activation rows (streams) whose RMSNorm statistic every wave reduces in the prologue: 2 (the engine's v2 batches) or 4.
+template <int NTILE, int PRO, int EPI, int NW, int MR>
+constexpr int dgemv_min_waves_per_simd() {
+  return MR > 2 ? 1 : ((NTILE == 2 && PRO == DG_PRO_NORM && NW == 4) ? 5 : ((EPI == DG_EPI_ROPE && NW == 8) ? 4 : 1));
+}
+
+template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR = 4>
+__global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI, NW, MR>())) void dgemv_kernel(DgArgs a) {
   static_assert(EPI != DG_EPI_SWIGLU || NTILE == 2, "swiglu needs the gate and the up tile in one block");
   static_assert(EPI == DG_EPI_SWIGLU || NTILE == 1, "one tile per block");
   __shared__ f32x4 red[NW - 1][NTILE][64];
@@ -126,11 +135,11 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   constexpr int T = NW * 64, XP = 2;      // XP row pieces per thread are requested up front (all of them for one stream)
   const int n4 = a.n_stat >> 2;
   const int kp = K >> 3, xpieces = PRO == DG_PRO_NORM ? M * kp : 0;
-  f32x4 pv[PRO == DG_PRO_NORM ? 4 : 1][2];
+  f32x4 pv[PRO == DG_PRO_NORM ? MR : 1][2];
   u32x4 hv[PRO == DG_PRO_NORM ? XP : 1], nv[PRO == DG_PRO_NORM ? XP : 1];
   if (PRO == DG_PRO_NORM) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = lane + 64 * u;           // unconditional (clamped) loads: a branch here would serialise them
@@ -171,9 +180,9 @@ __global__ __launch_bounds__(NW * 64) void dgemv_kernel(DgArgs a) {
   load_x(c + STEP, sb);
   __builtin_amdgcn_sched_barrier(0);
   if (PRO == DG_PRO_NORM) {
-    float rr[4];
+    float rr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MR; ++m) {
       float sacc = 0.f;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -337,7 +346,8 @@ static int dg_check(const DgArgs& a, int pro, int epi) {
 // [RMSNorm] q/k/v Linear [bias + M-RoPE + KV append]: W = the row-permuted decode copy of the fused q|k|v weight
 int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_ROPE)) return rc;
-  dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
+  if (a.M <= 2) dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 2><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
+  else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 4><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
 }
 // o_proj / down_proj: x plain, residual add in place + per-tile sums of squares
@@ -349,13 +359,15 @@ int dgemv_resid(const DgArgs& a, hipStream_t st) {
 // [RMSNorm] gate/up Linear [SwiGLU]
 int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_SWIGLU)) return rc;
-  dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 1><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+  if (a.M <= 2) dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 1, 2><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+  else dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 1, 4><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
 }
 // [final RMSNorm] lm_head
 int dgemv_norm_bf16(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_BF16)) return rc;
-  dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 1><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+  if (a.M <= 2) dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 1, 2><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+  else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 1, 4><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
 }
 

@@ -876,7 +876,11 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
                               const lcc_sampling* sp, void* stream) {
   LCC_TRY(ensure_ready(e));
   if (n_streams <= 0 || !slots || n_steps < 0) return fail(LCC_ERR_ARG, "bad argument");
-  if (n_streams > 16) return fail(LCC_ERR_SHAPE, "decode batches of more than 16 streams are not supported yet");
+  // <= 16 streams: one MFMA column tile of the weight-streaming GEMVs.  17..64: the rows go through the 64-row GEMM tiles of the
+  // prefill path (every weight byte is still read once per step) with the decode attention; beyond that the caller splits.
+  if (n_streams > LCC_MAX_DECODE_BATCH)
+    return fail(LCC_ERR_SHAPE, "decode batches of more than %d streams are not supported", LCC_MAX_DECODE_BATCH);
+  if (n_streams > e->lim.max_new_rows) return fail(LCC_ERR_STATE, "%d streams > max_new_rows %d", n_streams, e->lim.max_new_rows);
   if (n_steps == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int max_len = 0;
@@ -899,7 +903,7 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   const int nsplit = std::max(1, std::min(maxsplit, (ntile + tps - 1) / tps));
 
   LayerCtx cx{};
-  cx.S = n_streams; cx.skinny = true; cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
+  cx.S = n_streams; cx.skinny = n_streams <= 16; cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
   cx.nsplit_attn = nsplit;
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
   cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
@@ -919,6 +923,7 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
       LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));
       LCC_TRY(mrope_table_decode(d_slots, e->d_pos, e->inv_freq, n_streams, bf.cos, bf.sin, st));
       LCC_TRY(run_layers(e, bf, cx, st));
+      if (!cx.skinny) LCC_TRY(rmsnorm_bf16(bf.h, e->final_norm, bf.xn, n_streams, e->c.hidden_size, e->c.rms_eps, st));
     }
     LCC_TRY(advance_lengths(d_slots, e->d_kv_len, e->d_pos, n_streams, e->d_done, st));
     LCC_TRY(head_and_sample(e, bf, v2 ? nullptr : bf.xn, n_streams, d_slots, sp, first_step_index + step, st));

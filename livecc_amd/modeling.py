@@ -80,6 +80,7 @@ class _Cfg:
 
 class LiveCCForConditionalGeneration:
     main_input_name = "input_ids"
+    DECODE_GROUP = 64          # LCC_MAX_DECODE_BATCH of include/livecc_amd.h: streams decoded per weight pass
 
     def __init__(self, cfg: LiveCCConfig, weights: WeightArena, device, max_streams: int = 1, max_kv_len: Optional[int] = None,
                  max_new_rows: int = 4096, max_patches: int = 16384, max_history: int = 512,
@@ -173,7 +174,8 @@ class LiveCCForConditionalGeneration:
         p = logits_processor[0]
         if not all(hasattr(p, a) for a in ("token_id", "base_threshold", "step")):
             raise NotImplementedError(f"unsupported logits processor {type(p).__name__}")
-        return int(p.token_id), float(p.base_threshold), float(p.step)
+        # a reused object continues from its `count` (ref demo/infer.py:17: threshold = base + step * count)
+        return int(p.token_id), float(p.base_threshold) + float(p.step) * int(getattr(p, "count", 0)), float(p.step)
 
     def _positions(self, st: StreamState, ids_new: np.ndarray, grids, past_len: int) -> np.ndarray:
         if past_len == 0:
@@ -304,13 +306,14 @@ class LiveCCForConditionalGeneration:
         # (video_qa: max_new_tokens=512, ref demo/infer.py:236) are cut into chunks of 32 steps so that the host can stop
         # early once every stream has emitted EOS.
         chunk = max_new_tokens - 1 if force_length else 32
-        for b0 in range(0, n, 16):   # decode batches of <= 16 streams (one MFMA column tile)
-            grp = slots[b0:b0 + 16]
+        G = self.DECODE_GROUP
+        for b0 in range(0, n, G):    # one weight pass per step for up to 64 streams (LCC_MAX_DECODE_BATCH)
+            grp = slots[b0:b0 + G]
             step = 1
             while step < max_new_tokens:
                 k = min(chunk, max_new_tokens - step)
-                eng.decode(grp, k, step, sp, scores_out=scores_buf[b0:b0 + 16] if scores_buf is not None else None,
-                           logits_out=logits_buf if (logits_buf is not None and n <= 16) else None)
+                eng.decode(grp, k, step, sp, scores_out=scores_buf[b0:b0 + G] if scores_buf is not None else None,
+                           logits_out=logits_buf if (logits_buf is not None and n <= G) else None)
                 step += k
                 if step < max_new_tokens and all(eng.generated_count(s) < step for s in grp):
                     break
@@ -320,7 +323,7 @@ class LiveCCForConditionalGeneration:
             if thr and logits_processor:
                 logits_processor[0].count += len(toks)        # keep the stateful processor's counter as HF would
             seq = torch.from_numpy(np.concatenate([full_ids[b], np.asarray(toks, dtype=np.int64)])).view(1, -1).to(self.device)
-            lg = logits_buf[:len(toks), b] if logits_buf is not None and n <= 16 else None
+            lg = logits_buf[:len(toks), b] if logits_buf is not None and n <= G else None
             outs.append(GenerateOutput(sequences=seq, past_key_values=st, logits=lg,
                                        scores=scores_buf[b] if scores_buf is not None else None))
         return outs

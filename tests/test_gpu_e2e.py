@@ -244,6 +244,48 @@ def test_eos_stops_and_threshold_processor(dev, tiny_models):
     r2.past_key_values.release()
 
 
+def test_stepped_threshold_processor_advances_per_generated_token(dev, tiny_models):
+    """`ThresholdLogitsProcessor(token, base, step)` (ref demo/infer.py:10-23): the threshold of the k-th generated token of a call is
+    base + step * k (its `count` starts at 0 with every fresh object).  With a step chosen so that the threshold crosses the
+    probability of the greedy token exactly at step j, the native stream must keep its tokens up to j-1 and pick the runner-up at j;
+    with a slightly smaller step nothing changes.  The object's `count` ends at the number of generated tokens."""
+    from livecc_amd import protocol
+    from livecc_amd.infer import ThresholdLogitsProcessor
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(6, 56, 56, seed=9, layout="TCHW"))
+    builder = protocol.TurnBuilder(cfg, seed=9)
+    grid = protocol.grid_of(6, 56, 56, cfg)
+    ids = torch.from_numpy(builder.turn_ids(0, protocol.num_video_tokens(grid, cfg))).view(1, -1)
+    n = 8
+
+    def run(procs):
+        r = native.generate(input_ids=ids, frames=frames, max_new_tokens=n, min_new_tokens=n, do_sample=False, repetition_penalty=1.0,
+                            logits_processor=procs, output_logits=True)
+        r.past_key_values.release()
+        return r.sequences[0, ids.shape[1]:].tolist(), r.logits.float().cpu()
+
+    toks, logits = run(None)
+    cands = [j for j in range(2, n) if toks[j] not in toks[:j]]
+    if not cands:
+        pytest.skip("degenerate sample")
+    j = cands[0]
+    t = toks[j]
+    p = torch.softmax(logits, dim=-1)[:, t]
+    # suppressed steps before j do not matter (t is not the argmax there); the threshold must be below p_j at j for the control run
+    for frac, fires in ((j + 0.5, False), (j - 0.5, True)):
+        proc = ThresholdLogitsProcessor(t, 0.0, float(p[j]) / frac)
+        got, lg = run([proc])
+        assert proc.count == n
+        assert got[:j] == toks[:j]
+        if not fires:
+            assert got == toks
+            continue
+        masked = logits[j].clone()
+        masked[t] = -float("inf")
+        assert got[j] != t and masked[got[j]] == masked.max(), (got[j], t, int(masked.argmax()))
+        assert torch.equal(lg[:j + 1], logits[:j + 1]), "same history up to step j -> identical raw logits"
+
+
 @pytest.mark.parametrize("name", ["small"])
 def test_streaming_generate_matches_oracle_small(dev, name):
     """GQA group 7 (as LiveCC-7B), 4+4 layers, hidden 896: exercises the 7-heads-per-KV-head decode packing."""
