@@ -450,30 +450,41 @@ class LiveCCForConditionalGeneration:
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def _prefill(self, slots, ids_new, pos3, vit, sp, scores_buf, logits_buf) -> None:
-        """One packed prefill when everything fits `max_new_rows`; otherwise every stream is prefilled alone in pieces of at
-        most `max_new_rows` rows over its carried KV (a prompt prefilled in one or in several calls gives bit-identical
-        logits: tests/test_gpu_fullsize.py).  Only the LAST piece's sampled token survives (each prefill call restarts the
-        history column), which is exactly the token of the un-split prefill."""
+        """One packed prefill when everything fits `max_new_rows`; otherwise consecutive streams are packed into groups of at
+        most `max_new_rows` rows (one launch sequence per group), and a stream that is longer than that by itself is prefilled
+        alone in pieces over its carried KV (a prompt prefilled in one or in several calls gives bit-identical logits:
+        tests/test_gpu_fullsize.py; only the LAST piece's sampled token survives -- each prefill call restarts the history
+        column -- which is exactly the token of the un-split prefill)."""
         cfg, eng = self.cfg, self.engine
         cap = eng.max_new_rows
-        if sum(len(x) for x in ids_new) <= cap:
+        lens = [len(x) for x in ids_new]
+        if sum(lens) <= cap:
             eng.prefill(slots, ids_new, pos3, vit, sp, scores_out=scores_buf, logits_out=logits_buf)
             return
-        if len(slots) > 1 and (scores_buf is not None or logits_buf is not None):
-            raise NotImplementedError("output_logits / output_scores with a multi-stream prompt longer than max_new_rows")
-        row0 = 0
-        for b, (slot, ids, pos) in enumerate(zip(slots, ids_new, pos3)):
-            is_vid = (ids == cfg.video_token_id) | (ids == cfg.image_token_id)
-            nv_before = 0
-            n_vid = int(is_vid.sum())
-            for a in range(0, len(ids), cap):
-                e = min(len(ids), a + cap)
-                k = int(is_vid[a:e].sum())
-                rows = vit[row0 + nv_before:row0 + nv_before + k] if (vit is not None and k) else None
-                nv_before += k
-                eng.prefill([slot], [ids[a:e]], [pos[:, a:e]], rows, sp,
-                            scores_out=scores_buf[b:b + 1] if scores_buf is not None else None, logits_out=logits_buf)
-            row0 += n_vid
+        is_vid = [(ids == cfg.video_token_id) | (ids == cfg.image_token_id) for ids in ids_new]
+        n_vid = [int(m.sum()) for m in is_vid]
+        row0 = np.concatenate([[0], np.cumsum(n_vid)]).astype(np.int64)      # first ViT row of every stream
+        sc = (lambda a, e: scores_buf[a:e]) if scores_buf is not None else (lambda a, e: None)
+        lg = (lambda a, e: logits_buf[0, a:e]) if logits_buf is not None else (lambda a, e: None)   # step 0 = the prefill's token
+        b, n = 0, len(slots)
+        while b < n:
+            if lens[b] > cap:                                   # one long prompt (one-shot video_qa / mcq): pieces over its own KV
+                ids, pos, nv_before = ids_new[b], pos3[b], 0
+                for a in range(0, lens[b], cap):
+                    e = min(lens[b], a + cap)
+                    k = int(is_vid[b][a:e].sum())
+                    rows = vit[row0[b] + nv_before:row0[b] + nv_before + k] if (vit is not None and k) else None
+                    nv_before += k
+                    eng.prefill([slots[b]], [ids[a:e]], [pos[:, a:e]], rows, sp, scores_out=sc(b, b + 1), logits_out=lg(b, b + 1))
+                b += 1
+                continue
+            e, rows_sum = b, 0
+            while e < n and lens[e] <= cap and rows_sum + lens[e] <= cap:
+                rows_sum += lens[e]
+                e += 1
+            rows = vit[row0[b]:row0[e]] if (vit is not None and row0[e] > row0[b]) else None
+            eng.prefill(slots[b:e], ids_new[b:e], pos3[b:e], rows, sp, scores_out=sc(b, e), logits_out=lg(b, e))
+            b = e
 
     # ---- ViT only (frames/s benchmarks, parity tests) ----
     @torch.inference_mode()

@@ -143,8 +143,8 @@ def _batched_streams_vs_hf(dev, cfg, shapes, seed0, name, max_new_tokens=5, init
     n = len(shapes)
     hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=2, init_scale=init_scale)
     hf32 = O.build_hf_model(cfg, dtype=torch.float32, seed=2, init_scale=init_scale)
-    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=n, max_kv_len=2048, max_new_rows=1024,
-                                                          max_patches=4096, max_history=16)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=n, max_kv_len=2048, max_new_rows=max(1024, 256 * n),
+                                                          max_patches=max(4096, 512 * n), max_history=16)
     frames = [torch.from_numpy(protocol.synth_frames(t, h, w, seed=seed0 + i, layout="TCHW")) for i, (t, h, w) in enumerate(shapes)]
     builders = [protocol.TurnBuilder(cfg, seed=seed0 + i) for i in range(n)]
     states, past, turns = [None] * n, [None] * n, [[] for _ in range(n)]

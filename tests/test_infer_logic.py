@@ -159,3 +159,51 @@ def test_clip_level_entry_point_keeps_the_stream_clock(infer):
     assert spans == [(0.0, 3.0), (3.0, 4.0), (4.0, 5.0)] and state["last_timestamp"] == 4.5
     spans = [s for s, _, _ in infer.live_cc_clip(clip[:4], state, max_new_tokens=3)]
     assert spans == [(5.0, 6.0), (6.0, 7.0)]
+
+
+def test_prefill_packs_streams_into_groups_under_max_new_rows():
+    """`_prefill` host logic: streams are packed into consecutive groups of <= max_new_rows rows, a stream longer than that is cut
+    into pieces alone, ViT rows follow their streams, and step-0 logits / scores land in the rows of their streams."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from livecc_amd.modeling import LiveCCForConditionalGeneration as M
+    VID = 9
+    calls = []
+
+    class Eng:
+        max_new_rows = 100
+
+        def prefill(self, slots, ids, pos3, vit, sp, scores_out=None, logits_out=None):
+            nv = sum(int((np.asarray(x) == VID).sum()) for x in ids)
+            assert (vit is None and nv == 0) or vit.shape[0] == nv
+            assert sum(len(x) for x in ids) <= self.max_new_rows
+            for x, p in zip(ids, pos3):
+                assert p.shape == (3, len(x))
+            calls.append(dict(slots=list(slots), rows=[len(x) for x in ids], vit=None if vit is None else vit[:, 0].tolist(),
+                              sc=None if scores_out is None else tuple(scores_out.shape), lg=None if logits_out is None else tuple(logits_out.shape)))
+            if logits_out is not None:
+                logits_out[:, 0] = torch.tensor([float(s) for s in slots])
+
+    m = M.__new__(M)
+    m.cfg = SimpleNamespace(video_token_id=VID, image_token_id=-5)
+    m.engine = Eng()
+    lens = [40, 50, 30, 250, 60, 10]
+    nvid = [10, 0, 5, 120, 20, 0]
+    ids = [np.concatenate([np.full(v, VID), np.arange(n - v) + 20]).astype(np.int64) for n, v in zip(lens, nvid)]
+    pos = [np.zeros((3, n), dtype=np.int64) for n in lens]
+    vit = torch.arange(sum(nvid), dtype=torch.float32).view(-1, 1).repeat(1, 2)
+    slots = [7, 3, 5, 1, 2, 0]
+    logits = torch.full((4, 6, 8), -1.0)
+    scores = torch.zeros(6, 8)
+    m._prefill(slots, ids, pos, vit, None, scores, logits)
+    assert [c["slots"] for c in calls] == [[7, 3], [5], [1], [1], [1], [2, 0]]
+    assert [c["rows"] for c in calls] == [[40, 50], [30], [100], [100], [50], [60, 10]]
+    assert calls[0]["vit"] == list(range(0, 10)) and calls[1]["vit"] == list(range(10, 15))
+    assert calls[2]["vit"] == list(range(15, 115)) and calls[3]["vit"] == list(range(115, 135)) and calls[4]["vit"] is None
+    assert calls[5]["vit"] == list(range(135, 155))
+    assert [c["lg"] for c in calls] == [(2, 8), (1, 8), (1, 8), (1, 8), (1, 8), (2, 8)] and calls[0]["sc"] == (2, 8)
+    assert logits[0, :, 0].tolist() == [7.0, 3.0, 5.0, 1.0, 2.0, 0.0] and (logits[1:] == -1).all()
+    calls.clear()
+    m._prefill(slots[:2], ids[:2], pos[:2], vit[:10], None, None, None)
+    assert len(calls) == 1 and calls[0]["rows"] == [40, 50]
