@@ -17,6 +17,7 @@
 //    Qwen2VLAttention q/k/v/o_proj 501-504, Qwen2MLP 453-466, lm_head 1218/1323).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -34,8 +35,8 @@ LCC_DEVICE bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
 }
 
 // epilogue shared by the tiled kernels.  acc[i][j][r] = C[mbase + i*16 + li][nbase + j*16 + g*4 + r] (swapped operands).
-template <int EPI, int MT, int NT>
-LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int ocbase, int li, int g,
+template <int EPI, int MT, int NT, int AM = MT, int AN = NT>   // the first MT x NT tiles of an AM x AN accumulator array
+LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[AM][AN], int mbase, int nbase, int ocbase, int li, int g,
                               const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
                               bf16_t* __restrict__ C, int ldc, int M, int N, float* __restrict__ partial,
                               const float* __restrict__ wscale) {
@@ -512,6 +513,128 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
   tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
+// ------------------------------------------------------------------------------------------------
+// tiled GEMM v4 ("tall"): ONE block row covers all of M (256 < M <= 448: a single-stream streaming chunk is 386 rows), 8 waves,
+// 448 x 160 x 64 block tile, LDS-DMA for both operands
+// ------------------------------------------------------------------------------------------------
+// Why: M = 386 on the 128 x 256 tiles of gemm_big_kernel is 4 row tiles (the fourth holds 2 rows) x 148 = 592 blocks = 2.3 rounds
+// of the 256 CUs at one block per CU: the gate/up GEMM of a chunk ran at 0.65 PF / 29.8 % MfmaUtil against 50.7 % at M = 3088
+// (profiles/r02).  Split-K or stream-K on those tiles buys <= 13 % (1.75 instead of 2 rounds).  Here every block owns ALL rows and
+// 160 columns, so N = 37888 is 237 blocks = ONE round on 92.5 % of the CUs, the W panel of a block is read once from L2, and the
+// activation tile (448 x 64 per k-step, the same for every block) comes out of L2.
+//   * waves: 4 (M) x 2 (N).  M-wave wm owns rows wm*112 .. +111 = 7 MFMA row tiles; N-wave 0 owns column tiles 0-5, N-wave 1
+//     tiles 6-9 (gate/up pairs stay inside a wave: SwiGLU epilogue).  Waves w and w + 4 share a SIMD, so every SIMD issues
+//     7 x (6 + 4) x 2 = 140 MFMAs per k-step.  A wave whose rows end early (M = 386: the last M-wave has 4 live row tiles)
+//     takes the 4-row-tile code path; a wave without rows only feeds the DMA ring.
+//   * LDS: A image 448 rows x 128 B (XOR-swizzled 16-byte chunks, as gemm_big_kernel) + W tile 20 fragment sub-tiles of 1 KB =
+//     77,824 B per stage, two stages = 155,648 B; per k-step 76 KB of DMA (1216 clk at 64 B/clk) under 2240 clk of MFMA issue.
+// Requires packed bf16 W, K % 64 == 0.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tall_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K) {
+  constexpr int BM = 448, BN = 160, BK = 64, WM = 112, MT = 7, NT0 = 6;
+  constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
+  constexpr int B_SUB = (BN / 16) * 2;            // 20 fragment sub-tiles of 1 KB
+  constexpr int STAGE = A_UNITS + B_SUB * 64;
+  constexpr int A_PER_WAVE = BM / 64;             // 7 pieces of 8 rows x 128 B per wave
+  extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
+
+  const int n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int li = lane & 15, g = lane >> 4;
+  const int K32 = K >> 5, nfrag = N >> 4;
+  const int rows_left = M - wm * WM;                                     // wave-uniform
+  const int mt_live = rows_left <= 0 ? 0 : min(MT, (rows_left + 15) >> 4);
+
+  int aoffs[A_PER_WAVE];                         // element offsets from A (the row is clamped into the matrix)
+#pragma unroll
+  for (int q = 0; q < A_PER_WAVE; ++q) {
+    const int row = (wave * A_PER_WAVE + q) * 8 + (lane >> 3);
+    aoffs[q] = min(row, M - 1) * lda + (((lane & 7) ^ (lane >> 3)) << 3);
+  }
+  // W sub-tiles: waves 0-3 copy three each (0..11), waves 4-7 two each (12..19); sub-tile st = fragment row st >> 1, 32-k block st & 1
+  const int nb = wave < 4 ? 3 : 2;
+  const int st0 = wave < 4 ? wave * 3 : 12 + (wave - 4) * 2;
+  const bf16_t* bsrc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int st = min(st0 + q, B_SUB - 1);
+    const int fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
+    bsrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+    u32x4* sbase = dsmem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < A_PER_WAVE; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoffs[q] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < nb)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * 1024),
+                                         (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (st0 + q) * 64), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][NT0];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  issue(0, 0);
+  int aoff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (wm * WM + li) * 8 + ((kk * 4 + g) ^ (li & 7));
+  const int boff = A_UNITS + (wn * NT0 * 2) * 64 + lane;
+
+  // one k-tile of this wave: MTW live row tiles x NTW column tiles.  Per 32-k half: the NTW W fragments are read up front, the
+  // activation fragments stream through a 3-register ring two row tiles ahead of their MFMAs.
+  auto ktile = [&](const u32x4* s, auto mtw_c, auto ntw_c) {
+    constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fb[NTW], fa[3];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) fb[j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+      fa[0] = as_bf16x8(s[aoff[kk]]);
+      if (MTW > 1) fa[1] = as_bf16x8(s[aoff[kk] + 128]);
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        if (i + 2 < MTW) fa[(i + 2) % 3] = as_bf16x8(s[aoff[kk] + (i + 2) * 128]);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(fb[j], fa[i % 3], acc[i][j]);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I4 = std::integral_constant<int, 4>;
+  using I6 = std::integral_constant<int, 6>;
+  using I7 = std::integral_constant<int, 7>;
+  const int nbase = n0 + wn * NT0 * 16;
+  // The live tile shape of a wave is loop-invariant, so every shape gets its OWN copy of the k loop (same barrier sequence in all
+  // of them): one loop with a switch inside made hipcc keep the accumulators of all shapes alive across the paths and spill 190
+  // registers; a single-shape loop needs 252.
+  auto run = [&](auto mtw_c, auto ntw_c) {
+    constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
+    for (int kt = 0; kt < nkt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
+      if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+      if constexpr (MTW > 0) ktile(dsmem + (kt & 1) * STAGE, mtw_c, ntw_c);
+    }
+    if constexpr (MTW > 0)
+      tile_epilogue<EPI, (MTW > 0 ? MTW : 1), (MTW > 0 ? NTW : 2), MT, NT0>(acc, wm * WM, nbase, nbase / 2, li, g, bias, residual, ldr, C, ldc, M, N,
+                                                                        nullptr, nullptr);
+  };
+  if (mt_live == 0) run(I0{}, I4{});                 // no rows: DMA + barriers only
+  else if (wn == 0) { if (mt_live <= 4) run(I4{}, I6{}); else run(I7{}, I6{}); }
+  else { if (mt_live <= 4) run(I4{}, I4{}); else run(I7{}, I4{}); }
+}
+
 // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel; 2 (default): measured best per tile shape --
 // 64-row tiles (72 KB ring, 2 blocks/CU) take the LDS-DMA kernel (1.5-1.6x), 128-row tiles keep the register-staged
 // kernel (64 KB, 2 blocks/CU; the 96 KB ring would leave 1 block/CU and measured 0.75x).
@@ -588,8 +711,30 @@ static int big_tile_rows(const GemmArgs& a, int S) {
   return 0;
 }
 
+// The tall kernel serves one-block-row problems whose column tiles fill most of ONE round of the chip (7B gate/up at a streaming
+// chunk: 237 blocks).  Variant 8 forces it wherever it is legal (tests).
+static bool tall_legal(const GemmArgs& a) { return big_eligible(a) && !a.w_fp8 && a.M <= 448 && (a.N & 15) == 0; }
+static bool tall_wanted(const GemmArgs& a) {
+  if (!tall_legal(a)) return false;
+  if (g_gemm_variant == 8) return true;
+  if (g_gemm_variant != 2) return false;
+  const int blocks = (a.N + 159) / 160;
+  return a.M > 256 && blocks >= 192 && blocks <= 256;
+}
+template <int EPI>
+static void launch_tall(const GemmArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (448 * 8 + 20 * 64) * 16;   // 155,648 B
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  gemm_tall_kernel<EPI><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
+}
+
 template <int EPI>
 static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
+  if (tall_wanted(a)) return launch_tall<EPI>(a, st);
   const int big = big_tile_rows(a, 1);
   if (big == 256) return launch_big<256, EPI>(a, st);
   if (big == 128) return launch_big<128, EPI>(a, st);
