@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
 //   * LDS: A image 448 rows x 128 B (XOR-swizzled 16-byte chunks, as gemm_big_kernel) + W tile 20 fragment sub-tiles of 1 KB =
 //     77,824 B per stage, two stages = 155,648 B; per k-step 76 KB of DMA (1216 clk at 64 B/clk) under 2240 clk of MFMA issue.
 // Requires packed bf16 W, K % 64 == 0.
-template <int EPI>
+template <int EPI, int SCHED>
 __global__ __launch_bounds__(512) void gemm_tall_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
@@ -607,6 +607,14 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
         if (i + 2 < MTW) fa[(i + 2) % 3] = as_bf16x8(s[aoff[kk] + (i + 2) * 128]);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(fb[j], fa[i % 3], acc[i][j]);
+      }
+      if (SCHED == 1) {   // pin the issue order: the fragment reads up front, then one activation read per row tile of MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, NTW + (MTW > 1 ? 2 : 1), 0);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          if (i + 2 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+        }
       }
     }
   };
@@ -726,10 +734,15 @@ static void launch_tall(const GemmArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (448 * 8 + 20 * 64) * 16;   // 155,648 B
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  gemm_tall_kernel<EPI><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
+  static const int sched = [] { const char* v = getenv("LCC_TALL_SCHED"); return v ? atoi(v) : 0; }();   // 0 compiler order, 1 pinned
+  if (sched == 1)
+    gemm_tall_kernel<EPI, 1><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
+  else
+    gemm_tall_kernel<EPI, 0><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
 }
 
 template <int EPI>

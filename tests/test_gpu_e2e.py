@@ -92,8 +92,10 @@ def _replay_native(native, cfg, frames, builder, max_new_tokens, repetition_pena
     return out
 
 
-def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_penalty, streaming_eos=None, min_exact_frac=0.8):
-    """hf32 may be None (large configs: only the bf16 oracle = the reference's own dtype is run)."""
+def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_penalty, streaming_eos=None, min_exact_frac=0.8,
+                    strict_rate=0.95):
+    """hf32 may be None (large configs: only the bf16 oracle = the reference's own dtype is run).  Returns the counters;
+    `strict_rate=None` leaves the rate assertions (identical tokens, strict-margin identity) to a caller that pools several streams."""
     from oracle import hf_oracle as O
     s16, s32 = O.OracleStream(hf16, cfg), (O.OracleStream(hf32, cfg) if hf32 is not None else None)
     n_steps = n_exact = n_checked = n_strict = n_strict_eq = 0
@@ -139,9 +141,13 @@ def _compare_stream(cfg, hf16, hf32, native_turns, frames, name, repetition_pena
                 n_strict_eq += int(own == toks[k])
     record(name, dict(steps=n_steps, exact=n_exact, margin_checked=n_checked, worst_rel_dlogit=worst["dl"],
                       worst_err_ratio=worst["ratio"], margin_gt_ref_error=n_strict, exact_where_margin_gt_ref_error=n_strict_eq))
+    out = dict(steps=n_steps, exact=n_exact, strict=n_strict, strict_eq=n_strict_eq)
+    if strict_rate is None:
+        return out
     assert n_exact >= min_exact_frac * n_steps, f"{name}: only {n_exact}/{n_steps} greedy tokens identical to the bf16 oracle"
-    assert n_strict_eq >= 0.95 * n_strict, (f"{name}: native token differs from the oracle's on {n_strict - n_strict_eq} of {n_strict} steps "
-                                            f"whose oracle margin exceeds the oracle's own bf16-vs-fp32 error")
+    assert n_strict_eq >= strict_rate * n_strict, (f"{name}: native token differs from the oracle's on {n_strict - n_strict_eq} of {n_strict} "
+                                                   f"steps whose oracle margin exceeds the oracle's own bf16-vs-fp32 error")
+    return out
 
 
 @pytest.mark.parametrize("use_pixel_values,fused_tails,fused_attn", [(False, 0, 1), (True, 0, 1), (False, 1, 1), (False, 0, 5), (False, 0, 7)])

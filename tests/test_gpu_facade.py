@@ -167,8 +167,17 @@ def _batched_streams_vs_hf(dev, cfg, shapes, seed0, name, max_new_tokens=5, init
             turns[i].append(dict(turn_ids=new, grid=grid, new_tokens=seq[n_in:].tolist(), logits=o.logits.float().cpu(), frames=ab))
     for st in states:
         st.release()
+    # the hard bounds (logit error, error ratio vs fp32, margin-guaranteed token identity) are asserted per stream; the two RATES are
+    # pooled over the streams (a rate over the ~8 decided steps of one short stream is one mismatch away from any threshold)
+    tot = dict(steps=0, exact=0, strict=0, strict_eq=0)
     for i in (range(n) if check is None else check):
-        _compare_stream(cfg, hf16, hf32, turns[i], frames[i], f"{name}[{i}]", 1.05)
+        r = _compare_stream(cfg, hf16, hf32, turns[i], frames[i], f"{name}[{i}]", 1.05, strict_rate=None)
+        for k in tot:
+            tot[k] += r[k]
+    from tests.util import record
+    record(name + "[pooled]", tot)
+    assert tot["exact"] >= 0.8 * tot["steps"], tot
+    assert tot["strict_eq"] >= 0.95 * tot["strict"], tot
 
 
 def test_generate_batch_of_three_streams_matches_hf_per_stream(dev):
