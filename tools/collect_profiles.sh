@@ -20,6 +20,8 @@ for f in $LOGS/bench_*.log; do
   n=$(basename $f .log)
   grep '^{' $f | tail -n 1 > $DST/${n}_n1.json
 done
+for f in $LOGS/*.jsonl; do [ -f "$f" ] && cp $f $DST/; done
+[ -f gpurun_out/parity_report.json ] && cp gpurun_out/parity_report.json $DST/parity_report.json
 [ -f $LOGS/test_full.log ] && tail -n 12 $LOGS/test_full.log > $DST/pytest_gpu_tail.txt
 [ -f $LOGS/smoke.log ] && tail -n 2 $LOGS/smoke.log > $DST/smoke_tail.txt
 ls -la $DST

@@ -29,11 +29,12 @@ d = dict(kernel="dgemv_kernel<2,NORM,SWIGLU,4,1> ([RMSNorm] gate/up GEMV [SwiGLU
 gemm = {}
 for f in glob.glob(os.path.join(out, "pmc_gemm_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm_big_kernel" not in r.get("Kernel_Name", ""):
+        kn = r.get("Kernel_Name", "")
+        if "gemm_big_kernel" not in kn and "gemm_tall_kernel" not in kn:
             continue
-        key = "M3088" if "<256" in r["Kernel_Name"] else "M386"
+        key = "M386_gemm_tall_kernel" if "gemm_tall_kernel" in kn else ("M3088_gemm_big_kernel_256" if "<256" in kn else "M386_gemm_big_kernel_128")
         gemm.setdefault(key, {}).setdefault(r.get("Counter_Name"), []).append(float(r["Counter_Value"]))
-d["gemm_big_kernel_counters_mean_per_dispatch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in gemm.items()}
+d["gemm_counters_mean_per_dispatch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in gemm.items()}
 d["gemm_note"] = ("MfmaUtil = rocprofv3 derived metric reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum)/(reduce(GRBM_GUI_ACTIVE,max)*SIMD_NUM)*100 (gfx94x formula); "
                   "the raw SQ_* / GRBM_* values are per-dispatch means of the CSV rows as rocprofv3 writes them")
 print(json.dumps(d, indent=1))
