@@ -144,6 +144,9 @@ class LiveCCDemoInfer:
         key = video_path if isinstance(video_path, str) else id(video_path)
         if key not in self._cached_video_readers_with_hw:
             self._cached_video_readers_with_hw[key] = V.get_smart_resized_video_reader(video_path, max_pixels)
+        if state.get("video_pts") is None:
+            # the reference fills these only when it opens the reader (:91-95), so a second state over an already cached video
+            # silently yields nothing there; here every new state starts from the cached reader
             state["video_pts"] = self._cached_video_readers_with_hw[key][0].pts
             state["last_video_pts_index"] = -1
         video_pts = state.get("video_pts", None)

@@ -20,6 +20,7 @@ All wrappers require bf16 tensors on the GPU and raise otherwise (no CPU path).
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -160,8 +161,14 @@ def _cache_classes():
         def reset(self) -> None:
             self.length = 0
 
-        def crop(self, tokens_to_remove: int) -> None:
-            self.length = max(0, self.length - int(tokens_to_remove))
+        def crop(self, max_length: int) -> None:
+            """HF semantics (cache_utils.DynamicLayer.crop): keep `max_length` tokens; a negative value removes that many.  The
+            arena rows past the new length are simply overwritten by the next `update`."""
+            max_length = int(max_length)
+            if max_length < 0:
+                max_length = self.length + max_length
+            if max_length < self.length:
+                self.length = max(0, max_length)
 
         def reorder_cache(self, beam_idx) -> None:
             raise NotImplementedError("beam search is not part of the reference's path")
@@ -176,7 +183,8 @@ def _cache_classes():
             self.last_update = {}
             self._ident = {}
             super().__init__(layers=[NativeKVLayer(self, i) for i in range(tc.num_hidden_layers)])
-            _LIVE_CACHES.append(self)
+            _LIVE_CACHES[:] = [r for r in _LIVE_CACHES if r() is not None]      # weak references: a dropped cache frees its arena
+            _LIVE_CACHES.append(weakref.ref(self))
 
         def identity_tables(self, s: int):
             if s not in self._ident:
@@ -187,7 +195,7 @@ def _cache_classes():
     return NativeKVLayer, NativeKVCache
 
 
-_LIVE_CACHES: List[object] = []
+_LIVE_CACHES: List["weakref.ref"] = []      # caches the attention function may be called under (newest last)
 
 
 def NativeKVCache(config, max_cache_len: int, device):
@@ -224,7 +232,8 @@ def lcc_attention_forward(module, query, key, value, attention_mask=None, dropou
         raise NotImplementedError(f"livecc_amd attention: head_dim {D}, causal={causal}")
     Hkv, L = key.shape[1], key.shape[2]
     layer = getattr(module, "layer_idx", 0)
-    cache = next((c for c in reversed(_LIVE_CACHES) if c.last_update.get(layer, (None, None))[1] == L
+    live = [c for c in (r() for r in reversed(_LIVE_CACHES)) if c is not None]
+    cache = next((c for c in live if c.last_update.get(layer, (None, None))[1] == L
                   and key.data_ptr() == c.arena.k_view(0, layer).data_ptr()), None)
     if cache is not None:
         kv, past = cache.arena, L - S

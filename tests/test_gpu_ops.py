@@ -666,5 +666,16 @@ def test_unmodified_hf_model_on_the_gpu_with_every_plugin_matches_hf_cpu(dev):
         assert s_gpu.past_key_values is cache and cache.get_seq_length() == s_gpu.past_ids.shape[1]
         record("hf_model_with_plugins_vs_hf_cpu", dict(worst_rel_dlogit=worst))
         assert worst <= 6e-2, f"HF-on-GPU with the native plugins differs from HF CPU by {worst:.3g} of the logit scale"
+        # HF crop semantics (keep n tokens / negative: remove n) and the weak registry of live caches
+        n = cache.get_seq_length()
+        cache.crop(n + 5); assert cache.get_seq_length() == n
+        cache.crop(n - 3); assert cache.get_seq_length() == n - 3
+        cache.crop(-2); assert cache.get_seq_length() == n - 5
+        import gc
+        live_before = sum(r() is not None for r in plugin._LIVE_CACHES)
+        s_gpu.past_key_values = None
+        del cache
+        gc.collect()
+        assert sum(r() is not None for r in plugin._LIVE_CACHES) == live_before - 1, "a dropped NativeKVCache must free its arena"
     finally:
         plugin.revert_livecc_amd_kernel_to_qwen2_vl()
