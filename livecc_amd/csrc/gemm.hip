@@ -747,7 +747,9 @@ static void launch_tall(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI>
 static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
-  if (tall_wanted(a)) return launch_tall<EPI>(a, st);
+  if constexpr (EPI != EPI_PARTIAL) {       // split-K slabs stay on the 128/256-row tiles (the tall kernel has no K split)
+    if (tall_wanted(a)) return launch_tall<EPI>(a, st);
+  }
   const int big = big_tile_rows(a, 1);
   if (big == 256) return launch_big<256, EPI>(a, st);
   if (big == 128) return launch_big<128, EPI>(a, st);

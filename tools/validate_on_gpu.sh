@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 GPU call K: full validation + profiles + the benchmark lines kept under profiles/r02
+# Full validation on an MI355X box (through gpurun): every -m gpu test, smoke(), the benchmark lines kept under profiles/<round>, rocprofv3 profiles
 set -x
 mkdir -p gpurun_out/r02
 export TMPDIR=/tmp
