@@ -302,6 +302,21 @@ def attn_decode(q: torch.Tensor, kv: KvArena, layer: int, slots: torch.Tensor, k
     return out
 
 
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, vit_index: Optional[torch.Tensor] = None,
+                 vit_rows: Optional[torch.Tensor] = None, indirect: Optional[torch.Tensor] = None, n_rows: Optional[int] = None):
+    """`embed_tokens(input_ids)` + `masked_scatter` of the video rows (Q2VL:1159-1176) in one pass: row s of the result is
+    `vit_rows[vit_index[s]]` where `vit_index[s] >= 0`, else `table[ids[s]]` (decode: `table[ids[indirect[s]]]`, the current token of
+    stream slot `indirect[s]`).  int32 index tensors on the GPU; bf16 rows, dim % 8 == 0."""
+    S = int(n_rows if n_rows is not None else (indirect.numel() if indirect is not None else ids.numel()))
+    out = torch.empty(S, table.shape[1], dtype=torch.bfloat16, device=table.device)
+    _lib.check(_lib.load().lcc_embed_gather_bf16(
+        _chk(ids, torch.int32, "ids"), _chk(indirect, torch.int32, "indirect") if indirect is not None else None,
+        _chk(vit_index, torch.int32, "vit_index") if vit_index is not None else None, _chk(table, torch.bfloat16, "table"),
+        _chk(vit_rows, torch.bfloat16, "vit_rows") if vit_rows is not None else None, out.data_ptr(), S, table.shape[1], _st(out)),
+        "lcc_embed_gather_bf16")
+    return out
+
+
 def attn_decode_fused(qkv_partial: torch.Tensor, bias: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, kv: KvArena, layer: int,
                       slots: torch.Tensor, kv_len: torch.Tensor, n_q_heads: int, nsplit: int, counters: Optional[torch.Tensor] = None):
     """qkv_partial: fp32 [NS, B, (Hq+2Hkv)*128] split-K slabs of the q/k/v Linear.  Appends the new K/V at kv_len[slot] and returns

@@ -679,3 +679,29 @@ def test_unmodified_hf_model_on_the_gpu_with_every_plugin_matches_hf_cpu(dev):
         assert sum(r() is not None for r in plugin._LIVE_CACHES) == live_before - 1, "a dropped NativeKVCache must free its arena"
     finally:
         plugin.revert_livecc_amd_kernel_to_qwen2_vl()
+
+
+def test_embed_gather_with_video_row_scatter_is_bit_exact(dev):
+    """SURVEY a12 (Q2VL:1159-1176): embedding rows + the ViT rows scattered over the <|video_pad|> positions in order, and the decode
+    form (current token of a stream slot through an indirection) -- pure data movement, bit-exact."""
+    from livecc_amd import ops
+    V, H, S = 1000, 896, 301
+    g = torch.Generator().manual_seed(7)
+    table = _rand((V, H), dev, 1.0, 11)
+    ids = torch.randint(0, V, (S,), generator=g, dtype=torch.int32)
+    is_vid = torch.zeros(S, dtype=torch.bool)
+    is_vid[20:120] = True
+    is_vid[200:230] = True
+    n_vid = int(is_vid.sum())
+    vit = _rand((n_vid, H), dev, 1.0, 12)
+    vit_index = torch.full((S,), -1, dtype=torch.int32)
+    vit_index[is_vid] = torch.arange(n_vid, dtype=torch.int32)
+    got = ops.embed_gather(ids.to(dev), table, vit_index.to(dev), vit)
+    ref = table[ids.long().to(dev)].clone()
+    ref[is_vid.to(dev)] = vit                                   # masked_scatter: video rows in order
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.embed_gather(ids.to(dev), table), table[ids.long().to(dev)])
+    cur_tok = torch.randint(0, V, (16,), generator=g, dtype=torch.int32)      # per-slot current token; streams use slots 9, 2, 14
+    slots = torch.tensor([9, 2, 14], dtype=torch.int32)
+    got = ops.embed_gather(cur_tok.to(dev), table, indirect=slots.to(dev))
+    assert torch.equal(got, table[cur_tok[slots.long()].long().to(dev)])
