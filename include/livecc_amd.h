@@ -154,6 +154,11 @@ int lcc_debug_bench_attn_decode(int variant, int iters, const float* qkv_partial
                                 const void* sin, const int32_t* slots, const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay,
                                 int layer, void* q_scratch, void* out, int B, int n_q_heads, int nsplit_sep, int nsplit_fused,
                                 float* ws_o, float* ws_ml, int32_t* counters, float* out_us, void* stream);
+/* Device-wide hand-off cost (design input for a persistent decode-layer kernel): mode 0 = `iters` grid barriers inside one launch of
+ * `blocks` co-resident blocks (every wait bounded: a block that gives up is counted in *out_fails), 1 = `iters` dependent launches of a
+ * trivial `blocks`-block kernel, 2 = mode 0 with a 16-KB streaming read per block between barriers.  Microseconds per hand-off. */
+int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, void* scratch, size_t scratch_bytes, float* out_us, int* out_fails,
+                                 void* stream);
 int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode uses the fused kernel for batches of >= 16 (stream,
                                           KV head) pairs; bit 2: for every batch; bit 1: key splits merged in the same launch by the
                                           last-arriving block instead of a combine launch (default off) */

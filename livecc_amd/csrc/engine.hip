@@ -1109,6 +1109,74 @@ extern "C" int lcc_debug_bench_attn_decode(int variant, int iters, const float* 
   if (rc != 0) return fail(rc, "lcc_debug_bench_attn_decode: invalid arguments (%d)", rc);
   return check_launch("lcc_debug_bench_attn_decode");
 }
+// ---- what does a device-wide hand-off cost?  (the number the "one persistent launch per decode layer" design stands or falls with)
+// mode 0: `iters` grid barriers inside ONE launch of `blocks` co-resident blocks (monotonic agent-scope counter: arrive = relaxed
+//         fetch_add after a release fence, wait = acquire loads with s_sleep; every wait is BOUNDED -- a block that gives up counts
+//         itself in *fails and leaves, so a mis-sized grid cannot hang the GPU);
+// mode 1: `iters` dependent launches of a kernel of `blocks` blocks that touches one cache line per block (the kernel boundary);
+// mode 2: mode 0 with a 16-KB streaming read per block between barriers (a barrier under memory load).
+typedef __attribute__((ext_vector_type(4))) unsigned int bench_u32x4;
+__global__ __launch_bounds__(256) void grid_barrier_bench_kernel(unsigned* counter, unsigned* fails, int iters, int nblocks, const bench_u32x4* stream_src,
+                                                                 unsigned* sink) {
+  unsigned acc = 0;
+  for (int it = 1; it <= iters; ++it) {
+    if (stream_src != nullptr) {
+      const bench_u32x4 v = __builtin_nontemporal_load(stream_src + ((size_t)(blockIdx.x * 997 + it) % 4096) * 1024 + threadIdx.x * 4);
+      acc += v.x ^ v.w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = (unsigned)it * (unsigned)nblocks;
+      int spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > 100000) { atomicAdd(fails, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void boundary_bench_kernel(unsigned* buf, int it) {
+  if (threadIdx.x == 0) buf[blockIdx.x * 32] = buf[((blockIdx.x + 1) % gridDim.x) * 32] + (unsigned)it;
+}
+extern "C" int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, void* scratch, size_t scratch_bytes, float* out_us, int* out_fails,
+                                            void* stream) {
+  if (!scratch || !out_us || !out_fails || blocks < 1 || blocks > 1024 || iters < 1) return fail(LCC_ERR_ARG, "bad argument");
+  const size_t need = 4096 + (size_t)blocks * 128 + (mode == 2 ? (size_t)4096 * 1024 * 16 : 0);
+  if (scratch_bytes < need) return fail(LCC_ERR_ARG, "scratch too small: %zu bytes needed", need);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* ctr = (unsigned*)scratch;                       // [0] counter, [1] fails, [2] sink
+  unsigned* buf = ctr + 1024;
+  const bench_u32x4* src = mode == 2 ? reinterpret_cast<const bench_u32x4*>((char*)scratch + 4096 + (size_t)blocks * 128) : nullptr;
+  HIP_TRY(hipMemsetAsync(scratch, 0, 4096 + (size_t)blocks * 128, st));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  if (mode == 1) {
+    for (int it = -8; it < iters; ++it) {
+      if (it == 0) HIP_TRY(hipEventRecord(e0, st));
+      boundary_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(buf, it);
+    }
+  } else {
+    grid_barrier_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(ctr, ctr + 1, 8, blocks, src, ctr + 2);   // warm-up
+    HIP_TRY(hipMemsetAsync(scratch, 0, 64, st));
+    HIP_TRY(hipEventRecord(e0, st));
+    grid_barrier_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(ctr, ctr + 1, iters, blocks, src, ctr + 2);
+  }
+  HIP_TRY(hipEventRecord(e1, st));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  unsigned f = 0;
+  HIP_TRY(hipMemcpy(&f, ctr + 1, 4, hipMemcpyDeviceToHost));
+  *out_us = ms * 1000.f / (float)iters;
+  *out_fails = (int)f;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return check_launch("lcc_debug_bench_grid_barrier");
+}
 // ---- decode pipeline v2 operators (decode_v2.hip) ----
 extern "C" int lcc_decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_t* done, uint32_t* seen, int words_per_stream,
                                      const void* embed_table, void* h, float* stats, int dim, const int32_t* pos, const float* inv_freq,
