@@ -909,10 +909,21 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
   if (g_attn_variant == 2 && n_groups > 0) {
     constexpr size_t lds = (size_t)4 * (6 + 5) * 1024;
     static bool once = false;
-    if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0, 4>, lds); once = true; }
-    attn_shared_kernel<80, 2, 0, 4><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
-        qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
-        heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
+    if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0, 4>, lds); set_lds_attr(attn_shared_kernel<80, 1, 0, 8>, lds); once = true; }
+    // a group = 128 query rows of one head: 4 waves x 32 rows, or 8 waves x 16 rows.  The per-wave chain QK^T -> softmax -> PV is
+    // latency-bound; with few blocks on the chip (one stream's 2-frame chunk: 12 groups x 16 heads = 192 blocks, one wave per SIMD)
+    // two shorter chains per SIMD overlap where one long one cannot: 254.4 -> 258.3 tok/s single stream without the ViT prefetch
+    // (neutral with it: the other stream's waves already fill the gaps).  LCC_VIT_ATTN_WAVES=4|8 forces one.
+    static const int forced = [] { const char* v = getenv("LCC_VIT_ATTN_WAVES"); return v ? atoi(v) : 0; }();
+    const int waves = forced ? forced : ((long)n_groups * heads <= 512 ? 8 : 4);
+    if (waves == 8)
+      attn_shared_kernel<80, 1, 0, 8><<<dim3(n_groups, heads), dim3(512), lds, st>>>(
+          qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
+          heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
+    else
+      attn_shared_kernel<80, 2, 0, 4><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
+          qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
+          heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
     return 0;
   }
   attn_vit_kernel<80, 2><<<dim3((n_tiles + 3) / 4, heads), dim3(256), 0, st>>>(
