@@ -180,7 +180,8 @@ class StreamServer:
             st.kv, st.past_ids = o.past_key_values, seq[:-1]            # ref demo/infer.py:173-174
             st.turn_index += 1
             st.last_pts_index, st.last_timestamp = last_idx, last_ts
-            toks = [int(t) for t in seq[n_in:] if t != self.cfg.eos_token_id]
+            eos = set(getattr(self.model, "eos_token_ids", None) or (self.cfg.eos_token_id,))     # <|im_end|> and <|endoftext|>
+            toks = [int(t) for t in seq[n_in:] if int(t) not in eos]
             state = dict(last_timestamp=st.last_timestamp, turn_index=st.turn_index, dropped_s=st.dropped_s)
             if not hf_spaces:
                 state.update(past_ids=st.past_ids, past_key_values=st.kv)
