@@ -595,6 +595,11 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
   // prefill with few output tiles (N = hidden): split-K slabs, reduced by the fused residual-add + RMSNorm kernel
   const int tp_o = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, e->qd);
   const int tp_dn = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, I);
+  // q/k/v of a short prefill (one streaming chunk): split-K slabs consumed by the rope / KV-append kernel (267.5 -> 269.1 tok/s single
+  // stream; LCC_PREFILL_QKV_SPLIT=0 restores the bf16 GEMM output)
+  static const int qkv_split_on = [] { const char* v = getenv("LCC_PREFILL_QKV_SPLIT"); return v ? atoi(v) : 1; }();
+  const int tp_qkv = (cx.skinny || !qkv_split_on || e->c.llm_fp8 || (size_t)4 * std::min<size_t>(e->lim.max_new_rows, 4096) * H <
+                      (size_t)8 * S * e->qkvd) ? 1 : gemm_tiled_num_splits(S, e->qkvd, H);
   // fp8 weights: the same GemmArgs with the byte pointer, the row scales and the dequantisation scratch of the tiled path
   auto set_w = [&](GemmArgs& g, const bf16_t* w, const float* scale) {
     g.w_packed = 1; g.W = w;
@@ -626,6 +631,13 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       if (!fused_attn)
         LCC_TRY(rope_kv_append_bf16(nullptr, b.partial, sp_qkv, L.qkv_b, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
                                     e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
+    } else if (tp_qkv > 1) {
+      // one streaming chunk: N = 4608 is 252 tiles of 64 x 128 (one latency-bound block per CU) -> split K, the fp32 slabs are
+      // reduced (+ bias, one bf16 rounding as in the GEMM epilogue) by the rope / KV-append kernel
+      g.partial = b.partial; g.nsplit = tp_qkv;
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(rope_kv_append_bf16(nullptr, b.partial, tp_qkv, L.qkv_b, b.cos, b.sin, cx.tok_stream, cx.tok_pos, e->d_kv_len,
+                                  e->d_kv_base, e->lay, l, b.q, S, e->c.n_q_heads, st));
     } else {
       g.bias = L.qkv_b; g.C = b.qkv; g.ldc = e->qkvd;
       LCC_TRY(gemm_bf16(g, st));
