@@ -89,7 +89,7 @@ def distributed_generate(records: Sequence[dict], model_path: str, output_dir: s
     from . import distributed as D
     from .config import get_config
     from .infer import LiveCCDemoInfer
-    from .modeling import LiveCCForConditionalGeneration
+    from .modeling import LiveCCForConditionalGeneration, read_generation_config
     from .weights import WeightArena, from_pretrained
 
     rank, local, world = D.init_from_env()
@@ -98,7 +98,11 @@ def distributed_generate(records: Sequence[dict], model_path: str, output_dir: s
     cfg = get_config(model_path)
     arena = from_pretrained(model_path, cfg, dev) if rank == 0 else WeightArena(cfg, dev)
     D.broadcast_weights(arena.flat, src=0)
+    gen_cfg, eos_ids = read_generation_config(model_path)      # as from_pretrained: the checkpoint's sampling defaults and EOS ids
+    if eos_ids is not None:
+        model_kw.setdefault("eos_token_ids", eos_ids)
     model = LiveCCForConditionalGeneration(cfg, arena, dev, **model_kw)
+    model.generation_config = gen_cfg
     infer = LiveCCDemoInfer(model_path=model_path, model=model)
     save_dir = os.path.join(output_dir, os.path.basename(os.path.normpath(model_path)))
     generate_shard(records, infer, save_dir, rank, world, simple_ctx, repetition_penalty, max_new_tokens)

@@ -78,6 +78,21 @@ class _Cfg:
         self.vocab_size = c.vocab_size
 
 
+def read_generation_config(model_path: str):
+    """(generation_config.json as a dict, its EOS id list or None): what HF's `from_pretrained` attaches to the model and what
+    `generate` falls back to (do_sample / top_k / top_p / temperature / eos_token_id)."""
+    import json
+    import os
+    gen_cfg = {}
+    gc = os.path.join(model_path, "generation_config.json")
+    if os.path.exists(gc):
+        with open(gc) as f:
+            gen_cfg = json.load(f)
+    eos = gen_cfg.get("eos_token_id")
+    eos_ids = None if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [eos])
+    return gen_cfg, eos_ids
+
+
 class LiveCCForConditionalGeneration:
     main_input_name = "input_ids"
     DECODE_GROUP = 64          # LCC_MAX_DECODE_BATCH of include/livecc_amd.h: streams decoded per weight pass
@@ -126,16 +141,10 @@ class LiveCCForConditionalGeneration:
         device = device_map if isinstance(device_map, (str, torch.device)) and device_map not in ("auto",) else "cuda"
         if "cuda" not in str(device):
             raise RuntimeError("livecc_amd has no CPU path; use device_map='cuda[:i]' (the oracle under oracle/ is the CPU path)")
-        import json
-        import os
         cfg = get_config(model_path)
-        gen_cfg = {}
-        gc = os.path.join(model_path, "generation_config.json")
-        if os.path.exists(gc):
-            gen_cfg = json.load(open(gc))
-        eos = gen_cfg.get("eos_token_id")
-        if eos is not None and "eos_token_ids" not in kw:
-            kw["eos_token_ids"] = list(eos) if isinstance(eos, (list, tuple)) else [eos]
+        gen_cfg, eos_ids = read_generation_config(model_path)
+        if eos_ids is not None and "eos_token_ids" not in kw:
+            kw["eos_token_ids"] = eos_ids
         arena = _arena_from_pretrained(model_path, cfg, device, llm_fp8=bool(kw.pop("llm_fp8", False)))
         model = cls(cfg, arena, device, **kw)
         model.generation_config = gen_cfg
@@ -260,6 +269,9 @@ class LiveCCForConditionalGeneration:
         full_ids = []
         for rq in requests:
             st = rq.get("state") or self.new_stream()
+            if st.released or st.model is not self:
+                raise ValueError("past_key_values: this stream state was released (its KV slot may serve another stream) or belongs to "
+                                 "another model")
             ids_full = torch.as_tensor(rq["input_ids"]).reshape(-1).cpu().numpy().astype(np.int64)
             past_len = st.get_seq_length()
             if len(ids_full) <= past_len:

@@ -66,3 +66,17 @@ def test_sharded_safetensors_load_into_the_arena(tmp_path, naming, llm_fp8):
     os.remove(d / "model-00002-of-00002.safetensors")
     with pytest.raises(KeyError):
         W.from_pretrained(str(d), cfg, "cpu")
+
+
+def test_read_generation_config_gives_sampling_defaults_and_eos_list(tmp_path):
+    """`from_pretrained` and the offline driver both take the checkpoint's generation_config.json: sampling defaults and the EOS id
+    list ([<|im_end|>, <|endoftext|>] in the released checkpoints); a scalar EOS becomes a one-element list; no file -> ({}, None)."""
+    import json
+    from livecc_amd.modeling import read_generation_config
+    assert read_generation_config(str(tmp_path)) == ({}, None)
+    (tmp_path / "generation_config.json").write_text(json.dumps(
+        {"do_sample": True, "top_k": 1, "top_p": 0.001, "temperature": 0.01, "eos_token_id": [151645, 151643]}))
+    g, eos = read_generation_config(str(tmp_path))
+    assert g["top_k"] == 1 and g["do_sample"] is True and eos == [151645, 151643]
+    (tmp_path / "generation_config.json").write_text(json.dumps({"eos_token_id": 151645}))
+    assert read_generation_config(str(tmp_path))[1] == [151645]
