@@ -58,3 +58,25 @@ def test_parity_report_and_kv_schedule():
     b = protocol.TurnBuilder(cfg, seed=0)
     n0 = len(b.turn_ids(0, protocol.num_video_tokens(protocol.grid_of(6, 56, 84, cfg), cfg)))
     assert kv[:3] == [n0 + 1, n0 + 2, n0 + 3] and len(kv) == 3 * 3
+
+
+@pytest.mark.timeout(300)
+def test_the_drivers_own_torchrun_command_line():
+    """The driver launches N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`: the ranks must take WORLD_SIZE from that launcher (no second self-launch)
+    and rank 0 alone prints the one JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2"] + SMALL
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["launcher"] == "torchrun" and out["steps"] == 1 and out["warmup"] == 0
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "cpu_baseline"):
+        assert key in out, key
