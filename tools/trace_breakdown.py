@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Per-phase breakdown of a rocprofv3 kernel trace of bench.py (`rocprofv3 --kernel-trace --output-format csv`): what one decode step
+and one decoder layer cost, kernel by kernel, and how much of the wall time between the first and the last kernel of a step is not
+covered by any kernel (launch gaps).  A decode step starts at every `decode_step_begin_kernel` (pipeline v2) or `seen_set_kernel`
+(round-1 launch sequence) and ends at the next `sample_*` kernel on the same queue.
+
+    python tools/trace_breakdown.py <..._kernel_trace.csv> [n_layers]
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)               # drop the argument list
+    return name.replace("lcc::", "")
+
+
+def load(path):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Kind", "KERNEL_DISPATCH") != "KERNEL_DISPATCH":
+                continue
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "0")))
+    rows.sort()
+    return rows
+
+
+def breakdown(rows, n_layers=28):
+    steps, cur = [], None
+    for s, e, name, q in rows:
+        if name.startswith("decode_step_begin_kernel") or name.startswith("seen_set_kernel"):
+            cur = dict(queue=q, kernels=[])
+        if cur is not None and q == cur["queue"]:
+            cur["kernels"].append((s, e, name))
+            if name.startswith("sample_") and not name.startswith("sample_partial"):
+                steps.append(cur)
+                cur = None
+    per_kernel = defaultdict(lambda: [0, 0.0])
+    wall = busy = 0.0
+    for st in steps:
+        ks = st["kernels"]
+        wall += (ks[-1][1] - ks[0][0]) / 1e3
+        for s, e, name in ks:
+            per_kernel[name][0] += 1
+            per_kernel[name][1] += (e - s) / 1e3
+            busy += (e - s) / 1e3
+    n = max(1, len(steps))
+    out = dict(decode_steps=len(steps), avg_step_us=round(wall / n, 2), avg_kernel_time_per_step_us=round(busy / n, 2),
+               avg_gap_per_step_us=round((wall - busy) / n, 2), us_per_layer=round(wall / n / max(1, n_layers), 2), kernels={})
+    for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+        out["kernels"][name] = dict(calls_per_step=round(c / n, 2), avg_us=round(t / c, 2), us_per_step=round(t / n, 2))
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(breakdown(load(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 28), indent=1))
