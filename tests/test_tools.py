@@ -17,7 +17,9 @@ def test_trace_breakdown_finds_decode_steps_and_gaps(tmp_path):
         lines.append(f'"KERNEL_DISPATCH","Agent 2",{queue},0,1,1,1,"{name}",1,{t},{t + dur}\n')
         t += dur + gap
 
-    k("void lcc::gemm_big_kernel<128, 4, 1, false>(unsigned short const*, int)", 100000)       # prefill: not part of a step
+    k("lcc::seen_set_kernel(unsigned int*, int)", 3000)                                        # a prefill call: marks ids, GEMMs, samples
+    k("void lcc::gemm_big_kernel<128, 4, 1, false>(unsigned short const*, int)", 100000)
+    k("lcc::sample_final_kernel(float const*, int)", 2000)
     for _ in range(2):
         k("lcc::decode_step_begin_kernel(int const*, int const*)", 3000)
         for _layer in range(2):

@@ -38,7 +38,9 @@ def breakdown(rows, n_layers=28):
         if cur is not None and q == cur["queue"]:
             cur["kernels"].append((s, e, name))
             if name.startswith("sample_") and not name.startswith("sample_partial"):
-                steps.append(cur)
+                # a prefill call also marks ids (seen_set) and samples: it is recognised by its GEMM / prefill-attention kernels
+                if not any(k[2].startswith(("gemm_", "attn_shared", "attn_prefill", "attn_vit")) for k in cur["kernels"]):
+                    steps.append(cur)
                 cur = None
     per_kernel = defaultdict(lambda: [0, 0.0])
     wall = busy = 0.0
