@@ -207,3 +207,43 @@ def test_prefill_packs_streams_into_groups_under_max_new_rows():
     calls.clear()
     m._prefill(slots[:2], ids[:2], pos[:2], vit[:10], None, None, None)
     assert len(calls) == 1 and calls[0]["rows"] == [40, 50]
+
+
+def test_sampling_arguments_resolve_like_hf_generate():
+    """Explicit arguments override generation_config.json, which overrides HF's defaults (do_sample False, temperature 1.0, top_k 50,
+    top_p 1.0); `do_sample=None` (what video_qa / live_cc_once_for_evaluation pass, ref demo/infer.py:236-241, 297-302) lets the
+    checkpoint decide; invalid warper parameters are rejected with HF's messages."""
+    import pytest
+    from livecc_amd.modeling import LiveCCForConditionalGeneration as M
+    m = M.__new__(M)
+    m.generation_config = {}
+    assert m._resolve_sampling(None, {}) == dict(do_sample=False)
+    assert m._resolve_sampling(False, {"top_k": 5}) == dict(do_sample=False)
+    assert m._resolve_sampling(True, {}) == dict(do_sample=True, temperature=1.0, top_k=50, top_p=1.0, seed=0)
+    m.generation_config = {"do_sample": True, "top_k": 1, "top_p": 0.001, "temperature": 0.01}        # the released checkpoints'
+    assert m._resolve_sampling(None, {}) == dict(do_sample=True, temperature=0.01, top_k=1, top_p=0.001, seed=0)
+    assert m._resolve_sampling(None, {"top_k": 20, "seed": 7})["top_k"] == 20 and m._resolve_sampling(None, {"seed": 7})["seed"] == 7
+    assert m._resolve_sampling(False, {}) == dict(do_sample=False)
+    assert m._resolve_sampling(True, {"top_k": None})["top_k"] == 0                                     # HF: top_k=None disables the warper
+    with pytest.raises(ValueError):
+        m._resolve_sampling(True, {"temperature": 0.0})
+    with pytest.raises(ValueError):
+        m._resolve_sampling(True, {"top_p": 1.5})
+
+
+def test_threshold_processor_parameters_continue_from_count():
+    """ref demo/infer.py:10-23: threshold = base + step * count; a reused processor object continues where it stopped, and anything
+    that is not the reference's processor is refused instead of silently ignored."""
+    import pytest
+    from livecc_amd.infer import ThresholdLogitsProcessor
+    from livecc_amd.modeling import LiveCCForConditionalGeneration as M
+    assert M._threshold_params(None) is None and M._threshold_params([]) is None
+    p = ThresholdLogitsProcessor(77, 0.25, 0.05)
+    assert M._threshold_params([p]) == (77, 0.25, 0.05)
+    p.count = 4
+    tok, base, step = M._threshold_params([p])
+    assert tok == 77 and abs(base - 0.45) < 1e-12 and step == 0.05
+    with pytest.raises(NotImplementedError):
+        M._threshold_params([p, p])
+    with pytest.raises(NotImplementedError):
+        M._threshold_params([object()])
