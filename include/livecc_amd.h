@@ -260,6 +260,19 @@ int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, int* n_out)
  * milliseconds per decode step, for the step-level roofline (weights + KV bytes / step time) */
 int lcc_engine_profile_read_steps(lcc_engine* e, float* ms_out, int max_n, int* n_out);
 
+/* Parity instrumentation (tests only; SURVEY section 7 step 1: per-stage tensors).  While bound, every lcc_llm_prefill / lcc_llm_decode
+ * call copies the residual stream (HF `hidden_states`, Q2VL:762-844) of its rows into `taps` = bf16 [2*n_layers + 1][max_rows][hidden]:
+ * index 0 = the embeddings entering layer 0 (Q2VL:1159-1176), 2l+1 = after the attention block of layer l (the input of
+ * post_attention_layernorm, Q2VL:594-603), 2l+2 = the output of layer l (Q2VL:605-612).  `overrides` = bf16 [n_layers + 1][max_rows][hidden]
+ * (prefill only): the input of layer l is REPLACED by overrides[l] before the layer runs and overrides[n_layers] replaces the input
+ * of the final norm -- teacher forcing per layer, so that one layer's arithmetic (or final norm + lm_head) is compared in isolation
+ * with HF's on the oracle's own input.  NULL, NULL, 0 unbinds.  A call with more rows than
+ * max_rows fails with LCC_ERR_STATE.  lcc_debug_set_vit_taps: the same for the vision tower (Q2VL:700-729): taps bf16
+ * [vit_depth + 1][max_rows][vit_embed] (0 = PatchEmbed output, l+1 = output of block l), overrides [vit_depth + 1][max_rows][vit_embed]
+ * (input of block l; [vit_depth] = input of the PatchMerger). */
+int lcc_debug_set_llm_taps(lcc_engine* e, void* taps, const void* overrides, int max_rows);
+int lcc_debug_set_vit_taps(lcc_engine* e, void* taps, const void* overrides, int max_rows);
+
 /* stream (slot) state */
 int lcc_slot_reset(lcc_engine* e, int slot, void* stream);                 /* new video stream: empty KV, empty history */
 int lcc_slot_set_length(lcc_engine* e, int slot, int kv_len, int next_pos, void* stream);  /* truncate after EOS */

@@ -138,6 +138,8 @@ def load():
         "lcc_engine_profile": (i32, [vp, i32, i32]),
         "lcc_engine_profile_read": (i32, [vp, vp, i32, C.POINTER(i32)]),
         "lcc_engine_profile_read_steps": (i32, [vp, vp, i32, C.POINTER(i32)]),
+        "lcc_debug_set_llm_taps": (i32, [vp, vp, vp, i32]),
+        "lcc_debug_set_vit_taps": (i32, [vp, vp, vp, i32]),
         "lcc_slot_reset": (i32, [vp, i32, vp]),
         "lcc_slot_set_length": (i32, [vp, i32, i32, i32, vp]),
         "lcc_slot_get_length": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),

@@ -172,6 +172,14 @@ def qwen2vl_2b() -> LiveCCConfig:
                         name="qwen2vl-2b")
 
 
+def qwen2vl_2b_untied() -> LiveCCConfig:
+    """Qwen2-VL-2B shapes with a separate lm_head (parity tests with the `decisive` synthetic weights, whose lm_head is a row
+    permutation of the embedding table)."""
+    c = qwen2vl_2b()
+    c.tie_word_embeddings, c.name = False, "qwen2vl-2b-untied"
+    return c
+
+
 def qwen2vl_72b() -> LiveCCConfig:
     return LiveCCConfig(hidden_size=8192, intermediate_size=29568, num_hidden_layers=80,
                         num_attention_heads=64, num_key_value_heads=8, name="qwen2vl-72b")
@@ -198,7 +206,7 @@ def small() -> LiveCCConfig:
     )
 
 
-PRESETS = {"livecc-7b": livecc_7b, "qwen2vl-2b": qwen2vl_2b, "qwen2vl-72b": qwen2vl_72b,
+PRESETS = {"livecc-7b": livecc_7b, "qwen2vl-2b": qwen2vl_2b, "qwen2vl-2b-untied": qwen2vl_2b_untied, "qwen2vl-72b": qwen2vl_72b,
            "tiny": tiny, "small": small}
 
 

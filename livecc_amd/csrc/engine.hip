@@ -139,6 +139,9 @@ struct lcc_engine {
   int prof_n = 0; bool prof_on = false;
   std::vector<hipEvent_t> step_ev;   // whole decode steps (layers + lm_head + sampler), 2 * capacity
   int step_n = 0;
+  // parity instrumentation (lcc_debug_set_llm_taps / lcc_debug_set_vit_taps): residual-stream taps and per-layer input overrides
+  bf16_t* llm_taps = nullptr; const bf16_t* llm_over = nullptr; int llm_tap_rows = 0;
+  bf16_t* vit_taps = nullptr; const bf16_t* vit_over = nullptr; int vit_tap_rows = 0;
   // host mirrors
   std::vector<int> h_kv_len, h_pos;
   std::vector<void*> h_kv_base;
@@ -518,8 +521,12 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   // K2: patch embed (Conv3d k=s=(2,14,14) == GEMM, no bias; K = 1176 is not a multiple of 32: row-major weight)
   g = GemmArgs(); g.w_packed = 0; g.A = patches; g.lda = PD; g.W = e->patch_embed; g.ldw = PD; g.C = x; g.ldc = E; g.M = P; g.N = E; g.K = PD;
   LCC_TRY(gemm_bf16(g, st));
+  if ((e->vit_taps || e->vit_over) && P > e->vit_tap_rows) return fail(LCC_ERR_STATE, "ViT taps bound for %d rows, call has %d patches", e->vit_tap_rows, P);
+  const size_t tap_stride = (size_t)e->vit_tap_rows * E;
+  if (e->vit_taps) HIP_TRY(hipMemcpyAsync(e->vit_taps, x, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));   // tap 0 = PatchEmbed output
   for (int l = 0; l < e->c.vit_depth; ++l) {
     const VitLayerW& L = e->vit[l];
+    if (e->vit_over) HIP_TRY(hipMemcpyAsync(x, e->vit_over + (size_t)l * tap_stride, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));
     LCC_TRY(layernorm_bf16(x, L.ln1_w, L.ln1_b, xn, P, E, 1e-6f, st));
     g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
     LCC_TRY(gemm_bf16(g, st));
@@ -536,8 +543,10 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     g = GemmArgs(); g.w_packed = 1; g.A = mlp; g.lda = MLP; g.W = L.fc2_w; g.ldw = MLP; g.bias = L.fc2_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
     g.M = P; g.N = E; g.K = MLP; g.epilogue = LCC_EPI_RESIDUAL;
     LCC_TRY(gemm_bf16(g, st));
+    if (e->vit_taps) HIP_TRY(hipMemcpyAsync(e->vit_taps + (size_t)(l + 1) * tap_stride, x, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));
   }
   // merger: LN -> view [P/4, 4E] -> Linear + GELU -> Linear
+  if (e->vit_over) HIP_TRY(hipMemcpyAsync(x, e->vit_over + (size_t)e->c.vit_depth * tap_stride, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));
   LCC_TRY(layernorm_bf16(x, e->mg_ln_w, e->mg_ln_b, xn, P, E, 1e-6f, st));
   g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = 4 * E; g.W = e->mg_fc1_w; g.ldw = 4 * E; g.bias = e->mg_fc1_b; g.C = mg; g.ldc = 4 * E;
   g.M = P / 4; g.N = 4 * E; g.K = 4 * E; g.epilogue = LCC_EPI_GELU_ERF;
@@ -606,10 +615,19 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     if (scale != nullptr) { g.w_fp8 = 1; g.wscale = scale; g.dq_scratch = b.dq; }
   };
   LCC_TRY(rmsnorm_bf16(b.h, e->llm[0].in_norm, b.xn, S, H, eps, st));
+  // parity instrumentation: tap 0 = embeddings, 2l+1 = residual stream after the attention block of layer l, 2l+2 = after its MLP;
+  // an override replaces the INPUT of layer l (teacher forcing per layer: every layer is fed the oracle's hidden state)
+  if ((e->llm_taps || e->llm_over) && S > e->llm_tap_rows) return fail(LCC_ERR_STATE, "LLM taps bound for %d rows, call has %d", e->llm_tap_rows, S);
+  const size_t tap_stride = (size_t)e->llm_tap_rows * H, tap_bytes = (size_t)S * H * 2;
+  if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     const bf16_t* next_norm = (l + 1 < e->c.n_layers) ? e->llm[l + 1].in_norm : e->final_norm;
     GemmArgs g;
+    if (e->llm_over) {
+      HIP_TRY(hipMemcpyAsync(b.h, e->llm_over + (size_t)l * tap_stride, tap_bytes, hipMemcpyDeviceToDevice, st));
+      LCC_TRY(rmsnorm_bf16(b.h, L.in_norm, b.xn, S, H, eps, st));
+    }
     // q/k/v projection (+bias) -> M-RoPE -> in-place KV append
     g = GemmArgs(); set_w(g, L.qkv_w, L.qkv_s); g.A = b.xn; g.lda = H; g.ldw = H; g.M = S; g.N = e->qkvd; g.K = H;
     const bool fuse = cx.skinny && S <= 2 && g_fuse_tails && !e->c.llm_fp8;   // batch-1 decode: consumer ops run as GEMV tails
@@ -673,6 +691,7 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(rmsnorm_bf16(b.h, L.post_norm, b.xn, S, H, eps, st));
     }
+    if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 1) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
     // SwiGLU MLP
     g = GemmArgs(); set_w(g, L.gate_up_w, L.gate_up_s); g.A = b.xn; g.lda = H; g.ldw = H; g.C = b.act; g.ldc = I; g.M = S; g.N = 2 * I; g.K = H;
     g.epilogue = LCC_EPI_SWIGLU;
@@ -700,6 +719,11 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
       LCC_TRY(gemm_bf16(g, st));
       if (l + 1 < e->c.n_layers) LCC_TRY(rmsnorm_bf16(b.h, next_norm, b.xn, S, H, eps, st));
     }
+    if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 2) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
+  }
+  if (e->llm_over) {   // overrides[n_layers] = the input of the final norm (isolates final norm + lm_head)
+    HIP_TRY(hipMemcpyAsync(b.h, e->llm_over + (size_t)e->c.n_layers * tap_stride, tap_bytes, hipMemcpyDeviceToDevice, st));
+    if (cx.skinny) LCC_TRY(rmsnorm_bf16(b.h, e->final_norm, b.xn, S, H, eps, st));
   }
   return 0;
 }
@@ -717,6 +741,10 @@ bool decode_v2_ok(const lcc_engine* e) {
 int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, hipStream_t st) {
   const int H = e->c.hidden_size, I = e->c.intermediate_size;
   const float eps = e->c.rms_eps;
+  if (e->llm_over) return fail(LCC_ERR_STATE, "per-layer input overrides are a prefill-only instrument (decode pipeline v2 carries row statistics)");
+  if (e->llm_taps && B > e->llm_tap_rows) return fail(LCC_ERR_STATE, "LLM taps bound for %d rows, decode batch has %d", e->llm_tap_rows, B);
+  const size_t tap_stride = (size_t)e->llm_tap_rows * H, tap_bytes = (size_t)B * H * 2;
+  if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     DgArgs a;
@@ -727,6 +755,7 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
     a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
     LCC_TRY(dgemv_resid(a, st));
+    if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 1) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
     a = DgArgs(); a.W = L.gate_up_w; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
     a.eps = eps; a.C = b.act; a.ldc = I;
     const bool prof = e->prof_on && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();   // one sample per step
@@ -735,6 +764,7 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
     a = DgArgs(); a.W = L.down_w; a.M = B; a.N = H; a.K = I; a.X = b.act; a.ldx = I; a.Hres = b.h; a.stats_out = b.stats;
     LCC_TRY(dgemv_resid(a, st));
+    if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 2) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
   }
   return 0;
 }
@@ -945,6 +975,19 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   return check_launch("lcc_llm_decode");
 }
 
+// parity instrumentation (tests only): see include/livecc_amd.h
+extern "C" int lcc_debug_set_llm_taps(lcc_engine* e, void* taps, const void* overrides, int max_rows) {
+  if (!e || max_rows < 0 || ((taps || overrides) && max_rows == 0)) return fail(LCC_ERR_ARG, "bad argument");
+  if (((uintptr_t)taps | (uintptr_t)overrides) & 15) return fail(LCC_ERR_ALIGN, "tap buffers must be 16-byte aligned");
+  e->llm_taps = (bf16_t*)taps; e->llm_over = (const bf16_t*)overrides; e->llm_tap_rows = max_rows;
+  return 0;
+}
+extern "C" int lcc_debug_set_vit_taps(lcc_engine* e, void* taps, const void* overrides, int max_rows) {
+  if (!e || max_rows < 0 || ((taps || overrides) && max_rows == 0)) return fail(LCC_ERR_ARG, "bad argument");
+  if (((uintptr_t)taps | (uintptr_t)overrides) & 15) return fail(LCC_ERR_ALIGN, "tap buffers must be 16-byte aligned");
+  e->vit_taps = (bf16_t*)taps; e->vit_over = (const bf16_t*)overrides; e->vit_tap_rows = max_rows;
+  return 0;
+}
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_path(int path) {
   if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");

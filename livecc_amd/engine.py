@@ -241,6 +241,40 @@ class Engine:
         _lib.check(self.lib.lcc_llm_decode(self.h, len(slots), slots_a.ctypes.data, n_steps, first_step_index, C.byref(sp),
                                            self._stream()), "lcc_llm_decode")
 
+    # ---- parity instrumentation (tests only): residual-stream taps / per-layer input overrides ----
+    def set_llm_taps(self, max_rows: int, overrides: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Bind (max_rows > 0) or unbind (0) the LLM taps; returns the tap tensor bf16 [2L+1, max_rows, H] that the following
+        prefill / decode calls fill.  `overrides`: bf16 [L + 1, max_rows, H] = the input of every layer and of the final norm (prefill only)."""
+        cfg = self.cfg
+        if max_rows <= 0:
+            _lib.check(self.lib.lcc_debug_set_llm_taps(self.h, None, None, 0), "lcc_debug_set_llm_taps")
+            self._llm_taps = self._llm_over = None
+            return None
+        taps = torch.zeros(2 * cfg.num_hidden_layers + 1, max_rows, cfg.hidden_size, dtype=torch.bfloat16, device=self.device)
+        if overrides is not None:
+            assert overrides.shape == (cfg.num_hidden_layers + 1, max_rows, cfg.hidden_size) and overrides.dtype == torch.bfloat16
+            overrides = overrides.to(self.device).contiguous()
+        self._llm_taps, self._llm_over = taps, overrides
+        _lib.check(self.lib.lcc_debug_set_llm_taps(self.h, taps.data_ptr(), overrides.data_ptr() if overrides is not None else None,
+                                                   max_rows), "lcc_debug_set_llm_taps")
+        return taps
+
+    def set_vit_taps(self, max_rows: int, overrides: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """The same for the vision tower: taps bf16 [depth+1, max_rows, E] (0 = PatchEmbed output), overrides [depth+1, max_rows, E] (last = PatchMerger input)."""
+        cfg = self.cfg
+        if max_rows <= 0:
+            _lib.check(self.lib.lcc_debug_set_vit_taps(self.h, None, None, 0), "lcc_debug_set_vit_taps")
+            self._vit_taps = self._vit_over = None
+            return None
+        taps = torch.zeros(cfg.vit_depth + 1, max_rows, cfg.vit_embed_dim, dtype=torch.bfloat16, device=self.device)
+        if overrides is not None:
+            assert overrides.shape == (cfg.vit_depth + 1, max_rows, cfg.vit_embed_dim) and overrides.dtype == torch.bfloat16
+            overrides = overrides.to(self.device).contiguous()
+        self._vit_taps, self._vit_over = taps, overrides
+        _lib.check(self.lib.lcc_debug_set_vit_taps(self.h, taps.data_ptr(), overrides.data_ptr() if overrides is not None else None,
+                                                   max_rows), "lcc_debug_set_vit_taps")
+        return taps
+
     def profile(self, enable: bool, max_samples: int = 4096) -> None:
         _lib.check(self.lib.lcc_engine_profile(self.h, 1 if enable else 0, max_samples), "lcc_engine_profile")
 

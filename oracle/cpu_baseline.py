@@ -11,7 +11,9 @@ Run as a subprocess; prints one JSON object per line as it progresses (build, ev
 report a measured or a partially extrapolated rate inside a fixed wall-clock budget.
 
 Weights: `--weights tiled:<seed>` = the seeded synthetic model of `livecc_amd.weights.fill_hf_model_tiled` -- bit-identical to
-`WeightArena.fill_tiled(seed)` on the GPU, so the logits of this process ARE the oracle for the native path at full shapes.
+`WeightArena.fill_tiled(seed)` on the GPU, so the logits of this process ARE the oracle for the native path at full shapes;
+`--weights decisive:<seed>` = its variant with decisive top-1 margins (livecc_amd/weights.py: DECISIVE_*), on which greedy token
+identity is a hard test.
 Parity mode: `--teacher tokens.npy` teacher-forces the generation along the native tokens ([turns, N] int) and `--logits-out`
 receives the raw lm_head logits of every step ([turns, N, V] fp32) plus this model's own argmax before forcing.
 `--dtype float32` = the fp32 truth for the error-ratio test (same bf16-representable weights).
@@ -48,10 +50,8 @@ def main():
     a = ap.parse_args()
     import numpy as np
     import torch
-    from transformers import Qwen2VLForConditionalGeneration
     from livecc_amd import protocol
     from livecc_amd.config import get_config
-    from livecc_amd.weights import fill_hf_model_tiled
     from oracle import hf_oracle as O
     cfg = get_config(a.config)
     dtype = getattr(torch, a.dtype)
@@ -68,20 +68,7 @@ def main():
         pass
     emit(event="start", cores=cores, threads=torch.get_num_threads(), cpu=cpu_model, config=cfg.name, dtype=a.dtype)
     t0 = time.perf_counter()
-    with torch.device("meta"):
-        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=dtype)
-    m = m.to_empty(device="cpu")
-    assert a.weights.startswith("tiled:"), "only the seeded tiled synthetic weights are supported offline"
-    fill_hf_model_tiled(m, cfg, int(a.weights.split(":")[1]))
-    with torch.no_grad():
-        for name, buf in m.named_buffers():
-            if "inv_freq" in name:
-                dim = buf.numel() * 2
-                theta = 10000.0 if "visual" in name else cfg.rope_theta
-                buf.copy_(1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float) / dim)))
-    m.eval()
-    m.generation_config.do_sample = False
-    m.generation_config.top_k = m.generation_config.top_p = m.generation_config.temperature = None
+    m = O.build_hf_model_synthetic(cfg, dtype, a.weights)
     emit(event="built", seconds=round(time.perf_counter() - t0, 2))
 
     n_frames = 6 + 2 * (a.turns - 1)

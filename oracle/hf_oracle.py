@@ -119,6 +119,39 @@ def build_hf_model(cfg: LiveCCConfig, dtype=torch.bfloat16, seed: int = 0, init_
     return model
 
 
+def parse_weight_spec(spec: str):
+    """'tiled:<seed>' | 'decisive:<seed>' -> (variant, seed): the seeded synthetic models of livecc_amd.weights.synthetic_param."""
+    variant, _, seed = spec.partition(":")
+    if variant not in ("tiled", "decisive"):
+        raise ValueError(f"only the seeded synthetic weights (tiled:<seed> / decisive:<seed>) exist offline, got {spec!r}")
+    return variant, int(seed or 0)
+
+
+def build_hf_model_synthetic(cfg: LiveCCConfig, dtype=torch.bfloat16, spec: str = "tiled:0"):
+    """HF model at `cfg`'s shapes filled with the seeded synthetic weights of `WeightArena.fill_tiled(seed, variant)` -- bit-identical
+    to the MI355X arena, so this model's outputs ARE the oracle for the native path at full shapes.  Built on the meta device (no
+    random init of 8 B parameters) and filled window by window."""
+    from transformers import Qwen2VLForConditionalGeneration
+    from livecc_amd.weights import fill_hf_model_tiled
+    variant, seed = parse_weight_spec(spec)
+    with torch.device("meta"):
+        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=dtype)
+    m = m.to_empty(device="cpu")
+    fill_hf_model_tiled(m, cfg, seed, variant)
+    if cfg.tie_word_embeddings:
+        m.tie_weights()
+    with torch.no_grad():
+        for name, buf in m.named_buffers():
+            if "inv_freq" in name:
+                dim = buf.numel() * 2
+                theta = 10000.0 if "visual" in name else cfg.rope_theta
+                buf.copy_(1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float) / dim)))
+    m.eval()
+    m.generation_config.do_sample = False
+    m.generation_config.top_k = m.generation_config.top_p = m.generation_config.temperature = None
+    return m
+
+
 def fake_quantize_llm_fp8(model) -> None:
     """Replace every LLM Linear weight (q/k/v/o, gate/up/down, lm_head) by its OCP-e4m3 per-output-row quantisation
     q * scale (the values the native fp8 weight path computes with), rounded to the model's dtype.  On an fp32 model the

@@ -61,3 +61,27 @@ def test_native_stream_against_golden_fixture(dev):
             break
     record("golden_stream_tiny", dict(agree=agree, total=total, worst_rel_dlogit=worst))
     assert agree >= 0.8 * total, f"only {agree}/{total} free-running greedy tokens equal the golden oracle tokens"
+
+
+STAGES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stages_tiny.npz")
+
+
+def test_native_stages_against_the_per_stage_golden_fixture(dev):
+    """Every stage of the native engine (PatchEmbed, each vision block, merger, each decoder layer after attention / after the MLP,
+    final norm + lm_head) on the COMMITTED bf16-oracle input of that stage against the committed fp32 truth of that stage
+    (tests/golden/stages_tiny.npz from oracle/make_golden.py): rms error <= 1.25 x the bf16 oracle's own."""
+    from livecc_amd import protocol
+    from livecc_amd.config import tiny
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O
+    from oracle.make_golden import load_stages
+    from tests.test_gpu_layer_parity import _compare, native_probe
+    a16, t32, g = load_stages(STAGES)
+    cfg = tiny()
+    seed_w, seed_in, n_frames, H, W = (int(x) for x in g["meta"])
+    hf16 = O.build_hf_model(cfg, torch.bfloat16, seed_w, 2.0)       # weights only; the oracle is not run here
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=2048, max_new_rows=1024,
+                                                          max_patches=4096, max_history=4)
+    frames = torch.from_numpy(protocol.synth_frames(10, H, W, seed=seed_in, layout="TCHW"))[:n_frames]
+    nat = native_probe(native, cfg, g["ids"], frames.to(dev), a16)
+    _compare("per_stage_golden_tiny", nat, a16, t32, cfg, g["ids"])

@@ -79,3 +79,38 @@ def test_bf16_oracle_is_close_to_fp32_oracle_in_fixture():
         a, b = g[f"t{ti}_logits_bf16"], g[f"t{ti}_logits_fp32"]
         rel = np.abs(a - b).max() / np.abs(b).max()
         assert 1e-4 < rel < 0.06, rel
+
+
+STAGES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stages_tiny.npz")
+
+
+def test_layer_probe_reproduces_the_per_stage_fixture():
+    """oracle/layer_probe.py (HF with recording / replacing hooks) re-run on the fixture's inputs: the bf16 run's per-stage tensors
+    within bf16 noise of the committed ones (bit-equal on the same host), the teacher-forced fp32 run's within fp32 noise; and the
+    structure the per-layer tests rely on: with overrides, every stage's recorded input IS the override, and the un-overridden
+    chain is self-consistent (llm_in[l+1] == llm_out[l])."""
+    from oracle import layer_probe as P
+    from oracle.make_golden import STAGE_KEYS16, STAGE_KEYS32, load_stages
+    a_ref, t_ref, g = load_stages(STAGES)
+    cfg = tiny()
+    seed_w, seed_in, n_frames, H, W = (int(x) for x in g["meta"])
+    hf16 = O.build_hf_model(cfg, torch.bfloat16, seed_w, 2.0)
+    hf32 = O.build_hf_model(cfg, torch.float32, seed_w, 2.0)
+    frames = torch.from_numpy(protocol.synth_frames(10, H, W, seed=seed_in, layout="TCHW"))[:n_frames]
+    pv, grid = O.patchify_normalize_ref(frames, cfg)
+    ids = protocol.TurnBuilder(cfg, seed=seed_in).turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    assert np.array_equal(np.asarray(ids), g["ids"]) and list(grid) == g["grid"].tolist()
+    a16 = P.probe(hf16, cfg, ids, pv, grid)
+    for k in STAGE_KEYS16:
+        d = (a16[k].float() - a_ref[k].float()).abs().max().item()
+        assert d <= 0.05 * a_ref[k].float().abs().max().item(), (k, d)
+    assert torch.equal(a16["llm_in"][1:], a16["llm_out"][:-1]) and torch.equal(a16["vit_in"][1:], a16["vit_out"][:-1])
+    assert torch.equal(a16["final_in"], a16["llm_out"][-1]) and torch.equal(a16["merger_in"], a16["vit_out"][-1])
+    t32 = P.probe(hf32, cfg, ids, pv, grid, P.inputs_of(a_ref))
+    assert torch.equal(t32["llm_in"], a_ref["llm_in"].float()) and torch.equal(t32["vit_in"], a_ref["vit_in"].float())
+    for k in STAGE_KEYS32:
+        d = (t32[k] - t_ref[k]).abs().max().item()
+        assert d <= 1e-4 * t_ref[k].abs().max().item() + 1e-6, (k, d)
+    # the bf16 reference's own per-layer error against the teacher-forced truth: the unit of the per-layer parity bound
+    for r in P.layer_error_table(a_ref, a_ref, t_ref, ["vit_out", "llm_mid", "llm_out"]):
+        assert 1e-4 < r["err_ref16_rms"] / r["scale_rms"] < 2e-2, r
