@@ -156,7 +156,8 @@ int lcc_debug_bench_attn_decode(int variant, int iters, const float* qkv_partial
                                 float* ws_o, float* ws_ml, int32_t* counters, float* out_us, void* stream);
 /* Device-wide hand-off cost (design input for a persistent decode-layer kernel): mode 0 = `iters` grid barriers inside one launch of
  * `blocks` co-resident blocks (every wait bounded: a block that gives up is counted in *out_fails), 1 = `iters` dependent launches of a
- * trivial `blocks`-block kernel, 2 = mode 0 with a 16-KB streaming read per block between barriers.  Microseconds per hand-off. */
+ * trivial `blocks`-block kernel, 2 = mode 0 with a 16-KB streaming read per block between barriers, 3 / 4 = modes 0 / 2 on the
+ * XCD-hierarchical barrier (csrc/grid_sync.h: per-XCD arrival counters + one release fence per XCD leader).  Microseconds per hand-off. */
 int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, void* scratch, size_t scratch_bytes, float* out_us, int* out_fails,
                                  void* stream);
 int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode uses the fused kernel for batches of >= 16 (stream,

@@ -20,6 +20,7 @@
 
 #include "../../include/livecc_amd.h"
 #include "kernels.h"
+#include "grid_sync.h"
 
 using namespace lcc;
 
@@ -1169,7 +1170,9 @@ extern "C" int lcc_debug_bench_attn_decode(int variant, int iters, const float* 
 //         fetch_add after a release fence, wait = acquire loads with s_sleep; every wait is BOUNDED -- a block that gives up counts
 //         itself in *fails and leaves, so a mis-sized grid cannot hang the GPU);
 // mode 1: `iters` dependent launches of a kernel of `blocks` blocks that touches one cache line per block (the kernel boundary);
-// mode 2: mode 0 with a 16-KB streaming read per block between barriers (a barrier under memory load).
+// mode 2: mode 0 with a 16-KB streaming read per block between barriers (a barrier under memory load);
+// mode 3 / 4: modes 0 / 2 with the XCD-hierarchical barrier of grid_sync.h (per-XCD arrival counters, one release fence per XCD leader,
+//         per-XCD generation words) -- the form MI355X_MICROARCH.md prices at 4.1 us for 256 workgroups.
 typedef __attribute__((ext_vector_type(4))) unsigned int bench_u32x4;
 __global__ __launch_bounds__(256) void grid_barrier_bench_kernel(unsigned* counter, unsigned* fails, int iters, int nblocks, const bench_u32x4* stream_src,
                                                                  unsigned* sink) {
@@ -1195,18 +1198,34 @@ __global__ __launch_bounds__(256) void grid_barrier_bench_kernel(unsigned* count
   }
   if (acc == 0x12345678u) sink[0] = acc;
 }
+// modes 3 / 4: the same loop on the XCD-hierarchical barrier of grid_sync.h (MI355X_MICROARCH.md "barrier-xcd")
+__global__ __launch_bounds__(256) void grid_barrier_xcd_bench_kernel(GridSyncState* gs, int iters, const bench_u32x4* stream_src, unsigned* sink) {
+  GridSync g = gs_begin(gs);
+  if (!g.ok) return;
+  unsigned acc = 0;
+  for (int it = 1; it <= iters; ++it) {
+    if (stream_src != nullptr) {
+      const bench_u32x4 v = __builtin_nontemporal_load(stream_src + ((size_t)(blockIdx.x * 997 + it) % 4096) * 1024 + threadIdx.x * 4);
+      acc += v.x ^ v.w;
+    }
+    if (!gs_barrier(g)) return;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
 __global__ __launch_bounds__(256) void boundary_bench_kernel(unsigned* buf, int it) {
   if (threadIdx.x == 0) buf[blockIdx.x * 32] = buf[((blockIdx.x + 1) % gridDim.x) * 32] + (unsigned)it;
 }
 extern "C" int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, void* scratch, size_t scratch_bytes, float* out_us, int* out_fails,
                                             void* stream) {
   if (!scratch || !out_us || !out_fails || blocks < 1 || blocks > 1024 || iters < 1) return fail(LCC_ERR_ARG, "bad argument");
-  const size_t need = 4096 + (size_t)blocks * 128 + (mode == 2 ? (size_t)4096 * 1024 * 16 : 0);
+  if (mode < 0 || mode > 4) return fail(LCC_ERR_ARG, "mode must be 0..4");
+  const bool streaming = mode == 2 || mode == 4;
+  const size_t need = 4096 + (size_t)blocks * 128 + (streaming ? (size_t)4096 * 1024 * 16 : 0);
   if (scratch_bytes < need) return fail(LCC_ERR_ARG, "scratch too small: %zu bytes needed", need);
   hipStream_t st = (hipStream_t)stream;
   unsigned* ctr = (unsigned*)scratch;                       // [0] counter, [1] fails, [2] sink
   unsigned* buf = ctr + 1024;
-  const bench_u32x4* src = mode == 2 ? reinterpret_cast<const bench_u32x4*>((char*)scratch + 4096 + (size_t)blocks * 128) : nullptr;
+  const bench_u32x4* src = streaming ? reinterpret_cast<const bench_u32x4*>((char*)scratch + 4096 + (size_t)blocks * 128) : nullptr;
   HIP_TRY(hipMemsetAsync(scratch, 0, 4096 + (size_t)blocks * 128, st));
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -1215,6 +1234,13 @@ extern "C" int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, voi
       if (it == 0) HIP_TRY(hipEventRecord(e0, st));
       boundary_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(buf, it);
     }
+  } else if (mode >= 3) {
+    static_assert(sizeof(GridSyncState) <= 3584, "GridSyncState must fit the first 3.5 KB of the scratch");
+    GridSyncState* gs = (GridSyncState*)scratch;
+    grid_barrier_xcd_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(gs, 8, src, ctr + 900);   // warm-up
+    HIP_TRY(hipMemsetAsync(scratch, 0, 4096, st));
+    HIP_TRY(hipEventRecord(e0, st));
+    grid_barrier_xcd_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(gs, iters, src, ctr + 900);
   } else {
     grid_barrier_bench_kernel<<<dim3(blocks), dim3(256), 0, st>>>(ctr, ctr + 1, 8, blocks, src, ctr + 2);   // warm-up
     HIP_TRY(hipMemsetAsync(scratch, 0, 64, st));
@@ -1226,7 +1252,7 @@ extern "C" int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, voi
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
   unsigned f = 0;
-  HIP_TRY(hipMemcpy(&f, ctr + 1, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&f, mode >= 3 ? &((GridSyncState*)scratch)->fail[0] : ctr + 1, 4, hipMemcpyDeviceToHost));
   *out_us = ms * 1000.f / (float)iters;
   *out_fails = (int)f;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

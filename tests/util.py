@@ -47,7 +47,8 @@ def record(name, d):
     _REC[name] = d
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, "parity_report.json"), "w") as f:
+        w = os.environ.get("PYTEST_XDIST_WORKER")          # pytest -n N: one report per worker process (merged by the caller)
+        with open(os.path.join(OUT, f"parity_report_{w}.json" if w else "parity_report.json"), "w") as f:
             json.dump(_REC, f, indent=1, sort_keys=True, default=float)
     except OSError:
         pass

@@ -42,6 +42,7 @@ def breakdown(rows, n_layers=28):
                 if not any(k[2].startswith(("gemm_", "attn_shared", "attn_prefill", "attn_vit")) for k in cur["kernels"]):
                     steps.append(cur)
                 cur = None
+    prefill = prefill_breakdown(rows)
     per_kernel = defaultdict(lambda: [0, 0.0])
     wall = busy = 0.0
     for st in steps:
@@ -56,6 +57,37 @@ def breakdown(rows, n_layers=28):
                avg_gap_per_step_us=round((wall - busy) / n, 2), us_per_layer=round(wall / n / max(1, n_layers), 2), kernels={})
     for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
         out["kernels"][name] = dict(calls_per_step=round(c / n, 2), avg_us=round(t / c, 2), us_per_step=round(t / n, 2))
+    out["prefill"] = prefill
+    return out
+
+
+def prefill_breakdown(rows):
+    """LLM prefill calls (embed_gather_kernel ... first sample_* on the same queue, recognised by their GEMM / prefill-attention
+    kernels) and vision-tower calls (patchify / cast ... the last GEMM before the next non-ViT kernel are not delimited by a marker, so
+    the ViT is reported as the per-kernel totals of everything that is neither inside a decode step nor inside an LLM prefill)."""
+    calls, cur = [], None
+    for s, e, name, q in rows:
+        if name.startswith("embed_gather_kernel") and cur is None:
+            cur = dict(queue=q, kernels=[])
+        if cur is not None and q == cur["queue"]:
+            cur["kernels"].append((s, e, name))
+            if name.startswith("sample_") and not name.startswith("sample_partial"):
+                if any(k[2].startswith(("gemm_", "attn_shared", "attn_prefill")) for k in cur["kernels"]):
+                    calls.append(cur)
+                cur = None
+    per_kernel = defaultdict(lambda: [0, 0.0])
+    wall = busy = 0.0
+    for c in calls:
+        ks = c["kernels"]
+        wall += (ks[-1][1] - ks[0][0]) / 1e3
+        for s, e, name in ks:
+            per_kernel[name][0] += 1
+            per_kernel[name][1] += (e - s) / 1e3
+            busy += (e - s) / 1e3
+    n = max(1, len(calls))
+    out = dict(prefill_calls=len(calls), avg_call_us=round(wall / n, 1), avg_kernel_time_per_call_us=round(busy / n, 1), kernels={})
+    for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:24]:
+        out["kernels"][name] = dict(calls_per_prefill=round(c / n, 2), avg_us=round(t / c, 2), us_per_prefill=round(t / n, 1))
     return out
 
 
