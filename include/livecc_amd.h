@@ -71,8 +71,8 @@ int lcc_debug_set_attn_variant(int variant);
 int lcc_debug_set_fused_tails(int on);
 /* decode launch sequence of the engine: 1 (default) = pipeline v2 where eligible (bf16 weights, the row-permuted decode copy
  * "llm.<i>.qkv_w_dec" of every q|k|v weight set): RMSNorm / bias + M-RoPE + KV append / residual add run inside the weight-streaming
- * GEMVs, 6 launches per layer, for batches of up to 4 streams; 0 = the round-1 sequence of 9 launches per layer (always used
- * with fp8 weights and for larger batches).  Merging the attention key splits inside the o_proj GEMV as well (5 launches) was
+ * GEMVs, 6 launches per layer, for the batch sizes the engine routes to it (see lcc_llm_decode); 0 = the round-1 sequence of 9 launches
+ * per layer (always used with fp8 weights and for larger batches).  Merging the attention key splits inside the o_proj GEMV as well (5 launches) was
  * measured slower: 4-wave attention blocks 10.0 us + o_proj 9.8 us vs 7.3 + 4.9 + 6.8 us. */
 int lcc_debug_set_decode_path(int path);
 int lcc_gemv_num_splits(int N, int K);

@@ -433,10 +433,16 @@ __global__ __launch_bounds__(SNT) void sample_topk_topp_kernel(SampleParams P) {
     for (int w = 0; w < SNT / 64; ++w) z += s_scan[w];
     // remove while ascending cumulative probability <= 1 - top_p  (TopPLogitsWarper), i.e. mass <= (1 - top_p) * Z
     const unsigned long long cut = (unsigned long long)((double)(1.0f - P.top_p) * (double)z);
-    const uint32_t kp = descend(false, true, cut, key_floor);
-    key_floor = kp > key_floor ? kp : key_floor;
     const uint32_t kmax = order_key(xm);
-    if (key_floor > kmax) key_floor = kmax;                 // min_tokens_to_keep = 1
+    if (cut >= z) {
+      // no key has mass(keys <= t) > cut (top_p below ~6e-8: 1.0f - top_p rounds to 1): HF removes everything but the last sorted
+      // element (min_tokens_to_keep = 1) -- keep the maximum only (the descent's fallback would land on the SMALLEST key of the top bin)
+      key_floor = kmax;
+    } else {
+      const uint32_t kp = descend(false, true, cut, key_floor);
+      key_floor = kp > key_floor ? kp : key_floor;
+      if (key_floor > kmax) key_floor = kmax;               // min_tokens_to_keep = 1
+    }
   }
 
   // ---- final pass: masses of the kept set in thread-major order, processed scores out, inverse-CDF draw ----

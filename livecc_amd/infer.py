@@ -48,6 +48,7 @@ def _hw(clip: torch.Tensor, layout: str):
 
 
 class LiveCCDemoInfer:
+    MAX_CACHED_READERS = 8     # decoded-video readers kept by live_cc (the reference never evicts; a long-running server must)
     VIDEO_PLAY_END = object()
     VIDEO_PLAY_CONTINUE = object()
     fps = protocol.FPS
@@ -86,6 +87,10 @@ class LiveCCDemoInfer:
             self.system_prompt_offset = None
         self._cached_video_readers_with_hw = {}
         self.last_generated: list = []      # per generate call of the most recent flows: span, new prompt ids, generated ids
+
+    def close_video(self, video_path) -> None:
+        """Drop the cached reader of a finished video (path or DecodedVideo object) so that its frames can be freed."""
+        self._cached_video_readers_with_hw.pop(video_path if isinstance(video_path, str) else id(video_path), None)
 
     # --------------------------------------------------------------------------------------------------------------
     # one generate call per chunk (ref demo/infer.py:132-180, step 5)
@@ -144,6 +149,8 @@ class LiveCCDemoInfer:
         key = video_path if isinstance(video_path, str) else id(video_path)
         if key not in self._cached_video_readers_with_hw:
             self._cached_video_readers_with_hw[key] = V.get_smart_resized_video_reader(video_path, max_pixels)
+            while len(self._cached_video_readers_with_hw) > self.MAX_CACHED_READERS:       # oldest first (dict order)
+                self._cached_video_readers_with_hw.pop(next(iter(self._cached_video_readers_with_hw)))
         if state.get("video_pts") is None:
             # the reference fills these only when it opens the reader (:91-95), so a second state over an already cached video
             # silently yields nothing there; here every new state starts from the cached reader
@@ -166,12 +173,13 @@ class LiveCCDemoInfer:
             return
         timestamps = torch.arange(last_timestamp + self.frame_time_interval, video_timestamp, self.frame_time_interval).tolist()
         # 3. fetch frames at the required timestamps, resized on the GPU (ref :113-118)
+        # Only the frames that are due travel to HBM (the reference fetches exactly these with decord's get_batch, ref
+        # video_process_patch.py:146): the frame indices are chosen on the host, `reader.get_batch` uploads them (a decoded video
+        # that already lives on the GPU is indexed in place) and the resize runs on the GPU.  A 5-minute 1080p30 video is ~56 GB of
+        # uint8 frames -- it is never made resident as a whole.
         from . import resize as R
-        frames = reader.frames if reader.frames.is_cuda else reader.frames.to(self.model.device)
-        if frames is not reader.frames:
-            reader.frames = frames                       # keep the decoded video resident in HBM for the next calls
-        clip, clip_timestamps, clip_idxs = R.get_smart_resized_clip(frames, resized_height, resized_width, timestamps, video_pts,
-                                                                   last_video_pts_index + 1, reader.layout)
+        clip, clip_timestamps, clip_idxs = R.get_smart_resized_clip(reader, resized_height, resized_width, timestamps, video_pts,
+                                                                   last_video_pts_index + 1, reader.layout, device=self.model.device)
         if len(clip_idxs) == 0:
             return
         state["last_video_pts_index"] = clip_idxs[-1]

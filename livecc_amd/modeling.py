@@ -131,6 +131,7 @@ class LiveCCForConditionalGeneration:
         self._side: Optional[torch.cuda.Stream] = None
         self._vit_cache: dict = {}
         self._vit_last_event: Optional[torch.cuda.Event] = None
+        self._sample_calls = 0                      # generate calls that drew their Philox seed from torch.initial_seed()
 
     # ---- constructors ----
     @classmethod
@@ -214,7 +215,8 @@ class LiveCCForConditionalGeneration:
             raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
         if top_k < 0 or not (0 < float(top_p) <= 1.0):
             raise ValueError(f"top_k must be >= 0 and top_p in (0, 1], got {top_k}, {top_p}")
-        return dict(do_sample=True, temperature=float(temperature), top_k=top_k, top_p=float(top_p), seed=int(kw.get("seed", g.get("seed", 0)) or 0))
+        seed = kw.get("seed", g.get("seed"))
+        return dict(do_sample=True, temperature=float(temperature), top_k=top_k, top_p=float(top_p), seed=None if seed is None else int(seed))
 
     @torch.inference_mode()
     def generate(self, input_ids: torch.Tensor = None, pixel_values_videos: Optional[torch.Tensor] = None,
@@ -243,7 +245,7 @@ class LiveCCForConditionalGeneration:
     def generate_batch(self, requests: Sequence[dict], repetition_penalty: float = 1.0, logits_processor=None,
                        max_new_tokens: int = 16, force_length: bool = False, eos_token_id=None,
                        output_logits: bool = False, output_scores: bool = False, do_sample: bool = False, temperature: float = 1.0,
-                       top_k: int = 0, top_p: float = 1.0, seed: int = 0, prefetch: Optional[Sequence[dict]] = None) -> List[GenerateOutput]:
+                       top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None, prefetch: Optional[Sequence[dict]] = None) -> List[GenerateOutput]:
         """Many streams, one call: the ViTs of all clips run as one batch, all prefills as one packed batch, and the
         decode steps advance every stream together (weights are streamed from HBM once per step for the whole batch).
         Each request: input_ids (1-D, full history like the reference's cat(past_ids, new_ids)), optional
@@ -264,6 +266,12 @@ class LiveCCForConditionalGeneration:
             raise ValueError(f"max_new_tokens={max_new_tokens} exceeds this model's max_history={eng.max_history}: construct the model "
                              f"with max_history >= the largest max_new_tokens you generate (video_qa uses 512)")
         thr = self._threshold_params(logits_processor)
+        if seed is None:
+            # HF draws from torch's global generator, so two generate calls never repeat their draws; the kernel's Philox stream is
+            # keyed by (seed, slot, per-slot draw counter) and the counter restarts with every fresh stream -- without a per-call
+            # seed every new stream on a slot would replay the same "samples".  Explicit `seed=` keeps a call reproducible.
+            seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF
+            self._sample_calls += 1
         n = len(requests)
         states, ids_new, pos3, clips, slots = [], [], [], [], []
         full_ids = []
@@ -374,8 +382,7 @@ class LiveCCForConditionalGeneration:
         cfg = self.cfg
         with torch.cuda.stream(side):
             emb = self._vit_encode([c for _, c in todo], stream=side)     # ONE batched launch sequence (large-M GEMMs), sliced per clip
-            ev = torch.cuda.Event()
-            ev.record(side)
+            ev = self._vit_last_event                                     # recorded by _vit_encode after the last ViT kernel
             off = 0
             for k, clip in todo:
                 f, lay = clip["frames"], clip["layout"]
@@ -383,7 +390,6 @@ class LiveCCForConditionalGeneration:
                 n = ((f.shape[0] + 1) // 2) * (H // cfg.patch_size) * (W // cfg.patch_size) // 4
                 self._vit_cache[k] = (emb[off:off + n], ev, (clip["frames"], emb))
                 off += n
-            self._vit_last_event = ev
         while len(self._vit_cache) > 64:        # unclaimed prefetches do not accumulate
             self._vit_cache.pop(next(iter(self._vit_cache)))
 
@@ -392,10 +398,6 @@ class LiveCCForConditionalGeneration:
         main = torch.cuda.current_stream(self.device)
         hits = {i: self._vit_cache.pop(c["key"]) for i, c in enumerate(clips) if c.get("key") in self._vit_cache}
         miss = [i for i in range(len(clips)) if i not in hits]
-        if self._vit_last_event is not None and (miss or hits):
-            main.wait_event(self._vit_last_event)          # ViT calls share one workspace: never two in flight
-            if not self._vit_cache:
-                self._vit_last_event = None
         if not hits:
             return self._vit_encode(clips)
         parts: dict = {}
@@ -458,8 +460,21 @@ class LiveCCForConditionalGeneration:
             cur.append(pc); cur_p += n
         if cur:
             groups.append(cur)
+        # EVERY vision-tower launch goes through here: the tower has ONE private workspace + meta ring (lcc_engine_bind_vit_buffers),
+        # so the issuing stream first waits for the previous ViT call -- wherever it ran (main stream, prefetch side stream,
+        # get_video_features) -- and leaves an event behind for the next one.  Never two ViT calls in flight.
+        issuing = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if self._vit_last_event is not None:
+            issuing.wait_event(self._vit_last_event)
         outs = [eng.vit_encode(g, stream=stream) for g in groups]
-        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        out = outs[0]
+        if len(outs) > 1:
+            with torch.cuda.stream(issuing):
+                out = torch.cat(outs, dim=0)
+        ev = torch.cuda.Event()
+        ev.record(issuing)            # after the last ViT kernel AND the concatenation: consumers of `out` wait for this event
+        self._vit_last_event = ev
+        return out
 
     def _prefill(self, slots, ids_new, pos3, vit, sp, scores_buf, logits_buf) -> None:
         """One packed prefill when everything fits `max_new_rows`; otherwise consecutive streams are packed into groups of at

@@ -155,12 +155,16 @@ def resize_bicubic_aa(frames: torch.Tensor, height: int, width: int, layout: str
     return out
 
 
-def get_smart_resized_clip(video_frames: torch.Tensor, resized_height: int, resized_width: int, timestamps, video_pts,
-                           video_pts_index_from: int = 0, layout: str = "THWC"):
-    """ref video_process_patch.py:126-156 with the decoded video resident on the GPU (`video_frames` uint8, all frames):
-    returns (clip uint8 [n,3,h,w], kept timestamps, frame indices) -- the tensor `live_cc` feeds to the processor."""
+def get_smart_resized_clip(video, resized_height: int, resized_width: int, timestamps, video_pts,
+                           video_pts_index_from: int = 0, layout: str = "THWC", device=None):
+    """ref video_process_patch.py:126-156: returns (clip uint8 [n,3,h,w], kept timestamps, frame indices) -- the tensor `live_cc`
+    feeds to the processor.  `video`: a decoded-video reader with `get_batch(idxs, device)` (decord's interface: ONLY the selected
+    frames travel to `device`, as in the reference) or a uint8 tensor of all frames that already lives on the GPU."""
     idxs, ts = select_clip_frames(timestamps, video_pts, video_pts_index_from)
     if not idxs:
         return None, ts, idxs
-    sel = video_frames.index_select(0, torch.as_tensor(idxs, device=video_frames.device))
+    if hasattr(video, "get_batch"):
+        sel = video.get_batch(idxs, device=device)
+    else:
+        sel = video.index_select(0, torch.as_tensor(idxs, device=video.device))
     return resize_bicubic_aa(sel, resized_height, resized_width, layout), ts, idxs

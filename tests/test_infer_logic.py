@@ -50,7 +50,7 @@ class FakeModel:
 
 @pytest.fixture()
 def infer(monkeypatch):
-    def fake_clip(frames, h, w, ts, pts, index_from, layout="THWC"):
+    def fake_clip(frames, h, w, ts, pts, index_from, layout="THWC", device=None):
         idxs, kept = R.select_clip_frames(ts, pts, index_from)
         return (torch.zeros(len(idxs), 3, h, w, dtype=torch.uint8) if idxs else None), kept, idxs
     monkeypatch.setattr(R, "get_smart_resized_clip", fake_clip)
@@ -219,9 +219,9 @@ def test_sampling_arguments_resolve_like_hf_generate():
     m.generation_config = {}
     assert m._resolve_sampling(None, {}) == dict(do_sample=False)
     assert m._resolve_sampling(False, {"top_k": 5}) == dict(do_sample=False)
-    assert m._resolve_sampling(True, {}) == dict(do_sample=True, temperature=1.0, top_k=50, top_p=1.0, seed=0)
+    assert m._resolve_sampling(True, {}) == dict(do_sample=True, temperature=1.0, top_k=50, top_p=1.0, seed=None)
     m.generation_config = {"do_sample": True, "top_k": 1, "top_p": 0.001, "temperature": 0.01}        # the released checkpoints'
-    assert m._resolve_sampling(None, {}) == dict(do_sample=True, temperature=0.01, top_k=1, top_p=0.001, seed=0)
+    assert m._resolve_sampling(None, {}) == dict(do_sample=True, temperature=0.01, top_k=1, top_p=0.001, seed=None)
     assert m._resolve_sampling(None, {"top_k": 20, "seed": 7})["top_k"] == 20 and m._resolve_sampling(None, {"seed": 7})["seed"] == 7
     assert m._resolve_sampling(False, {}) == dict(do_sample=False)
     assert m._resolve_sampling(True, {"top_k": None})["top_k"] == 0                                     # HF: top_k=None disables the warper
@@ -247,3 +247,30 @@ def test_threshold_processor_parameters_continue_from_count():
         M._threshold_params([p, p])
     with pytest.raises(NotImplementedError):
         M._threshold_params([object()])
+
+
+def test_live_cc_uploads_only_the_due_frames_and_evicts_old_readers(infer, monkeypatch):
+    """the decoded video stays where the decoder put it (host); per call only the selected frame indices are fetched
+    through `get_batch` (the reference's decord call), and the reader cache is bounded."""
+    fetched = []
+
+    def spy_clip(video, h, w, ts, pts, index_from, layout="THWC", device=None):
+        idxs, kept = R.select_clip_frames(ts, pts, index_from)
+        assert hasattr(video, "get_batch"), "live_cc must hand the READER over, not a resident copy of all frames"
+        if idxs:
+            fetched.append(tuple(video.get_batch(idxs).shape))
+        return (torch.zeros(len(idxs), 3, h, w, dtype=torch.uint8) if idxs else None), kept, idxs
+    monkeypatch.setattr(R, "get_smart_resized_clip", spy_clip)
+    n = 40
+    vids = [V.DecodedVideo(torch.zeros(n, 56, 84, 3, dtype=torch.uint8), np.arange(n) / 4.0) for _ in range(infer.MAX_CACHED_READERS + 3)]
+    for v in vids:
+        state = {"video_path": v, "video_timestamp": 3.0}
+        list(infer.live_cc(message="q", state=state, max_new_tokens=2))
+        assert not v.frames.is_cuda and v.frames.shape[0] == n
+        kv = state.get("past_key_values")
+        if kv is not None:
+            kv.release()
+    assert fetched and all(s[0] <= 8 for s in fetched), fetched
+    assert len(infer._cached_video_readers_with_hw) <= infer.MAX_CACHED_READERS
+    infer.close_video(vids[-1])
+    assert id(vids[-1]) not in infer._cached_video_readers_with_hw
