@@ -51,9 +51,13 @@ def parse(argv=None):
     ap.add_argument("--max-new-tokens", type=int, default=16)
     ap.add_argument("--fused-tails", type=int, default=None, choices=[0, 1],
                     help="debug A/B: fuse add+rmsnorm / rope+append into the decode GEMV tails (default: library default)")
-    ap.add_argument("--workload", choices=["stream60", "long480"], default="stream60",
+    ap.add_argument("--workload", choices=["stream60", "long480", "oneshot480"], default="stream60",
                     help="long480 = BASELINE.json configs[3]: one 480-frame 280x280 video (24k visual tokens), 12 tokens per turn, "
-                         "KV growing to ~32k; overrides --frames/--height/--width/--max-new-tokens")
+                         "KV growing to ~32k; oneshot480 = the OTHER half of configs[3]: the reference's video_qa / MCQ first turn "
+                         "(ref demo/infer.py:182-242): all 480 frames in ONE generate call (ViT over 96,000 patches in 240 segments, "
+                         "one 24k-row LLM prefill served in pieces, then 32 decode tokens at L ~ 24k); both override "
+                         "--frames/--height/--width/--max-new-tokens")
+    ap.add_argument("--prefill-rows", type=int, default=4096, help="oneshot480: rows of one prefill launch sequence (max_new_rows)")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: LLM Linear weights as OCP e4m3 + fp32 row scales (BASELINE.json configs[4], 72B on one GPU)")
     ap.add_argument("--gemv-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemv_variant")
@@ -75,6 +79,8 @@ def parse(argv=None):
         a.parity = "full" if a.gpus == 1 else "bf16"
     if a.workload == "long480":
         a.frames, a.height, a.width, a.max_new_tokens = 480, 280, 280, 12
+    if a.workload == "oneshot480":
+        a.frames, a.height, a.width, a.max_new_tokens = 480, 280, 280, 32
     return a
 
 
@@ -151,6 +157,45 @@ def replay(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod,
     for s in states:
         s.release()
     return tokens, n * nframes
+
+
+def replay_oneshot(model, cfg, frames_list, builders_seed, max_new, protocol, torch_mod):
+    """The reference's video_qa / MCQ first turn (ref demo/infer.py:182-242, evaluation/distributed_mcq_predictor.py:72-105) for every
+    local stream: the WHOLE clip + a query in one generate call -- the vision tower over every temporal slice, one long prefill
+    (cut into max_new_rows pieces over the carried KV by the model), max_new forced greedy tokens.  Returns (tokens, frames)."""
+    n = len(frames_list)
+    reqs = []
+    for i in range(n):
+        clip = frames_list[i]
+        grid = protocol.grid_of(clip.shape[0], clip.shape[1], clip.shape[2], cfg)
+        b = protocol.TurnBuilder(cfg, seed=builders_seed[i])
+        b.query_len = 24
+        ids = b.turn_ids(0, protocol.num_video_tokens(grid, cfg), with_query=True)
+        reqs.append(dict(input_ids=torch_mod.from_numpy(ids), frames=clip, frames_layout="THWC", state=None))
+    outs = model.generate_batch(reqs, repetition_penalty=1.05, max_new_tokens=max_new, force_length=True)
+    for o in outs:
+        o.sequences[0, -1].item()          # the reference reads the answer back (processor.decode)
+        o.past_key_values.release()
+    return n * max_new, n * frames_list[0].shape[0]
+
+
+ONESHOT_TEXT_IDS = 14 + 3 + 10 + 2 + 24 + 5      # TurnBuilder: system, user header, 'Time=a-bs', vision start/end, 24-id query, trailer
+
+
+def oneshot_flops(cfg, nframes, height, width, n_text):
+    """Algorithmic flops of one one-shot call up to its first token (SURVEY 8d formulas): ViT per temporal slice of n patches
+    2 n (patch-embed + 32 blocks) + 32 * 4 n^2 * 1280 + merger; LLM prefill of S rows 2 * layer params * S + causal attention
+    4 * S * (S / 2) * q_dim per layer + lm_head once."""
+    n = (height // 14) * (width // 14)
+    slices = (nframes + 1) // 2
+    E, M, H = cfg.vit_embed_dim, cfg.vit_mlp_dim, cfg.hidden_size
+    blk = E * 3 * E + E * E + 2 * E * M
+    vit = slices * (2 * n * (cfg.patch_dim * E + cfg.vit_depth * blk) + cfg.vit_depth * 4 * n * n * E
+                    + 2 * (n // 4) * (4 * E * 4 * E + 4 * E * H))
+    S = slices * (n // 4) + n_text
+    lin = cfg.hidden_size * cfg.qkv_dim + cfg.q_dim * cfg.hidden_size + 3 * cfg.hidden_size * cfg.intermediate_size
+    llm = cfg.num_hidden_layers * (2 * lin * S + 4 * S * (S / 2) * cfg.q_dim) + 2 * cfg.vocab_size * H
+    return dict(vit_flops=float(vit), llm_prefill_flops=float(llm), prefill_rows=int(S), patches=int(slices * n))
 
 
 def kv_lengths_of_decode_steps(cfg, nframes, height, width, max_new, protocol):
@@ -366,17 +411,30 @@ def main():
             ops.set_gemv_variant(args.gemv_variant)
         if args.decode_path is not None:
             _lib.check(_lib.load().lcc_debug_set_decode_path(args.decode_path), "lcc_debug_set_decode_path")
-        model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
-                                               max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
-                                               max_history=max(16, args.max_new_tokens))
+        if args.workload == "oneshot480":
+            kv_total = (args.frames // 2) * n_tok_turn + 128 + args.max_new_tokens
+            model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=32 * ((kv_total + 31) // 32) + 64,
+                                                   max_new_rows=args.prefill_rows, max_patches=40 * 4 * n_tok_turn,
+                                                   max_history=max(16, args.max_new_tokens))
+        else:
+            model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
+                                                   max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
+                                                   max_history=max(16, args.max_new_tokens))
     frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + rank * spg + i)).to(dev)
               for i in range(spg)]
     seeds = [1234 + rank * spg + i for i in range(spg)]
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
 
     pf = not args.no_prefetch
+    oneshot = args.workload == "oneshot480"
+    if oneshot:
+        def run_once():
+            return replay_oneshot(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch)
+    else:
+        def run_once():
+            return replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, pf)
     for _ in range(args.warmup):
-        replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, pf)
+        run_once()
     if model.engine is not None:
         model.engine.profile(True, 16384)
     D.barrier(dev)
@@ -384,7 +442,7 @@ def main():
     t0 = time.perf_counter()
     toks = nfr = 0
     for _ in range(args.steps):
-        a, b = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, pf)
+        a, b = run_once()
         toks += a
         nfr += b
     sync()
@@ -425,7 +483,11 @@ def main():
             # whole decode step: every Linear weight of the 28 layers + lm_head once for the batch, plus each stream's KV read and
             # its new KV row written, plus the logits (SURVEY 8d "decode step" formula)
             wbytes = (cfg.decode_weight_bytes() // 2) if fp8 else cfg.decode_weight_bytes()
-            kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
+            if oneshot:
+                S0 = oneshot_flops(cfg, args.frames, args.height, args.width, ONESHOT_TEXT_IDS)["prefill_rows"]
+                kv_list = [S0 + k for k in range(1, args.max_new_tokens)]
+            else:
+                kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
             kv_avg = float(np.mean(kv_list)) if kv_list else 0.0
             step_bytes = wbytes + spg * (kv_avg * cfg.kv_bytes_per_token + cfg.kv_bytes_per_token + cfg.vocab_size * 4)
             s_ms = float(np.mean(st_ms))
@@ -436,6 +498,26 @@ def main():
                              us_per_layer=round((s_ms * 1e3) / cfg.num_hidden_layers, 2))
             if roof is not None:
                 roof["decode_step"] = step_roof
+        if oneshot:
+            # the one-shot call is MFMA-bound up to its first token: the vision tower over every slice + the long prefill.  Timed live
+            # with events around prefill-only calls (max_new_tokens = 1) on the launch stream; flops = SURVEY 8d formulas.
+            fl = oneshot_flops(cfg, args.frames, args.height, args.width, ONESHOT_TEXT_IDS)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 2
+            e0.record()
+            for _ in range(reps):
+                replay_oneshot(model, cfg, frames, seeds, 1, protocol, torch)
+            e1.record()
+            e1.synchronize()
+            ms1 = e0.elapsed_time(e1) / reps
+            tf = spg * (fl["vit_flops"] + fl["llm_prefill_flops"]) / (ms1 * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="one-shot video_qa turn up to the first token: ViT over every temporal slice + the whole-clip LLM "
+                                             "prefill (every GEMM / attention launch of the call)",
+                        achieved=round(tf, 1), peak=2500.0, unit="TFLOP/s", frac=round(tf / 2500.0, 4), traffic=None,
+                        avg_call_ms=round(ms1, 2), calls_timed=reps, algorithmic_flops_per_call=spg * (fl["vit_flops"] + fl["llm_prefill_flops"]),
+                        vit_flops=fl["vit_flops"], llm_prefill_flops=fl["llm_prefill_flops"], prefill_rows=fl["prefill_rows"], patches=fl["patches"],
+                        prefill_rows_per_launch_sequence=args.prefill_rows, frames_per_s_to_first_token=round(spg * args.frames / (ms1 * 1e-3), 1),
+                        decode_gate_up=roof)
     cpu = par = None
     want_cpu = (args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)) and not args.standin
     if want_cpu:
@@ -482,6 +564,10 @@ def main():
         tag = " (BASELINE.json configs[1])" if spg == 1 else (" (BASELINE.json configs[2])" if n_streams == 64 else "")
     if args.workload == "long480" and cfg.name == "livecc-7b":
         tag = " (BASELINE.json configs[3]: 24k visual tokens, KV to ~32k)"
+    if oneshot:
+        tag = " ONE-SHOT: the whole clip in one generate call (ref demo/infer.py:182-242 video_qa first turn; BASELINE.json configs[3])"
+    if oneshot:
+        tag = " ONE-SHOT: the whole clip in one generate call (ref demo/infer.py:182-242 video_qa first turn; BASELINE.json configs[3])"
     if cfg.name == "qwen2vl-72b" and fp8:
         tag = " (BASELINE.json configs[4])"
     out = {
@@ -491,7 +577,7 @@ def main():
         "dtype": "bf16 (fp8 e4m3 LLM weights, bf16 MFMA)" if fp8 else "bf16",
         "data": "standin (launcher self-test, no GPU work)" if args.standin else "synthetic frames + synthetic prompt ids, seeded synthetic weights of the real architecture",
         "config": {"workload": f"{cfg.name} {spg} stream(s) per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
-                               f"{args.max_new_tokens} tokens/turn, greedy, repetition_penalty 1.05" + tag,
+                               f"{args.max_new_tokens} tokens/{'call' if oneshot else 'turn'}, greedy, repetition_penalty 1.05" + tag,
                    "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)"},
         "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
         "weight_broadcast_s": round(bcast_max, 3), "rccl_ranks": world, "launcher": "self" if os.environ.get("LCC_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single"),

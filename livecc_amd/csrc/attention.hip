@@ -892,10 +892,11 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 // ------------------------------------------------------------------------------------------------
 static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
 // 0: per-wave kernels everywhere (operands straight from L2);  1: prefill = LDS-shared kernel + key split, ViT = per-wave
-// kernel;  2 (default): LDS-shared for both.  (With the per-tile DMA address math hoisted out of the key loop the shared ViT
+// kernel;  2 (default): LDS-shared for both;  3: 2 with the LLM prefill on 32-row tiles / 32x32x16 MFMAs (attn32.hip).  (With the per-tile DMA address math hoisted out of the key loop the shared ViT
 // kernel went from 75 us -- slower than the 64-us per-wave kernel -- to on par for one stream and +1.7 % end to end at 8.)
 static int g_attn_variant = 2;
 void set_attn_variant(int v) { g_attn_variant = v; }
+int get_attn_variant() { return g_attn_variant; }
 
 template <class Kern>
 static void set_lds_attr(Kern k, size_t bytes) {
@@ -944,6 +945,12 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
   // Default for prefill: the LDS-shared kernel (the G heads of a KV group fetch every K/V tile once: G x less L2/TA traffic,
   // which bounds the per-wave kernel at ~17 TB/s of 64-byte row segments) TOGETHER with the key split (which gives every SIMD
   // 2-3 waves for the dependent MFMA->softmax->MFMA chain).  g_attn_variant 0 forces the per-wave kernel.
+  if (g_attn_variant == 3 && tile_rows == 32 && G <= 8) {   // 32x32x16 MFMA kernel (attn32.hip)
+    if (int rc = attn_prefill32_launch(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, S, ws_o,
+                                       ws_ml, scale_l2e(128), st)) return rc;
+    if (S > 1) attn_prefill_combine_kernel<<<dim3(n_q_heads, n_rows), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads, S);
+    return 0;
+  }
   if (g_attn_variant != 0 && G >= 2 && G <= 8) {
     constexpr size_t lds = (size_t)4 * 16 * 1024;
     const dim3 grid(n_tiles, lay.n_kv_heads, S);

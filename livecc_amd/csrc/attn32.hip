@@ -1,0 +1,221 @@
+// LLM prefill attention, second generation: 32-row query tiles on the 32x32x16 bf16 MFMA, K/V tiles shared by the G query heads of
+// one KV head through an LDS-DMA ring.  Replaces HF modeling_qwen2_vl.py:537-556 (Qwen2VLAttention core: causal, bottom-right aligned,
+// GQA) for prefill rows, same contract as attn_shared_kernel<128, NQ, 1, G> in attention.hip (which stays as variant 2).
+//
+// Why (profiles/r03/pmc_attn_summary.json, 8 streams x 386 rows x 6k keys on attn_shared_kernel<128,1,1,7>): 25 % MFMA busy, 8.3 VALU
+// instructions per MFMA, 16 ds_read_b128 per 16 MFMAs of 16 cycles each -- per CU and 32-key tile the LDS reads (112 KB / 256 B/clk
+// = 437 clk), the MFMAs (448 clk) and the softmax VALU work cost about the same and only partly overlap: 0.54 PF.  One wave now owns
+// 32 query rows of one head:
+//   * S^T[32 keys][32 queries] = K . Q^T  is 8 MFMAs of 32 cycles (k = 16 each), O^T[128 d][32 queries] += V^T . P^T another 8: the
+//     same 16 ds_read_b128 per tile now feed 512 MFMA cycles instead of 256 -- LDS traffic per flop halves;
+//   * in the 32x32 C/D layout a lane owns ONE query column (l & 31) and 16 keys, so the row maximum / sum are 15 in-lane steps + ONE
+//     cross-lane step (xor 32) instead of 7 + 2 per 8 scores;
+//   * the K rows of a tile are fetched in a permuted order (bits 2 and 3 of the row index swapped), so that the 16 scores a lane
+//     ends up with are exactly the 2 x 8 consecutive keys its B-operand slots of the two P.V MFMAs need: P goes from the softmax
+//     registers into the MFMA with 8 v_cvt_pk and no cross-lane traffic at all.
+// Layouts (gfx950 v_mfma_f32_32x32x16_bf16): A lane l = A[i = l & 31][k = (l >> 5) * 8 + e]; B lane l = B[k = (l >> 5) * 8 + e][j = l & 31];
+// C/D lane l, r = 0..15: D[i = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3)][j = l & 31].
+// With key(i) = tile * 32 + swap23(i): score register r of lane-half hh holds key offset 16 * (r >> 3) + 8 * hh + (r & 7).
+#include "common.h"
+#include "kernels.h"
+
+namespace lcc {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+LCC_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+LCC_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+__device__ unsigned int lcc_attn32_zero_page[256];
+
+// grid = (query tiles, KV heads, key splits); NWAVE waves: wave w < G computes query head hk * G + w, every wave feeds the DMA ring.
+// Tile tables as attn_prefill_kernel: stream slot, first row in q, valid rows (<= 32), cache index of row 0.
+template <int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
+    const bf16_t* __restrict__ q, bf16_t* __restrict__ out, const int32_t* __restrict__ tile_stream,
+    const int32_t* __restrict__ tile_q0, const int32_t* __restrict__ tile_nq, const int32_t* __restrict__ tile_pos0,
+    bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int heads, float scale_log2e, int nsplit,
+    float* __restrict__ ws_o, float* __restrict__ ws_ml) {
+  constexpr int D = 128, KP = 8, VP = 8, NP = KP + VP, NSTAGE = 4, PW = (NP + NWAVE - 1) / NWAVE;
+  extern __shared__ __attribute__((aligned(16))) u32x4 alds[];      // NSTAGE x NP pieces of 1 KB in MFMA fragment (lane) order
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, hh = lane >> 5;
+  const int grp = blockIdx.x, hk = blockIdx.y, G = heads / lay.n_kv_heads;
+  const int h = min(hk * G + wave, heads - 1);
+  const bool active = wave < G;
+  const int strm = tile_stream[grp], q0 = tile_q0[grp], nq = tile_nq[grp], pos0 = tile_pos0[grp];
+  const bf16_t* base = kv_base[strm] + (size_t)layer * lay.layer_stride();
+  const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
+  const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
+  const int nkeys = pos0 + nq, ntile = (nkeys + 31) / 32;
+  const int per = (ntile + nsplit - 1) / nsplit;
+  const int tb = nsplit > 1 ? min(ntile, (int)blockIdx.z * per) : 0;
+  const int te = nsplit > 1 ? min(ntile, tb + per) : ntile;
+  const int ldq = heads * D;
+  const int qr = min(col, nq - 1);                       // this lane's query row inside the tile (clamped: surplus columns are not stored)
+  const int key_limit = pos0 + qr + 1;                   // causal, bottom-right aligned: keys 0 .. pos (inclusive)
+
+  // Q^T fragments (B operand of K . Q^T), resident for the whole key loop: Q[row qr][d = ks * 16 + hh * 8 .. + 8]
+  u32x4 qf[KP];
+  {
+    const bf16_t* qp = q + (size_t)(q0 + qr) * ldq + h * D + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) qf[ks] = ld16(qp + ks * 16);
+  }
+
+  // DMA sources of this wave's pieces for key tile 0 + per-tile strides (computed once: a DMA issue is one multiply-add per piece).
+  // The KV cache is allocated in whole 32-key tiles, so the rows of the last (partial) tile exist and are masked.
+  const bf16_t* pbase[PW];
+  size_t pstride[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int p = min(j * NWAVE + wave, NP - 1);         // surplus slots re-fetch the last piece (same bytes, same place)
+    if (p < KP) {                                        // K piece ks = p: rows in swap23 order, 16 d per lane-half pair
+      pbase[j] = kbase + (size_t)swap23(col) * D + p * 16 + hh * 8;
+      pstride[j] = (size_t)32 * D;
+    } else {                                             // V^T piece (dt, s): V^T[d = dt * 32 + col][keys s * 16 + hh * 8 .. + 8]
+      const int dt = (p - KP) >> 1, s = (p - KP) & 1;
+      pbase[j] = vbase + (size_t)(dt * 32 + col) * 32 + s * 16 + hh * 8;
+      pstride[j] = (size_t)D * 32;
+    }
+  }
+  auto issue = [&](int t) {
+    const int tc = min(t, ntile - 1);
+    u32x4* sbase = alds + ((t - tb) % NSTAGE) * (NP * 64);
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int p = min(j * NWAVE + wave, NP - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pbase[j] + (size_t)tc * pstride[j]),
+                                       (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  int min_limit = key_limit;                             // wave-wide minimum of the key limits: tiles entirely below it need no mask
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) min_limit = min(min_limit, __shfl_xor(min_limit, off, 64));
+
+  auto compute = [&](int t) {
+    const u32x4* s = alds + ((t - tb) % NSTAGE) * (NP * 64);
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) sc = mfma32(as_bf16x8(s[ks * 64 + lane]), as_bf16x8(qf[ks]), sc);
+    const int kb = t * 32;
+    float mx = -INFINITY;
+    if (kb + 32 > min_limit) {                           // wave-uniform: only the diagonal / last tiles pay for the mask
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb + 16 * (r >> 3) + 8 * hh + (r & 7);
+        const float v = key < key_limit ? sc[r] : -INFINITY;
+        sc[r] = v;
+        mx = fmaxf(mx, v);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_use);            // m_run = -inf -> 0
+    m_run = m_new;
+    float p[16], psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = exp2f(fmaf(sc[r], scale_log2e, -m_use));    // masked scores are -inf -> 0
+      psum += p[r];
+    }
+    l_run = l_run * alpha + psum;
+    // lazy rescale: once the running maximum has settled alpha is exactly 1.0 in every lane and the 64 accumulator multiplies are
+    // skipped (x * 1.0f is exact: bit-identical to always rescaling)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+      pb[ss] = as_bf16x8((u32x4){pack2(p[8 * ss + 0], p[8 * ss + 1]), pack2(p[8 * ss + 2], p[8 * ss + 3]),
+                                 pack2(p[8 * ss + 4], p[8 * ss + 5]), pack2(p[8 * ss + 6], p[8 * ss + 7])});
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(s[(KP + dt * 2 + ss) * 64 + lane]), pb[ss], o[dt]);
+  };
+
+  // Two key tiles per barrier (4-stage ring = two pair-stages): after the barrier of pair P its DMAs have landed and every wave is
+  // done with pair P-1, whose stages receive pair P+1 while both tiles of pair P are multiplied.
+  issue(tb); issue(tb + 1);
+  for (int t = tb; t < te; t += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(t + 2); issue(t + 3);
+    if (active) {
+      compute(t);
+      if (t + 1 < te) compute(t + 1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this block may land after it has left the CU
+  if (!active) return;
+
+  float l = l_run + __shfl_xor(l_run, 32, 64);
+  const bool valid = col < nq;
+  if (nsplit > 1) {      // partial (o, m, l) of this key split; attn_prefill_combine_kernel merges them
+    if (valid) {
+      const size_t slot = ((size_t)(q0 + col) * heads + h) * nsplit + blockIdx.z;
+      float* op = ws_o + slot * D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * r4 + 4 * hh) =
+              (f32x4){o[dt][4 * r4], o[dt][4 * r4 + 1], o[dt][4 * r4 + 2], o[dt][4 * r4 + 3]};
+      if (hh == 0) { ws_ml[slot * 2] = m_run; ws_ml[slot * 2 + 1] = l; }
+    }
+    return;
+  }
+  const float inv = 1.f / l;
+  if (valid) {
+    bf16_t* op = out + (size_t)(q0 + col) * ldq + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        st8(op + dt * 32 + 8 * r4 + 4 * hh, (u32x2){pack2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv),
+                                                   pack2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv)});
+  }
+}
+
+// launcher: 32-row tiles only; the caller (attention.hip: attn_prefill_bf16) runs the split merge
+int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
+                          const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,
+                          int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st) {
+  const int G = n_q_heads / lay.n_kv_heads;
+  if (G < 1 || G > 8 || lay.head_dim != 128) return LCC_ERR_SHAPE;
+  constexpr size_t lds = (size_t)4 * 16 * 1024;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  const dim3 grid(n_tiles, lay.n_kv_heads, nsplit > 1 ? nsplit : 1);
+  if (G <= 4)
+    attn_gqa32_kernel<4><<<grid, dim3(256), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
+                                                       scale_log2e, nsplit > 1 ? nsplit : 1, ws_o, ws_ml);
+  else
+    attn_gqa32_kernel<8><<<grid, dim3(512), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
+                                                       scale_log2e, nsplit > 1 ? nsplit : 1, ws_o, ws_ml);
+  return 0;
+}
+
+}  // namespace lcc

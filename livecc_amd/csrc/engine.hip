@@ -832,7 +832,9 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
   // 32-row tiles (NQ = 2) need ~200 VGPRs = one 7-wave block per CU; 16-row tiles run two blocks per CU.  Measured (8 streams x
   // 386 rows against 6k keys): 674 us with 16-row tiles vs 747 us with 32-row tiles, so the wide tile is kept for very large
   // prefills only (e.g. the 8 x 1114-row first turn), where the grid is several waves of blocks either way.
-  const int tile_rows = ((long)((S + 31) / 32) * e->c.n_q_heads >= 6144) ? 32 : 16;
+  // attention variant 3 (attn32.hip: 32x32x16 MFMAs, one wave = 32 rows of one head) always takes 32-row tiles.
+  const bool mfma32 = get_attn_variant() == 3 && e->c.n_q_heads / e->c.n_kv_heads <= 8;
+  const int tile_rows = (mfma32 || (long)((S + 31) / 32) * e->c.n_q_heads >= 6144) ? 32 : 16;
   int row = 0;
   for (int b = 0; b < n_streams; ++b) {
     const int past = e->h_kv_len[slots[b]];
@@ -873,6 +875,21 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
     int ks = (int)std::min<long>(8, 3072 / std::max<long>(waves, 1));
     ks = std::min(ks, (max_kv / 32) / 16);          // >= 16 key tiles per split
     cx.kv_split = (S <= 1024 && ks >= 2) ? ks : 1;
+    if (mfma32) {
+      // one 8-wave block per CU and (tile, KV head, split): choose the split count that fills whole rounds of the chip (blocks /
+      // (rounds * CUs)), slightly preferring fewer splits (every split writes and re-reads its fp32 partials)
+      int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+      const long base = (long)n_tiles * e->c.n_kv_heads;
+      const int ks_max = S <= 1024 ? std::max(1, std::min(8, (max_kv / 32) / 8)) : 1;    // >= 8 key tiles per split; workspace: S <= 1024
+      float best = -1.f; int best_ks = 1;
+      for (int k = 1; k <= ks_max; ++k) {
+        const long blocks = base * k, rounds = (blocks + cus - 1) / cus;
+        const float u = (float)blocks / (float)(rounds * cus) - 0.015f * (float)k;
+        if (u > best) { best = u; best_ks = k; }
+      }
+      static const int forced = [] { const char* v = getenv("LCC_ATTN32_SPLIT"); return v ? atoi(v) : 0; }();
+      cx.kv_split = forced > 0 ? std::min(forced, ks_max) : best_ks;
+    }
   }
   cx.slots = d_slots; cx.B = n_streams; cx.nsplit_attn = 1;
   LCC_TRY(run_layers(e, bf, cx, st));

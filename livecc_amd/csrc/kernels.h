@@ -85,6 +85,11 @@ int gather_rows_bf16(const bf16_t* in, const int32_t* rows, bf16_t* out, int n, 
 
 // ---- attention (attention.hip) ----
 void set_attn_variant(int v);
+int get_attn_variant();
+// LLM prefill attention on 32-row tiles / 32x32x16 MFMAs (attn32.hip); partials in the layout of attn_prefill_combine_kernel
+int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
+                          const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,
+                          int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st);
 // tile tables: 32-row query tiles (per-wave kernel); group tables: 128-row groups of one segment (LDS-shared kernel)
 int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* tile_seg, const int32_t* tile_q0,
                   const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,

@@ -98,10 +98,12 @@ def test_prefill_attention_long_cache_vs_fp32(dev, L, S):
     V = kv.v_view(0, 0)[:, :L].float().transpose(0, 1)
     ref = rb(_ref_attn_chunked(q.float().view(S, Hq, D), K, V, past))
     try:
-        for variant in (2, 1, 0):
+        for variant in (2, 3, 1, 0):
             ops.set_attn_variant(variant)
-            for tr, ns in ((16, 1), (16, 4), (32, 2), (16, 8), (32, 8)):
-                if variant != 2 and (tr, ns) not in ((16, 4), (32, 8)):
+            for tr, ns in ((16, 1), (16, 4), (32, 2), (16, 8), (32, 8), (32, 1), (32, 5)):
+                if variant == 3 and tr != 32:
+                    continue            # variant 3 = the 32-row / 32x32x16-MFMA kernel (attn32.hip)
+                if variant in (0, 1) and (tr, ns) not in ((16, 4), (32, 8)):
                     continue
                 got = ops.attn_prefill(q, kv, 0, [(0, S, past)], Hq, tile_rows=tr, nsplit=ns)
                 _check_attn(got.view(S, Hq, D), ref, f"attn_prefill_long[L{L},S{S},v{variant},rows{tr},split{ns}]")

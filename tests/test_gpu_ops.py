@@ -372,7 +372,7 @@ def _check_attn(got, ref, name, rel=0.02):
     assert (got - ref).abs().mean().item() <= 0.25 * rel * scale
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["attn_per_wave", "attn_prefill_shared", "attn_lds_shared_default"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["attn_per_wave", "attn_prefill_shared", "attn_lds_shared_default", "attn_prefill_mfma32"])
 def attn_variant(request):
     from livecc_amd import ops
     ops.set_attn_variant(request.param)

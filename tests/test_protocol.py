@@ -132,3 +132,81 @@ def test_model_constructors_pick_the_documented_text_offset_rule():
     assert inspect.signature(M.__init__).parameters["text_offset_rule"].default == "hf4"     # released checkpoints (4.5x training)
     src = inspect.getsource(M.from_hf_model)
     assert 'setdefault("text_offset_rule", "hf5")' in src                                    # oracle parity = the installed transformers
+
+
+def _hf45_get_rope_index(input_ids, video_grid_thw, cfg, image_grid_thw=()):
+    """INDEPENDENT restatement of transformers 4.5x `Qwen2VLForConditionalGeneration.get_rope_index` (the version the released LiveCC
+    checkpoints were trained with, ref README.md:30 'trained on transformers 4.50.0'), written from the published 4.5x algorithm --
+    the index-search structure of the original, not the run-length scan of `protocol.rope_index_first_turn`: every vision block is
+    located with `list.index`, the text before it continues at `previous block's max + 1`, the block's (t, h/merge, w/merge) meshgrid is
+    offset by `text_len + st_idx`, trailing text continues at max + 1, delta = max + 1 - len."""
+    m = cfg.spatial_merge_size
+    ids = np.asarray(input_ids).reshape(-1)
+    toks = ids.tolist()
+    starts = np.argwhere(ids == cfg.vision_start_token_id).reshape(-1)
+    vision_tokens = ids[starts + 1]
+    image_nums, video_nums = int((vision_tokens == cfg.image_token_id).sum()), int((vision_tokens == cfg.video_token_id).sum())
+    blocks, st, image_index, video_index = [], 0, 0, 0
+    remain_images, remain_videos = image_nums, video_nums
+    for _ in range(image_nums + video_nums):
+        ed_image = toks.index(cfg.image_token_id, st) if (cfg.image_token_id in toks and remain_images > 0) else len(toks) + 1
+        ed_video = toks.index(cfg.video_token_id, st) if (cfg.video_token_id in toks and remain_videos > 0) else len(toks) + 1
+        if ed_image < ed_video:
+            t, h, w = image_grid_thw[image_index]
+            image_index += 1; remain_images -= 1; ed = ed_image
+        else:
+            t, h, w = video_grid_thw[video_index]
+            video_index += 1; remain_videos -= 1; ed = ed_video
+        gt, gh, gw = int(t), int(h) // m, int(w) // m
+        text_len = ed - st
+        st_idx = int(blocks[-1].max()) + 1 if blocks else 0
+        blocks.append(np.broadcast_to(np.arange(text_len)[None, :], (3, text_len)) + st_idx)
+        t_index = np.repeat(np.arange(gt), gh * gw)
+        h_index = np.tile(np.repeat(np.arange(gh), gw), gt)
+        w_index = np.tile(np.arange(gw), gt * gh)
+        blocks.append(np.stack([t_index, h_index, w_index]) + text_len + st_idx)
+        st = ed + gt * gh * gw
+    if st < len(toks):
+        st_idx = int(blocks[-1].max()) + 1 if blocks else 0
+        n = len(toks) - st
+        blocks.append(np.broadcast_to(np.arange(n)[None, :], (3, n)) + st_idx)
+    pos = np.concatenate(blocks, axis=1)
+    return pos.astype(np.int64), int(pos.max()) + 1 - len(toks)
+
+
+def test_hf4_rule_against_an_independent_restatement_of_the_4_5x_algorithm():
+    """The product's "hf4" positions (`protocol.rope_index_first_turn`, the default of `from_pretrained`) against
+    `_hf45_get_rope_index` above on (a) the one-shot 480-frame video_qa / MCQ prompt (grid_t = 240 >> max(h, w) / 2: the case where
+    4.5x and 5.15 differ), (b) the TRAINING layout of ref data/lmm_dataset.py:177-183 -- the whole interleaved conversation in one
+    sequence, so every 6- / 2-frame chunk gets 3-D ids and advances the text position by max(t, h, w) only,
+    (c) random mixtures of video blocks and text."""
+    cfg = tiny()
+    rng = np.random.RandomState(5)
+
+    def seq(grids, text_lens):
+        ids = []
+        for g, n in zip(grids, text_lens):
+            ids += rng.randint(0, 1000, size=n).tolist()
+            ids += [cfg.vision_start_token_id] + [cfg.video_token_id] * protocol.num_video_tokens(g, cfg) + [cfg.vision_end_token_id]
+        ids += rng.randint(0, 1000, size=text_lens[-1]).tolist()
+        return np.asarray(ids, dtype=np.int64)
+    cases = [([(240, 20, 20)], [27, 34]),                                           # (a) one-shot 480 frames at 280x280
+             ([(3, 28, 52)] + [(1, 28, 52)] * 27, [27] + [22] * 27 + [5]),          # (b) the training layout of a 60-frame stream
+             ([(3, 4, 6), (1, 4, 6), (120, 2, 2), (1, 8, 2)], [5, 1, 9, 3, 2])]     # (c)
+    for _ in range(20):
+        k = int(rng.randint(1, 5))
+        cases.append(([(int(rng.randint(1, 40)), 2 * int(rng.randint(1, 8)), 2 * int(rng.randint(1, 8))) for _ in range(k)],
+                      [int(rng.randint(1, 30)) for _ in range(k + 1)]))
+    differ_from_hf5 = 0
+    for grids, text_lens in cases:
+        ids = seq(grids, text_lens)
+        want, dwant = _hf45_get_rope_index(ids, grids, cfg)
+        got, dgot = protocol.rope_index_first_turn(ids, grids, cfg, "hf4")
+        assert np.array_equal(got, want) and dgot == dwant, (grids, text_lens)
+        p5, _ = protocol.rope_index_first_turn(ids, grids, cfg, "hf5")
+        differ_from_hf5 += int(not np.array_equal(p5, want))
+    assert differ_from_hf5 >= 2, "the sweep must contain clips where the 4.5x and 5.15 text offsets differ"
+    # (b): every chunk of the training layout advances the running position by max(t, h/2, w/2) -- not by its token count
+    ids = seq(*cases[1])
+    pos, _ = protocol.rope_index_first_turn(ids, cases[1][0], cfg, "hf4")
+    assert int(pos.max()) + 1 < len(ids) // 4
