@@ -64,8 +64,8 @@ int lcc_debug_set_gemv_variant(int variant);
  * takes it when 256 < M <= 448 and ceil(N/160) fills 75-100 % of one round of the chip (LiveCC-7B gate/up of a streaming chunk) */
 int lcc_debug_set_gemm_variant(int variant);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
- * ViT per-wave; 2 = LDS-shared for both; 3 = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs (csrc/attn32.hip;
- * applies to calls with tile_rows = 32, the engine then always builds 32-row tiles) */
+ * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs
+ * (csrc/attn32.hip; applies to calls with tile_rows = 32, the engine then always builds 32-row tiles) */
 int lcc_debug_set_attn_variant(int variant);
 /* 1: on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add + RMSNorm) run as the
  * TAIL of that GEMV in its last-arriving block (agent-scope release/acquire); 0 (default, measured faster): separate kernels */

@@ -892,9 +892,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
 // ------------------------------------------------------------------------------------------------
 static inline float scale_l2e(int d) { return 1.4426950408889634f / sqrtf((float)d); }
 // 0: per-wave kernels everywhere (operands straight from L2);  1: prefill = LDS-shared kernel + key split, ViT = per-wave
-// kernel;  2 (default): LDS-shared for both;  3: 2 with the LLM prefill on 32-row tiles / 32x32x16 MFMAs (attn32.hip).  (With the per-tile DMA address math hoisted out of the key loop the shared ViT
+// kernel;  2: LDS-shared for both;  3 (default since round 3): 2 with the LLM prefill on 32-row tiles / 32x32x16 MFMAs (attn32.hip:
+// 373 vs 522 us at 8 x 386 rows x 6k keys, 1.36 vs 1.93 ms for a 4,096-row piece against 20k keys).  (With the per-tile DMA address math hoisted out of the key loop the shared ViT
 // kernel went from 75 us -- slower than the 64-us per-wave kernel -- to on par for one stream and +1.7 % end to end at 8.)
-static int g_attn_variant = 2;
+static int g_attn_variant = 3;
 void set_attn_variant(int v) { g_attn_variant = v; }
 int get_attn_variant() { return g_attn_variant; }
 

@@ -16,6 +16,8 @@
 // Layouts (gfx950 v_mfma_f32_32x32x16_bf16): A lane l = A[i = l & 31][k = (l >> 5) * 8 + e]; B lane l = B[k = (l >> 5) * 8 + e][j = l & 31];
 // C/D lane l, r = 0..15: D[i = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3)][j = l & 31].
 // With key(i) = tile * 32 + swap23(i): score register r of lane-half hh holds key offset 16 * (r >> 3) + 8 * hh + (r & 7).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -25,6 +27,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 LCC_DEVICE f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 LCC_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+LCC_DEVICE float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+LCC_DEVICE float vmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // hipcc emits v_max3_f32
+// max over the two lanes l and l ^ 32 with ONE v_permlane32_swap (instead of a ds_bpermute round trip through the LDS crossbar)
+LCC_DEVICE float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+LCC_DEVICE float xor32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 __device__ unsigned int lcc_attn32_zero_page[256];
 
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
     const int32_t* __restrict__ tile_q0, const int32_t* __restrict__ tile_nq, const int32_t* __restrict__ tile_pos0,
     bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int heads, float scale_log2e, int nsplit,
     float* __restrict__ ws_o, float* __restrict__ ws_ml) {
-  constexpr int D = 128, KP = 8, VP = 8, NP = KP + VP, NSTAGE = 4, PW = (NP + NWAVE - 1) / NWAVE;
+  constexpr int D = 128, KP = 8, VP = 8, NP = KP + VP, NSTAGE = 10, PW = (NP + NWAVE - 1) / NWAVE;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];      // NSTAGE x NP pieces of 1 KB in MFMA fragment (lane) order
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, hh = lane >> 5;
@@ -100,74 +113,123 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_limit = min(min_limit, __shfl_xor(min_limit, off, 64));
 
-  auto compute = [&](int t) {
-    const u32x4* s = alds + ((t - tb) % NSTAGE) * (NP * 64);
-    f32x16 sc;
+  // ---- software pipeline, one key tile per REGION: the softmax of tile t (vector pipe: ~70 VALU instructions) is issued next to 16
+  //      MFMAs (matrix pipe: 512 cycles) that do not depend on it -- the P . V of tile t-1 and the K . Q^T of tile t+1 -- in ONE
+  //      scheduling region, interleaved by sched_group_barrier.  A wave then always has matrix AND vector work in flight (with one
+  //      tile at a time per wave, the two waves of a SIMD ran the same phase in lock step behind the block barrier: the first version
+  //      of this kernel, 0.57 PF at 8 x 386 rows x 6k keys vs 0.54 for the 16x16x32 kernel).
+  auto stage_of = [&](int t) { return alds + ((t - tb) % NSTAGE) * (NP * 64); };
+  const int mlim = min(min_limit, te * 32);             // tiles reaching past it need the mask (causal diagonal / end of this split)
+  const int lim = min(key_limit, te * 32);              // this lane's effective key limit
+  bf16x8 p_prev[2];                                     // P of the previous tile, its P . V still pending
+  p_prev[0] = as_bf16x8((u32x4){0u, 0u, 0u, 0u});
+  p_prev[1] = p_prev[0];
+  const u32x4* v_prev = alds;                           // V stage of that tile (while nothing is pending P = 0: any landed stage will do)
+  f32x16 sc_a, sc_b;
+
+  auto region = [&](auto masked_tag, int t, f32x16& sc_cur, f32x16& sc_nxt) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const u32x4* vs = v_prev;
+    const u32x4* kn = stage_of(t + 1);
+    // matrix pipe: P.V of tile t-1 ...
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int ks = 0; ks < KP; ++ks) sc = mfma32(as_bf16x8(s[ks * 64 + lane]), as_bf16x8(qf[ks]), sc);
+      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(vs[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
+    // ... and K.Q^T of tile t+1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc_nxt[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) sc_nxt = mfma32(as_bf16x8(kn[ks * 64 + lane]), as_bf16x8(qf[ks]), sc_nxt);
+    // vector pipe: softmax of tile t
     const int kb = t * 32;
-    float mx = -INFINITY;
-    if (kb + 32 > min_limit) {                           // wave-uniform: only the diagonal / last tiles pay for the mask
+    if (MASKED) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb + 16 * (r >> 3) + 8 * hh + (r & 7);
-        const float v = key < key_limit ? sc[r] : -INFINITY;
-        sc[r] = v;
-        mx = fmaxf(mx, v);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+      for (int r = 0; r < 16; ++r) sc_cur[r] = (kb + 16 * (r >> 3) + 8 * hh + (r & 7)) < lim ? sc_cur[r] : -INFINITY;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    float mx = vmax3(sc_cur[0], sc_cur[1], sc_cur[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = vmax3(mx, sc_cur[r], sc_cur[r + 1]);
+    mx = vmax(mx, sc_cur[15]);
+    mx = xor32_max(mx);
+    const float m_new = vmax(m_run, mx * scale_log2e);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);            // m_run = -inf -> 0
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);       // m_run = -inf -> 0
     m_run = m_new;
     float p[16], psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = exp2f(fmaf(sc[r], scale_log2e, -m_use));    // masked scores are -inf -> 0
+      p[r] = __builtin_amdgcn_exp2f(fmaf(sc_cur[r], scale_log2e, -m_use));   // masked scores are -inf -> 0
       psum += p[r];
     }
     l_run = l_run * alpha + psum;
-    // lazy rescale: once the running maximum has settled alpha is exactly 1.0 in every lane and the 64 accumulator multiplies are
-    // skipped (x * 1.0f is exact: bit-identical to always rescaling)
+    bf16x8 pn[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+      pn[ss] = as_bf16x8((u32x4){pack2(p[8 * ss + 0], p[8 * ss + 1]), pack2(p[8 * ss + 2], p[8 * ss + 3]),
+                                 pack2(p[8 * ss + 4], p[8 * ss + 5]), pack2(p[8 * ss + 6], p[8 * ss + 7])});
+    // keep the exponentials and the packing of P INSIDE this region: P is only consumed by the next region's MFMAs, and LLVM otherwise
+    // sinks its computation behind the rescale branch below, where no matrix work is left to hide it
+    {
+      u32x4 w0 = as_u32x4(pn[0]), w1 = as_u32x4(pn[1]);
+      asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(l_run));
+      pn[0] = as_bf16x8(w0); pn[1] = as_bf16x8(w1);
+    }
+    // issue order: a few fragment reads ahead, then per MFMA one more read and a handful of vector instructions
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < 13) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, MASKED ? 7 : 5, 0);
+    }
+    // region boundary: the accumulators now hold tiles <= t-1 at the OLD maximum; bring them to the new one before tile t's P.V.
+    // Lazy: once the running maximum has settled alpha is exactly 1.0 in every lane and the 64 multiplies are skipped (x * 1.0f is
+    // exact: bit-identical to always rescaling)
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
-    bf16x8 pb[2];
+    p_prev[0] = pn[0]; p_prev[1] = pn[1];
+    v_prev = stage_of(t);
+  };
+
+  // Ring of NSTAGE = 10 tile stages = five pair-stages (160 KB: the whole LDS of the CU; the register budget allows one block per
+  // CU anyway).  At the top of the iteration of pair P = (t, t+1): pairs P-1 (its second tile still owes its P.V), P and P+1 have
+  // landed (counted vmcnt: only pair P+2, issued one iteration ago, may still be in flight; barrier: every wave's pieces), every
+  // wave is done with pair P-2, whose stages receive pair P+3 -- every DMA has TWO iterations to land (with one iteration of lead
+  // the loop ran at the DMA round trip: 2.2 us per pair at 8 x 386 rows x 6k keys against 1 us of MFMA work).
+  // The iteration enters with sc_a = K.Q^T of tile t and leaves with sc_a = K.Q^T of tile t+2.
+  issue(tb); issue(tb + 1); issue(tb + 2); issue(tb + 3); issue(tb + 4); issue(tb + 5);
+  for (int t = tb; t < te; t += 2) {
+    if (PW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(t + 6); issue(t + 7);
+    if (!active) continue;
+    if (t == tb) {
+      const u32x4* k0 = stage_of(tb);
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss)
-      pb[ss] = as_bf16x8((u32x4){pack2(p[8 * ss + 0], p[8 * ss + 1]), pack2(p[8 * ss + 2], p[8 * ss + 3]),
-                                 pack2(p[8 * ss + 4], p[8 * ss + 5]), pack2(p[8 * ss + 6], p[8 * ss + 7])});
+      for (int r = 0; r < 16; ++r) sc_a[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KP; ++ks) sc_a = mfma32(as_bf16x8(k0[ks * 64 + lane]), as_bf16x8(qf[ks]), sc_a);
+    }
+    if ((t + 1) * 32 > mlim) region(std::true_type{}, t, sc_a, sc_b); else region(std::false_type{}, t, sc_a, sc_b);
+    if ((t + 2) * 32 > mlim) region(std::true_type{}, t + 1, sc_b, sc_a); else region(std::false_type{}, t + 1, sc_b, sc_a);
+  }
+  if (active && te > tb) {     // the last tile's P.V (an empty key range never filled the ring: nothing to flush, and 0 x garbage = NaN)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(s[(KP + dt * 2 + ss) * 64 + lane]), pb[ss], o[dt]);
-  };
-
-  // Two key tiles per barrier (4-stage ring = two pair-stages): after the barrier of pair P its DMAs have landed and every wave is
-  // done with pair P-1, whose stages receive pair P+1 while both tiles of pair P are multiplied.
-  issue(tb); issue(tb + 1);
-  for (int t = tb; t < te; t += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(t + 2); issue(t + 3);
-    if (active) {
-      compute(t);
-      if (t + 1 < te) compute(t + 1);
-    }
+      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(v_prev[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this block may land after it has left the CU
   if (!active) return;
 
-  float l = l_run + __shfl_xor(l_run, 32, 64);
+  float l = xor32_sum(l_run);
   const bool valid = col < nq;
   if (nsplit > 1) {      // partial (o, m, l) of this key split; attn_prefill_combine_kernel merges them
     if (valid) {
@@ -201,7 +263,7 @@ int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stre
                           int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st) {
   const int G = n_q_heads / lay.n_kv_heads;
   if (G < 1 || G > 8 || lay.head_dim != 128) return LCC_ERR_SHAPE;
-  constexpr size_t lds = (size_t)4 * 16 * 1024;
+  constexpr size_t lds = (size_t)10 * 16 * 1024;
   static bool once = false;
   if (!once) {
     (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -876,11 +876,13 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
     ks = std::min(ks, (max_kv / 32) / 16);          // >= 16 key tiles per split
     cx.kv_split = (S <= 1024 && ks >= 2) ? ks : 1;
     if (mfma32) {
-      // one 8-wave block per CU and (tile, KV head, split): choose the split count that fills whole rounds of the chip (blocks /
-      // (rounds * CUs)), slightly preferring fewer splits (every split writes and re-reads its fp32 partials)
+      // one 8-wave block per CU and (tile, KV head, split).  Measured (tools/bench_attn.py, profiles/r03/attn_prefill_microbench.jsonl):
+      // a split costs its fp32 partials twice (write + combine launch: 3,088 rows x 28 heads x 3 splits = 137 MB, 415 vs 373 us at 8
+      // streams), so keys are split only while the unsplit grid cannot fill ONE round of the chip (one stream's chunk: 52 blocks ->
+      // 4 splits, 68 vs 177 us); then the split count that fills whole rounds best, slightly preferring fewer splits.
       int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
       const long base = (long)n_tiles * e->c.n_kv_heads;
-      const int ks_max = S <= 1024 ? std::max(1, std::min(8, (max_kv / 32) / 8)) : 1;    // >= 8 key tiles per split; workspace: S <= 1024
+      const int ks_max = (S <= 1024 && base < cus) ? std::max(1, std::min(8, (max_kv / 32) / 8)) : 1;   // >= 8 key tiles per split
       float best = -1.f; int best_ks = 1;
       for (int k = 1; k <= ks_max; ++k) {
         const long blocks = base * k, rounds = (blocks + cus - 1) / cus;
@@ -888,7 +890,7 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
         if (u > best) { best = u; best_ks = k; }
       }
       static const int forced = [] { const char* v = getenv("LCC_ATTN32_SPLIT"); return v ? atoi(v) : 0; }();
-      cx.kv_split = forced > 0 ? std::min(forced, ks_max) : best_ks;
+      cx.kv_split = forced > 0 ? std::min(forced, std::max(1, std::min(8, (max_kv / 32) / 8))) : best_ks;
     }
   }
   cx.slots = d_slots; cx.B = n_streams; cx.nsplit_attn = 1;

@@ -104,7 +104,7 @@ def set_gemv_variant(v: int) -> None:
 
 
 GEMM_DEFAULT_VARIANT = 2
-ATTN_DEFAULT_VARIANT = 2
+ATTN_DEFAULT_VARIANT = 3
 
 
 def set_attn_variant(v: int) -> None:
