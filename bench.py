@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--attn-variant", type=int, default=None, help="debug A/B: lcc_debug_set_attn_variant")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--decode-path", type=int, default=None, help="debug A/B: lcc_debug_set_decode_path")
+    ap.add_argument("--fused-attn", type=int, default=None, help="debug A/B: lcc_debug_set_fused_attn (bit 0 fused decode attention for "
+                                                                  ">= 16 (stream, KV head) pairs, bit 2 always, bit 1 in-launch split merge)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: do not overlap the next turn's vision tower with this turn's decode steps")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
@@ -409,6 +411,8 @@ def main():
             ops.set_attn_variant(args.attn_variant)
         if args.gemv_variant is not None:
             ops.set_gemv_variant(args.gemv_variant)
+        if args.fused_attn is not None:
+            _lib.load().lcc_debug_set_fused_attn(args.fused_attn)
         if args.decode_path is not None:
             _lib.check(_lib.load().lcc_debug_set_decode_path(args.decode_path), "lcc_debug_set_decode_path")
         if args.workload == "oneshot480":

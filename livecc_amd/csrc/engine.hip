@@ -698,7 +698,8 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
     g.epilogue = LCC_EPI_SWIGLU;
     // one sampled launch per decode step (the middle layer): an event pair opens a ~6 us bubble on the stream on each side, which
     // at 28 pairs per step was 8 % of the round-1 step time
-    const bool prof = e->prof_on && cx.skinny && cx.tok_pos == nullptr && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
+    // (decode steps of every batch size: the 17-64-stream path through the GEMM tiles is sampled too)
+    const bool prof = e->prof_on && cx.tok_pos == nullptr && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();
     if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
     LCC_TRY(gemm_bf16(g, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }

@@ -17,6 +17,8 @@ q = (torch.randn(B * S, Hq * 128, device=dev) * 0.7).to(torch.bfloat16)
 segs = [(b, S, L) for b in range(B)]
 nsplit = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 tile_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+if len(sys.argv) > 3:
+    ops.set_attn_variant(int(sys.argv[3]))      # 2 = attn_shared_kernel (16x16x32 MFMAs), 3 = attn_gqa32_kernel (32x32x16, attn32.hip)
 for i in range(4):
     out = ops.attn_prefill(q, kv, 0, segs, Hq, tile_rows=tile_rows, nsplit=nsplit)
 torch.cuda.synchronize()

@@ -25,7 +25,11 @@ def load(path):
         for r in csv.DictReader(f):
             if r.get("Kind", "KERNEL_DISPATCH") != "KERNEL_DISPATCH":
                 continue
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "0")))
+            name = short(r["Kernel_Name"])
+            if name.startswith("gemm_") and "Grid_Size_X" in r:      # the same GEMM template serves several shapes: tell them apart by grid
+                wx, wy = max(1, int(r.get("Workgroup_Size_X", 1))), max(1, int(r.get("Workgroup_Size_Y", 1)))
+                name += f" grid=({int(r['Grid_Size_X']) // wx},{int(r.get('Grid_Size_Y', 1)) // wy},{r.get('Grid_Size_Z', 1)})"
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "0")))
     rows.sort()
     return rows
 
