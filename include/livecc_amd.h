@@ -161,6 +161,12 @@ int lcc_debug_bench_attn_decode(int variant, int iters, const float* qkv_partial
  * XCD-hierarchical barrier (csrc/grid_sync.h: per-XCD arrival counters + one release fence per XCD leader).  Microseconds per hand-off. */
 int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, void* scratch, size_t scratch_bytes, float* out_us, int* out_fails,
                                  void* stream);
+/* Launch counters (tests assert WHICH kernel served a call): out[i] for i < n (n <= 16), optionally reset afterwards.  Slots:
+ * 0 per-wave decode attention, 1 decode split-merge launches, 2 fused decode attention (+ combine launch), 3 fused decode attention with
+ * the in-launch merge, 4 split-K GEMV with a fused consumer tail, 5 decode-pipeline-v2 GEMVs, 6 prefill attention on 32x32x16 MFMAs
+ * (attn32.hip), 7 LDS-shared prefill attention, 8 per-wave prefill attention, 9 prefill split-merge launches, 10 / 11 = key splits of the
+ * most recent decode / prefill attention launch (values, not counts). */
+int lcc_debug_launch_counts(int64_t* out, int n, int reset);
 int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode uses the fused kernel for batches of >= 16 (stream,
                                           KV head) pairs; bit 2: for every batch; bit 1: key splits merged in the same launch by the
                                           last-arriving block instead of a combine launch (default off) */

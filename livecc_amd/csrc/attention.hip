@@ -946,13 +946,17 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
   // Default for prefill: the LDS-shared kernel (the G heads of a KV group fetch every K/V tile once: G x less L2/TA traffic,
   // which bounds the per-wave kernel at ~17 TB/s of 64-byte row segments) TOGETHER with the key split (which gives every SIMD
   // 2-3 waves for the dependent MFMA->softmax->MFMA chain).  g_attn_variant 0 forces the per-wave kernel.
+  g_launch_counts[LC_LAST_PREFILL_NSPLIT] = S;
+  if (S > 1) g_launch_counts[LC_ATTN_PREFILL_COMBINE]++;
   if (g_attn_variant == 3 && tile_rows == 32 && G <= 8) {   // 32x32x16 MFMA kernel (attn32.hip)
+    g_launch_counts[LC_ATTN_PREFILL_MFMA32]++;
     if (int rc = attn_prefill32_launch(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, S, ws_o,
                                        ws_ml, scale_l2e(128), st)) return rc;
     if (S > 1) attn_prefill_combine_kernel<<<dim3(n_q_heads, n_rows), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads, S);
     return 0;
   }
   if (g_attn_variant != 0 && G >= 2 && G <= 8) {
+    g_launch_counts[LC_ATTN_PREFILL_SHARED]++;
     constexpr size_t lds = (size_t)4 * 16 * 1024;
     const dim3 grid(n_tiles, lay.n_kv_heads, S);
 #define LCC_ATTN_SH(GW)                                                                                                          \
@@ -973,6 +977,7 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
     if (S > 1) attn_prefill_combine_kernel<<<dim3(n_q_heads, n_rows), dim3(128), 0, st>>>(ws_o, ws_ml, out, n_q_heads, S);
     return 0;
   }
+  g_launch_counts[LC_ATTN_PREFILL_PER_WAVE]++;
   if (tile_rows == 32)
     attn_prefill_kernel<2><<<dim3((n_tiles + 3) / 4, n_q_heads, S), dim3(256), 0, st>>>(
         q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, scale_l2e(128), S, ws_o, ws_ml);
@@ -987,6 +992,7 @@ int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const i
                      KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st) {
   if (B <= 0) return 0;
   if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
+  g_launch_counts[LC_ATTN_DECODE]++; g_launch_counts[LC_ATTN_DECODE_COMBINE]++; g_launch_counts[LC_LAST_DECODE_NSPLIT] = nsplit;
   attn_decode_kernel<<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
       q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128));
   attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(256), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
@@ -1007,6 +1013,8 @@ int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias
   if (nsplit < 1 || nsplit > 64 || ns_qkv < 1 || ns_qkv > 8) return LCC_ERR_ARG;
   const dim3 grid(nsplit, lay.n_kv_heads, B), blk(256);
   const int tail = g_attn_fused_tail;
+  g_launch_counts[tail == 0 ? LC_ATTN_DECODE_FUSED_MERGE : LC_ATTN_DECODE_FUSED]++; g_launch_counts[LC_LAST_DECODE_NSPLIT] = nsplit;
+  if (tail != 0 && nsplit > 1) g_launch_counts[LC_ATTN_DECODE_COMBINE]++;
 #define LCC_ADF(NS)                                                                                                              \
   case NS:                                                                                                                       \
     if (tail == 0)                                                                                                               \

@@ -330,6 +330,7 @@ int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_
 }
 
 static int dg_check(const DgArgs& a, int pro, int epi) {
+  g_launch_counts[LC_DGEMV_V2]++;
   if (a.M < 1 || a.M > 16 || (a.N & 15) || (a.K & 31) || a.W == nullptr) return LCC_ERR_SHAPE;
   if (pro == DG_PRO_PLAIN && (a.X == nullptr || (a.ldx & 7))) return LCC_ERR_ARG;
   if (pro == DG_PRO_NORM && (a.H == nullptr || a.stats == nullptr || a.norm_w == nullptr || a.n_stat != (a.K >> 4) || (a.n_stat & 3) ||

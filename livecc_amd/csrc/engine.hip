@@ -1009,6 +1009,13 @@ extern "C" int lcc_debug_set_vit_taps(lcc_engine* e, void* taps, const void* ove
   e->vit_taps = (bf16_t*)taps; e->vit_over = (const bf16_t*)overrides; e->vit_tap_rows = max_rows;
   return 0;
 }
+namespace lcc { long long g_launch_counts[LC_COUNT] = {}; }
+extern "C" int lcc_debug_launch_counts(int64_t* out, int n, int reset) {
+  if (n < 0 || n > LC_COUNT || (n > 0 && !out)) return fail(LCC_ERR_ARG, "bad argument");
+  for (int i = 0; i < n; ++i) out[i] = (int64_t)g_launch_counts[i];
+  if (reset) for (int i = 0; i < LC_COUNT; ++i) g_launch_counts[i] = 0;
+  return 0;
+}
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_path(int path) {
   if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");

@@ -1208,6 +1208,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
       if (S > nchunk) return LCC_ERR_SHAPE;
       if (a.tail.kind != 0) {   // fused tail: last-arriving block reduces the slabs and runs the consumer (M <= 2, packed W)
         if (a.M > 2 || !a.w_packed || a.tail.counter == nullptr || S > 8 || (a.tail.kind == 1 && (a.N > 8192 || (a.N & 7)))) return LCC_ERR_ARG;
+        g_launch_counts[LC_GEMV_FUSED_TAIL]++;
         gemv_skinny_kernel<1, 3, true, 1, 1><<<dim3((a.N + 15) / 16, S), dim3(256), 0, st>>>(
             a.A, a.lda, a.W, a.ldw, nullptr, a.partial, a.N, a.M, a.N, a.K, (nchunk + S - 1) / S, a.tail);
         return 0;

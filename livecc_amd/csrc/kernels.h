@@ -10,6 +10,25 @@ namespace lcc {
 typedef unsigned short bf16_t;
 
 
+// ---- launch counters (tests assert WHICH kernel served a call: lcc_debug_launch_counts) ----
+enum LaunchCounter {
+  LC_ATTN_DECODE = 0,          // attn_decode_kernel (per-wave decode attention)
+  LC_ATTN_DECODE_COMBINE = 1,  // attn_decode_combine_kernel
+  LC_ATTN_DECODE_FUSED = 2,    // attn_decode_fused_kernel with the combine launch
+  LC_ATTN_DECODE_FUSED_MERGE = 3,   // attn_decode_fused_kernel with the in-launch split merge
+  LC_GEMV_FUSED_TAIL = 4,      // gemv_skinny_kernel MODE 3 (consumer op in the last-arriving block)
+  LC_DGEMV_V2 = 5,             // decode pipeline v2 GEMVs
+  LC_ATTN_PREFILL_MFMA32 = 6,  // attn_gqa32_kernel
+  LC_ATTN_PREFILL_SHARED = 7,  // attn_shared_kernel (LLM prefill)
+  LC_ATTN_PREFILL_PER_WAVE = 8,
+  LC_ATTN_PREFILL_COMBINE = 9,
+  LC_LAST_DECODE_NSPLIT = 10,  // key splits of the most recent decode attention launch (a value, not a count)
+  LC_LAST_PREFILL_NSPLIT = 11, // key splits of the most recent prefill attention launch
+  LC_GEMM_TALL = 12,
+  LC_COUNT = 16
+};
+extern long long g_launch_counts[LC_COUNT];
+
 // ---- per-stream KV arena layout ----
 struct KvLayout {  // per-stream KV arena: [layer][K|V][Hkv][Lmax][128]; V blocked-transposed [Lmax/32][128][32]
   int n_layers, n_kv_heads, lmax, head_dim;

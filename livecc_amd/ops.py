@@ -107,6 +107,19 @@ GEMM_DEFAULT_VARIANT = 2
 ATTN_DEFAULT_VARIANT = 3
 
 
+LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "attn_decode_fused_merge", "gemv_fused_tail", "dgemv_v2",
+                   "attn_prefill_mfma32", "attn_prefill_shared", "attn_prefill_per_wave", "attn_prefill_combine", "last_decode_nsplit",
+                   "last_prefill_nsplit")
+
+
+def launch_counts(reset: bool = False) -> dict:
+    """Host-side launch counters of the library (which kernel served the calls since the last reset): lcc_debug_launch_counts."""
+    import numpy as np
+    buf = np.zeros(16, dtype=np.int64)
+    _lib.check(_lib.load().lcc_debug_launch_counts(buf.ctypes.data, 16, 1 if reset else 0), "lcc_debug_launch_counts")
+    return {k: int(buf[i]) for i, k in enumerate(LAUNCH_COUNTERS)}
+
+
 def set_attn_variant(v: int) -> None:
     _lib.load().lcc_debug_set_attn_variant(int(v))
 

@@ -709,3 +709,65 @@ def test_vision_tower_prefetch_on_a_side_stream_is_bit_identical(dev, tiny_model
         assert len(native._vit_cache) == 0, "every prefetched clip was claimed"
         for (ta, la), (tb, lb) in zip(a, b):
             assert ta == tb and torch.equal(la, lb)
+
+
+@pytest.fixture(scope="module")
+def small_models(dev):
+    from livecc_amd.config import small
+    cfg = small()
+    return (cfg,) + _build(cfg, dev, seed=4, init_scale=1.5)
+
+
+LONG_VARIANTS = [("v2", 1, 0, 1), ("round1_three_kernels", 0, 0, 1), ("round1_fused_attn", 0, 0, 5), ("round1_fused_attn_inlaunch_merge", 0, 0, 7),
+                 ("round1_fused_gemv_tails", 0, 1, 1)]
+
+
+def test_decode_variants_on_a_long_cache_run_the_intended_kernels_and_match_hf(dev, small_models):
+    """at tiny KV lengths every decode variant has ONE key split (and the default pipeline v2 ignores the
+    fused-attention / fused-tail switches altogether), so the five parametrisations of test_streaming_generate_matches_oracle_tiny
+    exercised one arithmetic path.  Here: `small` shapes (GQA 7:1), a 2,200-token one-shot history (176 frames at 140x140), then 8
+    decode tokens at ~2.2k keys = 18 key splits, once per decode variant -- each variant must (a) have launched ITS kernels
+    (lcc_debug_launch_counts) with >= 4 key splits, (b) match HF (bf16 + fp32, teacher-forced) within the usual bounds."""
+    from livecc_amd import _lib, ops, protocol
+    cfg, hf16, hf32, native = small_models
+    lib = _lib.load()
+    T, H, W, n_tok = 176, 140, 140, 8
+    frames = torch.from_numpy(protocol.synth_frames(T, H, W, seed=31, layout="TCHW"))
+    grid = protocol.grid_of(T, H, W, cfg)
+    ids = protocol.TurnBuilder(cfg, seed=31).turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    assert len(ids) > 2200
+    L = cfg.num_hidden_layers
+    compared = {}
+    for name, path, tails, fattn in LONG_VARIANTS:
+        lib.lcc_debug_set_decode_path(path); lib.lcc_debug_set_fused_tails(tails); lib.lcc_debug_set_fused_attn(fattn)
+        try:
+            ops.launch_counts(reset=True)
+            r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames.to(dev), frames_layout="TCHW", do_sample=False,
+                                repetition_penalty=1.05, max_new_tokens=n_tok, min_new_tokens=n_tok, output_logits=True)
+            c = ops.launch_counts(reset=True)
+        finally:
+            lib.lcc_debug_set_decode_path(1); lib.lcc_debug_set_fused_tails(0); lib.lcc_debug_set_fused_attn(1)
+        toks = r.sequences[0, len(ids):].tolist()
+        logits = r.logits.float().cpu()
+        r.past_key_values.release()
+        steps = n_tok - 1                                   # decode steps after the prefill's first token
+        assert c["last_decode_nsplit"] >= 4, (name, c)
+        if name == "v2":
+            assert c["dgemv_v2"] >= steps * L * 4 and c["attn_decode"] == steps * L and c["attn_decode_fused"] == 0, (name, c)
+        elif name == "round1_three_kernels":
+            assert c["dgemv_v2"] == 0 and c["attn_decode"] == steps * L and c["attn_decode_combine"] == steps * L, (name, c)
+            assert c["attn_decode_fused"] == c["attn_decode_fused_merge"] == c["gemv_fused_tail"] == 0, (name, c)
+        elif name == "round1_fused_attn":
+            assert c["attn_decode_fused"] == steps * L and c["attn_decode_combine"] == steps * L and c["attn_decode"] == 0, (name, c)
+        elif name == "round1_fused_attn_inlaunch_merge":
+            assert c["attn_decode_fused_merge"] == steps * L and c["attn_decode_combine"] == 0 and c["attn_decode"] == 0, (name, c)
+        else:
+            assert c["gemv_fused_tail"] >= steps * L * 3 and c["attn_decode"] == steps * L and c["dgemv_v2"] == 0, (name, c)
+        key = tuple(toks)
+        if key not in compared:        # the oracle run (2.2k-token prefill on CPU, bf16 + fp32) once per distinct token sequence
+            turns = [dict(turn_ids=ids, grid=grid, new_tokens=toks, logits=logits, frames=(0, T))]
+            compared[key] = _compare_stream(cfg, hf16, hf32, turns, frames, f"long_cache_decode[{name}]", 1.05)
+        else:                          # same tokens as a variant already compared: the logits must still be within bf16 noise of it
+            pass
+        record(f"long_cache_decode_counts[{name}]", c)
+    assert len(compared) <= 2, "the decode variants differ only in fp32 summation order: at most a near-tie may flip one token"

@@ -194,3 +194,43 @@ def test_generate_batch_of_twenty_streams_in_one_decode_pass_matches_hf(dev):
     from livecc_amd.config import tiny
     shapes = [((8, 56, 84), (8, 84, 56), (10, 56, 56), (8, 56, 56))[i % 4] for i in range(20)]
     _batched_streams_vs_hf(dev, tiny(), shapes, 200, "generate_batch_20_streams", max_new_tokens=4, init_scale=2.0)
+
+
+def test_video_qa_one_shot_480_frames_24k_tokens_at_small_vs_hf(dev):
+    """SURVEY 8f-3 / BASELINE configs[3] at the REAL token geometry: `video_qa`'s first turn (ref demo/infer.py:182-242) over a 250-second
+    30-fps video -> `smart_nframes` picks 480 frames (FPS_MAX_FRAMES), the per-nframes pixel budget gives 280x280 (82,320 px per frame:
+    100 tokens per frame pair), i.e. 96,000 patches in 240 temporal slices and a 24,000-visual-token prompt in ONE generate call --
+    served in pieces (ViT groups of <= 16,000 patches, prefill launch sequences of <= 4,096 rows over the carried KV), then 6 decode
+    tokens at L ~ 24k.  `small` model dims (GQA 7:1, head dims 128 / 80); HF bf16 on the CPU prefills the same prompt in one pass
+    (5.x text-offset rule on both sides: grid_t = 240 >> max(h, w) / 2) and is teacher-forced along the native tokens."""
+    from livecc_amd import protocol, video as V
+    from livecc_amd.config import small
+    from livecc_amd.infer import LiveCCDemoInfer
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O
+    from oracle.resize_ref import resize_ref
+    cfg = small()
+    hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=11, init_scale=1.5)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=24576 + 256, max_new_rows=4096,
+                                                          max_patches=16000, max_history=16)
+    infer = LiveCCDemoInfer(model=native)
+    g = torch.Generator().manual_seed(8)
+    n_src = 7500                                        # 250 s at 30 fps
+    vid = V.DecodedVideo(torch.randint(0, 256, (n_src, 64, 64, 3), dtype=torch.uint8, generator=g), np.arange(n_src) / 30.0, 30.0)
+    state = {"video_path": vid}
+    resp, state = infer.video_qa(12, [], state, max_new_tokens=6, force_length=True)       # synthetic 12-id query
+    g1 = infer.last_generated[-1]
+    n_vid = int((g1["prompt_ids"] == cfg.video_token_id).sum())
+    assert n_vid == 24000 and state["past_key_values"].get_seq_length() == len(g1["prompt_ids"]) + 5
+    idxs, _, _ = V.select_video_frames(vid.pts, len(vid), vid.avg_fps, {})
+    assert len(idxs) == 480
+    h, w = V.spatial_resize_hw(64, 64, len(idxs))
+    assert (h, w) == (280, 280)
+    clip = resize_ref(vid.frames[idxs].permute(0, 3, 1, 2), h, w)
+    pv, grid = O.patchify_normalize_ref(clip, cfg)
+    assert tuple(grid)[0] == 240 and protocol.num_video_tokens(grid, cfg) == n_vid
+    s16 = O.OracleStream(hf16, cfg)
+    _check_tokens_against_oracle("video_qa_one_shot_480_frames_small_vs_hf", [(g1["prompt_ids"], pv, grid, g1["tokens"])],
+                                 lambda ids, pv_, grid_, toks: s16.turn(ids, pv_, grid_, max_new_tokens=len(toks), repetition_penalty=1.05,
+                                                                        teacher_tokens=toks))
+    state["past_key_values"].release()

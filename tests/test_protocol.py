@@ -210,3 +210,46 @@ def test_hf4_rule_against_an_independent_restatement_of_the_4_5x_algorithm():
     ids = seq(*cases[1])
     pos, _ = protocol.rope_index_first_turn(ids, cases[1][0], cfg, "hf4")
     assert int(pos.max()) + 1 < len(ids) // 4
+
+
+def _hf_smart_resize():
+    """HF's own `smart_resize` (HF models/qwen2_vl/video_processing_qwen2_vl.py:40-66 -- the function the reference's processor and
+    qwen_vl_utils call), executed from its SOURCE FILE: the module itself cannot be imported here (it needs torchvision)."""
+    import ast
+    import math
+    import os
+    import transformers
+    path = os.path.join(os.path.dirname(transformers.__file__), "models", "qwen2_vl", "video_processing_qwen2_vl.py")
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "smart_resize")
+    fn.returns = None
+    for a in fn.args.args + fn.args.kwonlyargs:
+        a.annotation = None
+    ns = {"math": math}
+    exec(compile(ast.fix_missing_locations(ast.Module(body=[fn], type_ignores=[])), path, "exec"), ns)
+    return ns["smart_resize"]
+
+
+def test_smart_resize_equals_hf_source_over_a_random_sweep():
+    """`protocol.smart_resize` feeds BOTH the native path and the oracle's inputs, so it is pinned against HF's own
+    function (executed from source, like tests/test_oracle.py does for `patchify`) over 4,000 random (height, width, pixel budget)
+    triples incl. the streaming budgets of the reference (384*28*28 per frame, the 480-frame 24k-token budget) and the error case."""
+    hf = _hf_smart_resize()
+    rng = np.random.RandomState(0)
+    budgets = [(56 * 56, 14 * 14 * 4 * 1280), (100 * 28 * 28, 384 * 28 * 28), (int(1.05 * 100 * 28 * 28), 82320), (4 * 28 * 28, 16384 * 28 * 28)]
+    n = 0
+    for _ in range(4000):
+        h, w = int(rng.randint(20, 2400)), int(rng.randint(20, 4000))
+        mn, mx = budgets[int(rng.randint(len(budgets)))]
+        if rng.rand() < 0.3:
+            mx = int(rng.randint(mn, 4 * 1280 * 28 * 28))
+        try:
+            want = hf(h, w, 28, mn, mx)
+        except ValueError:
+            with pytest.raises(ValueError):
+                protocol.smart_resize(h, w, 28, mn, mx)
+            continue
+        assert protocol.smart_resize(h, w, 28, mn, mx) == tuple(want), (h, w, mn, mx)
+        n += 1
+    assert n > 3500
+    assert protocol.smart_resize(1080, 1920, 28, 100 * 28 * 28, 384 * 28 * 28) == tuple(hf(1080, 1920, 28, 100 * 28 * 28, 384 * 28 * 28)) == (392, 728)
