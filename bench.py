@@ -378,6 +378,7 @@ def main():
     from livecc_amd import distributed as D, protocol
     from livecc_amd.config import get_config
     rank, local, world = D.init_from_env(backend="gloo" if args.standin else None)
+    numa = D.pin_to_gpu_numa_node(local) if (world > 1 and not args.standin) else dict(pinned=False, reason="single rank")
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: pass --gpus {world} or let "
                          f"bench.py launch the ranks itself")
@@ -459,6 +460,13 @@ def main():
     total_frames = D.sum_over_ranks(float(nfr), dev)
     per_rank = D.gather_floats(toks / my_dt, dev)
     bcast_max = D.max_over_ranks(bcast_s, dev)
+    # per-rank whole-decode-step time (ms) and broadcast time: an 8-GPU run shows at a glance whether every rank streams at the same rate
+    my_step_ms = float(np.mean(model.engine.profile_read_steps(16384))) if model.engine is not None and not args.standin else 0.0
+    if not np.isfinite(my_step_ms):
+        my_step_ms = 0.0
+    step_ms_per_rank = D.gather_floats(my_step_ms, dev)
+    bcast_per_rank = D.gather_floats(bcast_s, dev)
+    numa_pinned = D.sum_over_ranks(1.0 if numa.get("pinned") else 0.0, dev)
     if rank != 0:
         return
     I, H = cfg.intermediate_size, cfg.hidden_size
@@ -586,6 +594,10 @@ def main():
         "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
         "weight_broadcast_s": round(bcast_max, 3), "rccl_ranks": world, "launcher": "self" if os.environ.get("LCC_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single"),
         "tokens_per_s_per_rank": [round(x, 2) for x in per_rank],
+        "decode_step_ms_per_rank": [round(x, 3) for x in step_ms_per_rank],
+        "weight_broadcast_s_per_rank": [round(x, 3) for x in bcast_per_rank],
+        "weight_broadcast_xgmi_bound_s": round(arena.nbytes() / 153e9, 3) if (arena is not None and world > 1) else 0.0,
+        "ranks_pinned_to_gpu_numa_node": int(numa_pinned),
         "roofline": roof, "cpu_baseline": cpu, "parity": par,
     }
     print(json.dumps(out), flush=True)

@@ -33,6 +33,46 @@ def init_from_env(backend: str = None) -> tuple:
     return rank, local, world
 
 
+def numa_cpus_of_gpu(local_rank: int):
+    """CPU ids of the NUMA node the GPU `local_rank` hangs off (PCI bus id -> /sys/bus/pci/devices/<bdf>/numa_node ->
+    /sys/devices/system/node/node<N>/cpulist), or None when the platform does not say."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{int(getattr(p, 'pci_domain_id', 0)):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return sorted(cpus) or None
+    except Exception:
+        return None
+
+
+def pin_to_gpu_numa_node(local_rank: int) -> dict:
+    """One process per GPU: keep the rank's host threads (Python orchestration, pinned meta ring, launches) on the CPUs of its GPU's
+    NUMA node -- on an 8-GPU node the ranks otherwise migrate across sockets and every launch crosses the inter-socket link.
+    Best effort (returns what it did); LCC_NO_NUMA_PIN=1 disables it."""
+    if os.environ.get("LCC_NO_NUMA_PIN") == "1":
+        return dict(pinned=False, reason="LCC_NO_NUMA_PIN=1")
+    cpus = numa_cpus_of_gpu(local_rank) if torch.cuda.is_available() else None
+    if not cpus:
+        return dict(pinned=False, reason="NUMA node of the GPU unknown")
+    try:
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return dict(pinned=False, reason="no overlap with the allowed CPU set")
+        os.sched_setaffinity(0, allowed)
+        return dict(pinned=True, cpus=len(allowed), first_cpu=allowed[0])
+    except Exception as e:                   # never fatal
+        return dict(pinned=False, reason=repr(e))
+
+
 def shard_streams(stream_ids: Sequence[int], rank: int, world: int) -> List[int]:
     """Static strided sharding, stream s -> GPU s % world (ref distributed_generate_livecc.py:49-50: idxs[i::N])."""
     return [s for s in stream_ids if s % world == rank]
