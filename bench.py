@@ -64,6 +64,7 @@ def parse(argv=None):
     ap.add_argument("--attn-variant", type=int, default=None, help="debug A/B: lcc_debug_set_attn_variant")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--decode-path", type=int, default=None, help="debug A/B: lcc_debug_set_decode_path")
+    ap.add_argument("--decode-chain", type=int, default=None, choices=[0, 1], help="debug A/B: lcc_debug_set_decode_chain")
     ap.add_argument("--fused-attn", type=int, default=None, help="debug A/B: lcc_debug_set_fused_attn (bit 0 fused decode attention for "
                                                                   ">= 16 (stream, KV head) pairs, bit 2 always, bit 1 in-launch split merge)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: do not overlap the next turn's vision tower with this turn's decode steps")
@@ -412,6 +413,8 @@ def main():
             ops.set_attn_variant(args.attn_variant)
         if args.gemv_variant is not None:
             ops.set_gemv_variant(args.gemv_variant)
+        if args.decode_chain is not None:
+            _lib.load().lcc_debug_set_decode_chain(args.decode_chain)
         if args.fused_attn is not None:
             _lib.load().lcc_debug_set_fused_attn(args.fused_attn)
         if args.decode_path is not None:
@@ -508,6 +511,17 @@ def main():
                              avg_step_us=round(s_ms * 1e3, 1), steps_timed=int(len(st_ms)), algorithmic_bytes_per_step=int(step_bytes),
                              weight_bytes=int(wbytes), mean_kv_len=round(kv_avg, 1),
                              us_per_layer=round((s_ms * 1e3) / cfg.num_hidden_layers, 2))
+            # the vision tower of the NEXT turn runs on a side stream under the first decode steps of a turn (prefetch): steps late in
+            # the call (index >= 8) see the GPU alone -- the kernel-efficiency number; `decode_step` above is every sampled step
+            try:
+                rel = model.engine.profile_read_step_index(16384)[:len(st_ms)]
+                late = np.asarray(st_ms)[rel >= 8]
+                if len(late):
+                    l_ms = float(np.mean(late))
+                    step_roof["late_steps_without_vision_tower_overlap"] = dict(avg_step_us=round(l_ms * 1e3, 1), steps_timed=int(len(late)),
+                                                                                frac=round(step_bytes / (l_ms * 1e-3) / 1e9 / 8000.0, 4))
+            except Exception:
+                pass
             if roof is not None:
                 roof["decode_step"] = step_roof
         if oneshot:

@@ -76,6 +76,12 @@ int lcc_debug_set_fused_tails(int on);
  * per layer (always used with fp8 weights and for larger batches).  Merging the attention key splits inside the o_proj GEMV as well (5 launches) was
  * measured slower: 4-wave attention blocks 10.0 us + o_proj 9.8 us vs 7.3 + 4.9 + 6.8 us. */
 int lcc_debug_set_decode_path(int path);
+/* 1 (default): pipeline v2 launches down_proj of layer l and the q/k/v GEMV of layer l+1 as ONE chained launch (5 launches per layer):
+ * the q/k/v blocks are resident next to the down_proj blocks, request their weights at once and then wait -- bounded -- for the
+ * down_proj blocks to publish the residual stream (write-through stores + a monotonic counter, Guideline 16 R1), so the HBM stream
+ * does not drain at the hand-off.  Used only when both grids fit the chip at once (LiveCC-7B: 224 + 288 blocks of 512 threads = 2 per
+ * CU) and for <= 2 streams; 0 = separate launches.  A hand-off that times out fails the call (lcc_slot_read_tokens) and disables it. */
+int lcc_debug_set_decode_chain(int on);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
  * [N/16][K/64][4 g][16 rows][16 k] (lane (g,row) owns 16 consecutive k), wscale = fp32 [N] per-output-row scale:
@@ -191,6 +197,13 @@ int lcc_dgemv_resid(const void* W_packed, const void* x, int ldx, void* h, float
 int lcc_dgemv_qkv_rope(const void* W_dec_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
                        const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* kv_len, void* const* kv_base,
                        lcc_kv_layout lay, int layer, void* q_out, int n_q_heads, int M, int K, void* stream);
+/* the chained launch as an operator (tests): h += Linear_down(x) with its tile statistics, then q|k|v of RMSNorm(h) as
+ * lcc_dgemv_qkv_rope -- `counter` / `err`: device uint32 words, *counter counts arrivals monotonically (pass its value BEFORE the call
+ * as `counter_before`), *err is set if a consumer block gives up.  LCC_ERR_STATE when the two grids do not fit the chip at once. */
+int lcc_dgemv_down_qkv(const void* W_down_packed, const void* x, int ldx, void* h, float* stats, int K_down,
+                       const void* W_qkv_dec_packed, const void* norm_w, float eps, const void* bias, const void* cos, const void* sin,
+                       const int32_t* tok_stream, const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer, void* q_out,
+                       int n_q_heads, int M, int hidden, uint32_t* counter, uint32_t counter_before, uint32_t* err, void* stream);
 int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
                           const void* vit_rows, void* out, int S, int dim, void* stream);             /* Q2VL:1159-1176 */
 int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, void* stream);
@@ -267,6 +280,9 @@ int lcc_engine_profile_read(lcc_engine* e, float* ms_out, int max_n, int* n_out)
 /* the same switch also brackets every WHOLE decode step (28 layers + final norm + lm_head + sampler) with an event pair:
  * milliseconds per decode step, for the step-level roofline (weights + KV bytes / step time) */
 int lcc_engine_profile_read_steps(lcc_engine* e, float* ms_out, int max_n, int* n_out);
+/* for the same samples: the index of the step inside its lcc_llm_decode call (0 = the step right after the prefill, which shares the
+ * GPU with a vision tower prefetched on the side stream; late steps run alone) */
+int lcc_engine_profile_read_step_index(lcc_engine* e, int32_t* idx_out, int max_n, int* n_out);
 
 /* Parity instrumentation (tests only; SURVEY section 7 step 1: per-stage tensors).  While bound, every lcc_llm_prefill / lcc_llm_decode
  * call copies the residual stream (HF `hidden_states`, Q2VL:762-844) of its rows into `taps` = bf16 [2*n_layers + 1][max_rows][hidden]:

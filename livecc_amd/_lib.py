@@ -91,6 +91,9 @@ def load():
         "lcc_debug_set_attn_variant": (i32, [i32]),
         "lcc_debug_set_fused_tails": (i32, [i32]),
         "lcc_debug_set_decode_path": (i32, [i32]),
+        "lcc_debug_set_decode_chain": (i32, [i32]),
+        "lcc_dgemv_down_qkv": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp, C.c_uint32,
+                                     vp, vp]),
         "lcc_gemv_num_splits": (i32, [i32, i32]),
         "lcc_debug_mfma_probe": (i32, [vp, vp, vp, vp]),
         "lcc_patchify_norm_u8": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp]),
@@ -139,6 +142,7 @@ def load():
         "lcc_engine_profile": (i32, [vp, i32, i32]),
         "lcc_engine_profile_read": (i32, [vp, vp, i32, C.POINTER(i32)]),
         "lcc_engine_profile_read_steps": (i32, [vp, vp, i32, C.POINTER(i32)]),
+        "lcc_engine_profile_read_step_index": (i32, [vp, vp, i32, C.POINTER(i32)]),
         "lcc_debug_set_llm_taps": (i32, [vp, vp, vp, i32]),
         "lcc_debug_set_vit_taps": (i32, [vp, vp, vp, i32]),
         "lcc_slot_reset": (i32, [vp, i32, vp]),

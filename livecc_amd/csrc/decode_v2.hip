@@ -22,6 +22,8 @@
 //     op sequence, Q2VL:180-222) + the in-place KV append (cache_utils.py:127-146) run in the epilogue from registers.
 // All of it is HBM-bound weight streaming (same packed fragment order, nontemporal 16-byte loads, 2-stage software pipeline as
 // gemv_skinny_kernel); MFMA is only the multiply unit.  Algorithmic bytes per layer are unchanged (466 MB at 7B).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -31,6 +33,30 @@ __device__ unsigned int lcc_zero_page_v2[64];  // 256 zero bytes: activation ope
 
 enum { DG_PRO_PLAIN = 0, DG_PRO_NORM = 1 };
 enum { DG_EPI_BF16 = 0, DG_EPI_SWIGLU = 1, DG_EPI_RESID = 2, DG_EPI_ROPE = 3 };
+
+// ---- chained launches (round 3): two dependent GEMVs in ONE launch.  The consumer's blocks (q/k/v of layer l+1) are resident next to
+// the producer's (down_proj of layer l), request their weights -- which do not depend on the producer -- right away, and only then
+// wait for the producer's blocks to have published the residual stream: the HBM stream does not drain at the hand-off (the
+// "prefetch-credit" of MI355X_MICROARCH.md) and one kernel boundary per layer disappears.  Hand-off = Guideline 16, recipe R1:
+// the producer's epilogue stores are write-through (relaxed agent-scope 8-byte atomic stores = `global_store_dwordx2 sc0 sc1`), the
+// storing wave drains them (vmcnt(0)), one lane adds 1 to a monotonic counter; the consumer polls that ONE word relaxed from one lane
+// (s_sleep between polls), then reads the published bytes with agent-scope (sc1, L1-bypassing) loads.  Placement-independent; the
+// spin is bounded (a block that gives up raises *err and the engine fails the call).  Deadlock-free by construction: the launch is
+// only used when producer + consumer blocks fit the chip at once, and producer blocks never wait.
+enum { DG_CHAIN_NONE = 0, DG_CHAIN_SIGNAL = 1, DG_CHAIN_WAIT = 2 };
+struct DgChain { unsigned* flag; unsigned target; unsigned* err; };
+
+LCC_DEVICE u32x4 ld16_agent(const void* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (u32x4){(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+}
+LCC_DEVICE f32x4 ld16f_agent(const void* p) { return __builtin_bit_cast(f32x4, ld16_agent(p)); }
+LCC_DEVICE void st8_agent(void* p, u32x2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // x fragment of 8 consecutive k for activation row m: PRO_NORM = bf16(w * bf16(h * r))
 LCC_DEVICE u32x4 norm_frag(u32x4 hv, u32x4 wv, float r) {
@@ -53,19 +79,18 @@ constexpr int dgemv_min_waves_per_simd() {
   return MR > 2 ? 1 : ((NTILE == 2 && PRO == DG_PRO_NORM && NW == 4) ? 5 : ((EPI == DG_EPI_ROPE && NW == 8) ? 4 : 1));
 }
 
-template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR = 4>
-__global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI, NW, MR>())) void dgemv_kernel(DgArgs a) {
+template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR, int CHAIN>
+LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f32x4 (*red)[NTILE][64], bf16_t* s_x) {
   static_assert(EPI != DG_EPI_SWIGLU || NTILE == 2, "swiglu needs the gate and the up tile in one block");
   static_assert(EPI == DG_EPI_SWIGLU || NTILE == 1, "one tile per block");
-  __shared__ f32x4 red[NW - 1][NTILE][64];
+  static_assert(CHAIN != DG_CHAIN_SIGNAL || EPI == DG_EPI_RESID, "the producer of a chained launch publishes the residual stream");
   // PRO_NORM: the activation rows are built ONCE per block in LDS (M * K <= 16384 elements) and the MFMA fragments are
   // read from there.  (The first version normalised every fragment in registers: 16 lanes of a wave computed the same 8 values and
   // every one of the N/16 blocks repeated it -- +6.7 us on the gate/up GEMV, +24 us on lm_head.)
   constexpr bool XLDS = PRO != DG_PRO_PLAIN;
-  extern __shared__ __attribute__((aligned(16))) bf16_t s_x[];   // XLDS: M * K bf16 (dynamic: 7 KB for one stream at 7B)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int M = a.M, N = a.N, K = a.K;
-  const int n0 = blockIdx.x * (NTILE * 16);
+  const int n0 = bid * (NTILE * 16);
   const int nchunk = (K + 63) >> 6, K32 = (K + 31) >> 5;
   const int xm = min(li, M - 1);
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_v2) + g * 8;
@@ -133,6 +158,21 @@ __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI,
   // per lane, summed by a butterfly -- the same fixed order in every wave of every block), and the block's threads share the
   // 8-element pieces of the residual rows and of the norm weight that are normalised into LDS
   constexpr int T = NW * 64, XP = 2;      // XP row pieces per thread are requested up front (all of them for one stream)
+  if (CHAIN == DG_CHAIN_WAIT) {
+    // consumer of a chained launch: the weights first (they do not depend on the producer), then wait for the producer's blocks
+    __builtin_amdgcn_sched_barrier(0);
+    load_w(c, sa);
+    load_w(c + STEP, sb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while ((int)(__hip_atomic_load(ch.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.target) < 0) {
+        if (++spins > 400000) { __hip_atomic_fetch_or(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(16);
+      }
+    }
+    __syncthreads();
+  }
   const int n4 = a.n_stat >> 2;
   const int kp = K >> 3, xpieces = PRO == DG_PRO_NORM ? M * kp : 0;
   f32x4 pv[PRO == DG_PRO_NORM ? MR : 1][2];
@@ -143,12 +183,13 @@ __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI,
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = lane + 64 * u;           // unconditional (clamped) loads: a branch here would serialise them
-        pv[m][u] = *reinterpret_cast<const f32x4*>(a.stats + (size_t)min(m, M - 1) * a.n_stat + 4 * (i < n4 ? i : 0));
+        const float* sp = a.stats + (size_t)min(m, M - 1) * a.n_stat + 4 * (i < n4 ? i : 0);
+        pv[m][u] = CHAIN == DG_CHAIN_WAIT ? ld16f_agent(sp) : *reinterpret_cast<const f32x4*>(sp);
       }
 #pragma unroll
     for (int u = 0; u < XP; ++u) {
       const int p = (int)threadIdx.x + u * T, pc = p < xpieces ? p : 0;
-      hv[u] = ld16(a.H + (size_t)pc * 8);                    // rows are contiguous: [M][K]
+      hv[u] = CHAIN == DG_CHAIN_WAIT ? ld16_agent(a.H + (size_t)pc * 8) : ld16(a.H + (size_t)pc * 8);   // rows are contiguous: [M][K]
       nv[u] = ld16(a.norm_w + (size_t)(pc % kp) * 8);
     }
   }
@@ -174,8 +215,10 @@ __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI,
   // keep the small loads AHEAD of the weight stream in the memory queue (vmcnt retires in issue order): the compiler otherwise
   // sinks some of them behind the weight loads and then has to wait for the whole first stage before the prologue can run
   __builtin_amdgcn_sched_barrier(0);
-  load_w(c, sa);
-  load_w(c + STEP, sb);
+  if (CHAIN != DG_CHAIN_WAIT) {
+    load_w(c, sa);
+    load_w(c + STEP, sb);
+  }
   load_x(c, sa);
   load_x(c + STEP, sb);
   __builtin_amdgcn_sched_barrier(0);
@@ -196,7 +239,8 @@ __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI,
       if (p < xpieces) *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(hv[u], nv[u], row_r(p / kp));
     }
     for (int p = (int)threadIdx.x + XP * T; p < xpieces; p += T)       // batches of several streams: the remaining pieces
-      *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(ld16(a.H + (size_t)p * 8), ld16(a.norm_w + (size_t)(p % kp) * 8), row_r(p / kp));
+      *reinterpret_cast<u32x4*>(s_x + (size_t)p * 8) = norm_frag(CHAIN == DG_CHAIN_WAIT ? ld16_agent(a.H + (size_t)p * 8) : ld16(a.H + (size_t)p * 8),
+                                                                 ld16(a.norm_w + (size_t)(p % kp) * 8), row_r(p / kp));
     __syncthreads();
   }
   for (; c < nchunk; c += 2 * STEP) {
@@ -243,12 +287,21 @@ __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI,
       const u32x2 hv = e_h;
       const float v0 = rbf(lo2f(hv.x) + rbf(acc[0][0])), v1 = rbf(hi2f(hv.x) + rbf(acc[0][1]));
       const float v2 = rbf(lo2f(hv.y) + rbf(acc[0][2])), v3 = rbf(hi2f(hv.y) + rbf(acc[0][3]));
-      st8(hp, (u32x2){pack2(v0, v1), pack2(v2, v3)});
+      if (CHAIN == DG_CHAIN_SIGNAL) st8_agent(hp, (u32x2){pack2(v0, v1), pack2(v2, v3)});
+      else st8(hp, (u32x2){pack2(v0, v1), pack2(v2, v3)});
       ss = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
     }
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    if (g == 0 && li < M) a.stats_out[(size_t)li * (N >> 4) + (n0 >> 4)] = ss;
+    if (g == 0 && li < M) {
+      float* sp = a.stats_out + (size_t)li * (N >> 4) + (n0 >> 4);
+      if (CHAIN == DG_CHAIN_SIGNAL) __hip_atomic_store(reinterpret_cast<unsigned*>(sp), __float_as_uint(ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *sp = ss;
+    }
+    if (CHAIN == DG_CHAIN_SIGNAL) {       // wave 0 is the only storing wave: drain its write-through stores, then ONE lane publishes
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(ch.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   } else {   // DG_EPI_ROPE: tile rows 0-7 = channels d0..d0+7 of a head, rows 8-15 = their rotation partners d0+64..
     constexpr int D = 128;
     const int tile = n0 >> 4, head = tile >> 3, j = tile & 7;
@@ -285,6 +338,25 @@ __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI,
       for (int q = 0; q < 4; ++q) dst[q * 32] = f2bf(x[q]);
     }
   }
+}
+
+template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR = 4>
+__global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI, NW, MR>())) void dgemv_kernel(DgArgs a) {
+  __shared__ f32x4 red[NW - 1][NTILE][64];
+  extern __shared__ __attribute__((aligned(16))) bf16_t s_x[];   // PRO_NORM: M * K bf16 (dynamic: 7 KB for one stream at 7B)
+  dgemv_body<NTILE, PRO, EPI, NW, UNR, MR, DG_CHAIN_NONE>(a, DgChain{nullptr, 0u, nullptr}, blockIdx.x, red, s_x);
+}
+
+// down_proj of layer l (blocks [0, nb_down): producer, publishes the residual stream + its tile statistics) and the q/k/v GEMV of
+// layer l+1 (the remaining blocks: consumer) in ONE launch.  512-thread blocks, <= 128 VGPRs: two blocks per CU, so all
+// nb_down + nb_qkv blocks of LiveCC-7B (224 + 288 = 512 = 2 x 256 CUs) are resident at once (the host checks the capacity).
+// The producer part runs UNR = 3 (120 VGPRs; the stand-alone kernel's UNR = 4 needs 152).
+template <int MR>
+__global__ __launch_bounds__(512, 4) void dgemv_down_qkv_kernel(DgArgs down, DgArgs qkv, DgChain ch, int nb_down) {
+  __shared__ f32x4 red[7][1][64];
+  extern __shared__ __attribute__((aligned(16))) bf16_t s_x[];
+  if ((int)blockIdx.x < nb_down) dgemv_body<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 3, 4, DG_CHAIN_SIGNAL>(down, ch, blockIdx.x, red, s_x);
+  else dgemv_body<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, MR, DG_CHAIN_WAIT>(qkv, ch, (int)blockIdx.x - nb_down, red, s_x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -355,6 +427,31 @@ int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
 int dgemv_resid(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
   dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
+  return 0;
+}
+// chained launch: down_proj of one layer + q/k/v of the next (see dgemv_down_qkv_kernel).  `blocks_capacity` = co-resident 512-thread
+// blocks of that kernel on this device (dgemv_chain_capacity); LCC_ERR_STATE when the grid does not fit (the caller then launches the
+// two GEMVs separately).  *flag is a monotonic counter: the consumer waits for it to reach `target`.
+int dgemv_chain_capacity() {
+  static int cap = -1;
+  if (cap < 0) {
+    int per_cu = 0, cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dgemv_down_qkv_kernel<2>, 512, 16 * 1024) != hipSuccess) per_cu = 0;
+    cap = std::max(0, std::min(per_cu, 2)) * cus;
+  }
+  return cap;
+}
+int dgemv_down_qkv(const DgArgs& down, const DgArgs& qkv, unsigned* flag, unsigned target, unsigned* err, hipStream_t st) {
+  if (int rc = dg_check(down, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
+  if (int rc = dg_check(qkv, DG_PRO_NORM, DG_EPI_ROPE)) return rc;
+  if (flag == nullptr || err == nullptr) return LCC_ERR_ARG;
+  const int nb_down = down.N / 16, nb_qkv = qkv.N / 16;
+  // M <= 2 only: the 3-4 row variant of the q/k/v part needs 140 VGPRs and would spill under the two-blocks-per-CU register budget
+  if (qkv.M > 2 || down.M != qkv.M || nb_down + nb_qkv > dgemv_chain_capacity() || (size_t)qkv.M * qkv.K * 2 > 16 * 1024) return LCC_ERR_STATE;
+  const DgChain ch{flag, target, err};
+  dgemv_down_qkv_kernel<2><<<dim3(nb_down + nb_qkv), dim3(512), (size_t)qkv.M * qkv.K * 2, st>>>(down, qkv, ch, nb_down);
   return 0;
 }
 // [RMSNorm] gate/up Linear [SwiGLU]

@@ -24,6 +24,9 @@
 
 using namespace lcc;
 
+// 1: decode pipeline v2 launches down_proj(l) + q/k/v(l+1) as ONE chained launch where both grids fit the chip at once (decode_v2.hip)
+static int g_decode_chain = 1;
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -134,11 +137,14 @@ struct lcc_engine {
   int32_t* d_attn_cnt = nullptr;  // [16 streams x Hkv] arrival counters of the fused decode attention (zero between launches)
   uint32_t* d_seen = nullptr;
   uint32_t* d_rng_ctr = nullptr;  // per-slot Philox draw counter of the sampling kernel (zero for a fresh stream)
+  unsigned* d_chain = nullptr;    // [128] monotonic hand-off counters of the chained decode launches (one per layer) + [128] = error word
+  std::vector<unsigned> chain_epoch;   // host mirror: launches issued per counter (the consumer's target = epoch * producer blocks)
   bf16_t** d_kv_base = nullptr;
   // optional live timing of the dominant kernel (decode gate/up GEMV): hipEvent pairs on the launch stream
   std::vector<hipEvent_t> prof_ev;   // 2 * capacity
   int prof_n = 0; bool prof_on = false;
   std::vector<hipEvent_t> step_ev;   // whole decode steps (layers + lm_head + sampler), 2 * capacity
+  std::vector<int> step_rel;         // index of each sampled step inside its lcc_llm_decode call (0 = right after the prefill)
   int step_n = 0;
   // parity instrumentation (lcc_debug_set_llm_taps / lcc_debug_set_vit_taps): residual-stream taps and per-layer input overrides
   bf16_t* llm_taps = nullptr; const bf16_t* llm_over = nullptr; int llm_tap_rows = 0;
@@ -198,6 +204,7 @@ extern "C" lcc_engine* lcc_engine_create(const lcc_model_config* cfg, const lcc_
   e->words = cfg->vocab_size / 32; e->E = cfg->vit_embed; e->vit_hd = 80;
   e->lay = KvLayout{cfg->n_layers, cfg->n_kv_heads, lim->max_kv_len, 128};
   e->vit.resize(cfg->vit_depth); e->llm.resize(cfg->n_layers);
+  e->chain_epoch.assign(128, 0u);
   e->h_kv_len.assign(lim->max_slots, 0); e->h_pos.assign(lim->max_slots, 0); e->h_kv_base.assign(lim->max_slots, nullptr);
   return e;
 }
@@ -223,6 +230,7 @@ extern "C" int lcc_engine_profile(lcc_engine* e, int enable, int max_samples) {
       e->step_ev.push_back(ev);
     }
     e->prof_n = 0; e->step_n = 0;
+    e->step_rel.assign(max_samples, 0);
   }
   e->prof_on = enable != 0;
   return 0;
@@ -247,10 +255,17 @@ extern "C" int lcc_engine_profile_read_steps(lcc_engine* e, float* ms_out, int m
   *n_out = n;
   return 0;
 }
+extern "C" int lcc_engine_profile_read_step_index(lcc_engine* e, int32_t* idx_out, int max_n, int* n_out) {
+  if (!e || !idx_out || !n_out) return fail(LCC_ERR_ARG, "null argument");
+  const int n = std::min(std::min(e->step_n, max_n), (int)e->step_rel.size());
+  for (int i = 0; i < n; ++i) idx_out[i] = e->step_rel[i];
+  *n_out = n;
+  return 0;
+}
 extern "C" size_t lcc_engine_workspace_bytes(const lcc_engine* e) { return std::max(e->llm_ws_bytes(), e->vit_ws_bytes()); }
 extern "C" size_t lcc_engine_state_bytes(const lcc_engine* e) {
   const size_t B = e->lim.max_slots;
-  return align_up(B * 4) * 6 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096 + 1024;
+  return align_up(B * 4) * 6 + 256 + align_up(B * 8) + align_up(B * (size_t)e->lim.max_history * 4) + align_up(B * (size_t)e->words * 4) + 4096 + 1024 + 1024;
 }
 extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->lay.total() * 2; }
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
@@ -274,7 +289,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
   const size_t B = e->lim.max_slots;
   Carver cv; cv.base = e->state;
   e->d_kv_len = cv.take<int32_t>(B); e->d_pos = cv.take<int32_t>(B); e->d_hist_col = cv.take<int32_t>(B);
-  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_rng_ctr = cv.take<uint32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_attn_cnt = cv.take<int32_t>(256); e->d_kv_base = cv.take<bf16_t*>(B);
+  e->d_cur_tok = cv.take<int32_t>(B); e->d_done = cv.take<int32_t>(B); e->d_rng_ctr = cv.take<uint32_t>(B); e->d_counter = cv.take<int32_t>(16); e->d_attn_cnt = cv.take<int32_t>(256); e->d_chain = cv.take<unsigned>(160); e->d_kv_base = cv.take<bf16_t*>(B);
   e->d_history = cv.take<int32_t>(B * (size_t)e->lim.max_history);
   e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
   HIP_TRY(hipMemset(e->state, 0, state_bytes));
@@ -435,10 +450,18 @@ extern "C" int lcc_slot_read_tokens(lcc_engine* e, int slot, int32_t* out, int m
   if (!e || slot < 0 || slot >= e->lim.max_slots || !out || max_n < 0) return fail(LCC_ERR_ARG, "bad args");
   hipStream_t st = (hipStream_t)stream;
   int32_t v[3];
+  unsigned chain_err = 0;
+  HIP_TRY(hipMemcpyAsync(&chain_err, e->d_chain + 128, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(&v[0], e->d_kv_len + slot, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(&v[1], e->d_pos + slot, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(&v[2], e->d_hist_col + slot, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  if (chain_err != 0) {   // a consumer block of a chained decode launch gave up waiting: the step's results are not valid
+    g_decode_chain = 0;   // (never observed; the separate launches are the safe path from here on)
+    HIP_TRY(hipMemset(e->d_chain, 0, 160 * sizeof(unsigned)));
+    std::fill(e->chain_epoch.begin(), e->chain_epoch.end(), 0u);
+    return fail(LCC_ERR_STATE, "decode: a chained launch hand-off timed out (results invalid); chained launches are now disabled");
+  }
   e->h_kv_len[slot] = v[0]; e->h_pos[slot] = v[1];   // device counters are authoritative (EOS freezes them)
   const int n = std::min(std::min(v[2], max_n), e->lim.max_history);
   if (n > 0) HIP_TRY(hipMemcpy(out, e->d_history + (size_t)slot * e->lim.max_history, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -747,13 +770,22 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
   if (e->llm_taps && B > e->llm_tap_rows) return fail(LCC_ERR_STATE, "LLM taps bound for %d rows, decode batch has %d", e->llm_tap_rows, B);
   const size_t tap_stride = (size_t)e->llm_tap_rows * H, tap_bytes = (size_t)B * H * 2;
   if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
+  // chained launches: down_proj of layer l and q/k/v of layer l+1 in ONE launch (the consumer's weights stream under the producer's
+  // tail: decode_v2.hip).  Only when both grids fit the chip at once, <= 2 streams, <= 127 layers, and no parity taps are bound
+  // (a tap copy between the two halves would have to sit inside the launch).
+  auto qkv_args = [&](int l) {
+    const LlmLayerW& L = e->llm[l];
+    DgArgs a; a.W = L.qkv_w_dec; a.M = B; a.N = e->qkvd; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.in_norm;
+    a.eps = eps; a.bias = L.qkv_b; a.cs = b.cos; a.sn = b.sin; a.tok_stream = d_slots; a.kv_len = e->d_kv_len; a.kv_base = e->d_kv_base;
+    a.lay = e->lay; a.layer = l; a.q_out = b.q; a.n_q_heads = e->c.n_q_heads;
+    return a;
+  };
+  const bool chain = g_decode_chain && B <= 2 && e->c.n_layers <= 127 && !e->llm_taps && (long)B * H * 2 <= 16 * 1024 &&
+                     H / 16 + e->qkvd / 16 <= dgemv_chain_capacity();
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     DgArgs a;
-    a = DgArgs(); a.W = L.qkv_w_dec; a.M = B; a.N = e->qkvd; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.in_norm;
-    a.eps = eps; a.bias = L.qkv_b; a.cs = b.cos; a.sn = b.sin; a.tok_stream = d_slots; a.kv_len = e->d_kv_len; a.kv_base = e->d_kv_base;
-    a.lay = e->lay; a.layer = l; a.q_out = b.q; a.n_q_heads = e->c.n_q_heads;
-    LCC_TRY(dgemv_qkv_rope(a, st));
+    if (l == 0 || !chain) LCC_TRY(dgemv_qkv_rope(qkv_args(l), st));     // otherwise launched together with the previous layer's down_proj
     LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
     a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
     LCC_TRY(dgemv_resid(a, st));
@@ -765,7 +797,12 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     LCC_TRY(dgemv_norm_swiglu(a, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
     a = DgArgs(); a.W = L.down_w; a.M = B; a.N = H; a.K = I; a.X = b.act; a.ldx = I; a.Hres = b.h; a.stats_out = b.stats;
-    LCC_TRY(dgemv_resid(a, st));
+    if (chain && l + 1 < e->c.n_layers) {
+      const unsigned target = ++e->chain_epoch[l] * (unsigned)(H / 16);     // monotonic counter: every launch adds H/16 arrivals
+      LCC_TRY(dgemv_down_qkv(a, qkv_args(l + 1), e->d_chain + l, target, e->d_chain + 128, st));
+    } else {
+      LCC_TRY(dgemv_resid(a, st));
+    }
     if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 2) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
   }
   return 0;
@@ -990,7 +1027,11 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
     }
     LCC_TRY(advance_lengths(d_slots, e->d_kv_len, e->d_pos, n_streams, e->d_done, st));
     LCC_TRY(head_and_sample(e, bf, v2 ? nullptr : bf.xn, n_streams, d_slots, sp, first_step_index + step, st));
-    if (prof_step) { HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n + 1], st)); e->step_n++; }
+    if (prof_step) {
+      HIP_TRY(hipEventRecord(e->step_ev[2 * e->step_n + 1], st));
+      if (e->step_n < (int)e->step_rel.size()) e->step_rel[e->step_n] = step;
+      e->step_n++;
+    }
   }
   for (int b = 0; b < n_streams; ++b) { e->h_kv_len[slots[b]] += n_steps; e->h_pos[slots[b]] += n_steps; }
   return check_launch("lcc_llm_decode");
@@ -1017,6 +1058,7 @@ extern "C" int lcc_debug_launch_counts(int64_t* out, int n, int reset) {
   return 0;
 }
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
+extern "C" int lcc_debug_set_decode_chain(int on) { g_decode_chain = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_path(int path) {
   if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
   g_decode_path = path;
@@ -1315,6 +1357,21 @@ extern "C" int lcc_dgemv_qkv_rope(const void* W_dec_packed, const void* h, const
   a.tok_stream = tok_stream; a.kv_len = kv_len; a.kv_base = (bf16_t* const*)kv_base; a.lay = to_lay(lay); a.layer = layer; a.q_out = (bf16_t*)q_out;
   a.n_q_heads = n_q_heads;
   OP_RET(dgemv_qkv_rope(a, (hipStream_t)stream), "lcc_dgemv_qkv_rope");
+}
+extern "C" int lcc_dgemv_down_qkv(const void* W_down_packed, const void* x, int ldx, void* h, float* stats, int K_down,
+                                  const void* W_qkv_dec_packed, const void* norm_w, float eps, const void* bias, const void* cos, const void* sin,
+                                  const int32_t* tok_stream, const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer,
+                                  void* q_out, int n_q_heads, int M, int hidden, uint32_t* counter, uint32_t counter_before, uint32_t* err,
+                                  void* stream) {
+  if (!W_down_packed || !x || !h || !stats || !W_qkv_dec_packed || !norm_w || !bias || !cos || !sin || !tok_stream || !kv_len || !kv_base ||
+      !q_out || !counter || !err) return fail(LCC_ERR_ARG, "null pointer");
+  DgArgs d; d.W = (const bf16_t*)W_down_packed; d.M = M; d.N = hidden; d.K = K_down; d.X = (const bf16_t*)x; d.ldx = ldx; d.Hres = (bf16_t*)h;
+  d.stats_out = stats;
+  DgArgs a; a.W = (const bf16_t*)W_qkv_dec_packed; a.M = M; a.N = (n_q_heads + 2 * lay.n_kv_heads) * 128; a.K = hidden; a.H = (const bf16_t*)h;
+  a.stats = stats; a.n_stat = hidden / 16; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.bias = (const bf16_t*)bias; a.cs = (const bf16_t*)cos;
+  a.sn = (const bf16_t*)sin; a.tok_stream = tok_stream; a.kv_len = kv_len; a.kv_base = (bf16_t* const*)kv_base; a.lay = to_lay(lay); a.layer = layer;
+  a.q_out = (bf16_t*)q_out; a.n_q_heads = n_q_heads;
+  OP_RET(dgemv_down_qkv(d, a, counter, counter_before + (uint32_t)(hidden / 16), err, (hipStream_t)stream), "lcc_dgemv_down_qkv");
 }
 extern "C" int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int32_t* vit_index, const void* table,
                                      const void* vit_rows, void* out, int S, int dim, void* stream) {

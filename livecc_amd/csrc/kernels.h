@@ -155,6 +155,9 @@ int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_
 int dgemv_qkv_rope(const DgArgs& a, hipStream_t st);      // [RMSNorm] q|k|v Linear (row-permuted decode copy) [bias + M-RoPE + KV append]
 int dgemv_resid(const DgArgs& a, hipStream_t st);         // o_proj / down_proj [residual add in place + per-tile sums of squares]
 int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st);   // [RMSNorm] gate/up Linear [SwiGLU]
+// chained launch: down_proj of layer l + q/k/v of layer l+1, the consumer's weights prefetched under the producer (decode_v2.hip)
+int dgemv_chain_capacity();
+int dgemv_down_qkv(const DgArgs& down, const DgArgs& qkv, unsigned* flag, unsigned target, unsigned* err, hipStream_t st);
 int dgemv_norm_bf16(const DgArgs& a, hipStream_t st);     // [final RMSNorm] lm_head
 
 }  // namespace lcc

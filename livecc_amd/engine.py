@@ -291,6 +291,13 @@ class Engine:
         _lib.check(self.lib.lcc_engine_profile_read_steps(self.h, buf.ctypes.data, max_n, C.byref(n)), "lcc_engine_profile_read_steps")
         return buf[:n.value]
 
+    def profile_read_step_index(self, max_n: int = 4096) -> np.ndarray:
+        """For the samples of `profile_read_steps`: the index of each step inside its decode call (0 = right after the prefill)."""
+        buf = np.zeros(max_n, dtype=np.int32)
+        n = C.c_int()
+        _lib.check(self.lib.lcc_engine_profile_read_step_index(self.h, buf.ctypes.data, max_n, C.byref(n)), "lcc_engine_profile_read_step_index")
+        return buf[:n.value]
+
     def generated_count(self, slot: int) -> int:
         """Blocking: number of tokens the slot has generated in the current generate call (stops growing after EOS)."""
         buf = np.zeros(1, dtype=np.int32)

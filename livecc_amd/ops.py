@@ -424,3 +424,23 @@ def dgemv_qkv_rope(w_dec_packed: torch.Tensor, h: torch.Tensor, stats: torch.Ten
         _chk(tok_stream, torch.int32, "tok_stream"), _chk(kv_len, torch.int32, "kv_len"), kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr(),
         n_q_heads, M, K, _st(h)), "lcc_dgemv_qkv_rope")
     return q
+
+
+def dgemv_down_qkv_(w_down_packed: torch.Tensor, x: torch.Tensor, h: torch.Tensor, k_down: int, w_qkv_dec_packed: torch.Tensor,
+                    norm_w: torch.Tensor, eps: float, bias: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_stream: torch.Tensor,
+                    kv_len: torch.Tensor, kv: "KvArena", layer: int, n_q_heads: int, counter: torch.Tensor, counter_before: int,
+                    err: torch.Tensor):
+    """The chained decode launch as an operator (lcc_dgemv_down_qkv): h += Linear_down(x) in place (+ tile statistics), then q|k|v of
+    RMSNorm(h) with bias + M-RoPE + KV append.  Returns (stats [M, hidden/16], q [M, Hq*128]).  `counter` / `err`: int32 [1] device
+    words; `counter_before` = the counter's value before this call (it grows by hidden/16 per call)."""
+    M, hidden = h.shape
+    stats = torch.empty(M, hidden // 16, dtype=torch.float32, device=h.device)
+    q = torch.empty(M, n_q_heads * 128, dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.load().lcc_dgemv_down_qkv(
+        _chk(w_down_packed, torch.bfloat16, "w_down"), _chk(x, torch.bfloat16, "x"), x.shape[1], _chk(h, torch.bfloat16, "h"), stats.data_ptr(),
+        int(k_down), _chk(w_qkv_dec_packed, torch.bfloat16, "w_qkv"), _chk(norm_w, torch.bfloat16, "norm_w"), float(eps),
+        _chk(bias, torch.bfloat16, "bias"), _chk(cos, torch.bfloat16, "cos"), _chk(sin, torch.bfloat16, "sin"),
+        _chk(tok_stream, torch.int32, "tok_stream"), _chk(kv_len, torch.int32, "kv_len"), kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr(),
+        n_q_heads, M, hidden, _chk(counter, torch.int32, "counter"), int(counter_before), _chk(err, torch.int32, "err"), _st(h)),
+        "lcc_dgemv_down_qkv")
+    return stats, q

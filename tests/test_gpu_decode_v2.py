@@ -131,3 +131,51 @@ def test_decode_step_begin(dev):
     for sl, t in ((4, 4000), (0, 7)):                          # slot 2 is done: its token is not marked
         want[sl, t >> 5] |= np.uint32(1 << (t & 31))
     assert np.array_equal(seen.cpu().numpy().view(np.uint32), want)
+
+
+@pytest.mark.parametrize("Hq,Hkv,H,I", [(28, 4, 3584, 18944), (12, 2, 1536, 8960), (7, 1, 896, 2432)])
+@pytest.mark.parametrize("M", [1, 2])
+def test_chained_down_qkv_launch_is_bit_identical_to_the_two_launches(dev, Hq, Hkv, H, I, M):
+    """Round 3: down_proj of layer l and q/k/v of layer l+1 as ONE launch (the q/k/v blocks prefetch their weights, then wait for the
+    down_proj blocks' write-through residual rows: csrc/decode_v2.hip) must give bit-identical h, tile statistics, rotated q and KV
+    rows to lcc_dgemv_resid followed by lcc_dgemv_qkv_rope -- repeated 20 times on the same monotonic counter with a fresh residual
+    each time (a consumer that read a stale row would reproduce the previous iteration's values), error word never set."""
+    from livecc_amd import ops
+    from livecc_amd.config import LiveCCConfig
+    from livecc_amd.weights import qkv_decode_row_permutation
+    N = (Hq + 2 * Hkv) * 128
+    cfg = LiveCCConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=H)
+    w_down, w_qkv, b = _rand((H, I), dev, 0.03, 31), _rand((N, H), dev, 0.03, 32), _rand((N,), dev, 0.2, 33)
+    nw = (1.0 + 0.1 * _rand((H,), dev, 1.0, 34).float()).to(torch.bfloat16)
+    wd_p = ops.pack_weight(w_down)
+    wq_p = ops.pack_weight(w_qkv[qkv_decode_row_permutation(cfg).to(dev)].contiguous())
+    lens = [37, 100][:M]
+    slots = torch.arange(M, dtype=torch.int32, device=dev)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+    pos3 = torch.tensor([[l + 3 for l in lens]] * 3, dtype=torch.int32)
+    _, _, inv = _hf_mrope_ref(pos3)
+    c, s_ = ops.mrope_table(pos3.to(dev), inv.to(dev), [16, 24, 24])
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    before = 0
+    for it in range(20):
+        x, h0 = _rand((M, I), dev, 1.0, 40 + it), _rand((M, H), dev, 2.0, 80 + it)
+        kv_a, kv_b = ops.KvArena(M, 1, Hkv, 128, dev), ops.KvArena(M, 1, Hkv, 128, dev)
+        # the two launches
+        h_ref = h0.clone()
+        st_ref = ops.dgemv_resid_(wd_p, x, h_ref, (H, I))
+        q_ref = ops.dgemv_qkv_rope(wq_p, h_ref, st_ref, nw, 1e-6, b, c, s_, slots, kv_len, kv_b, 0, Hq)
+        # the chained launch
+        h = h0.clone()
+        try:
+            st, q = ops.dgemv_down_qkv_(wd_p, x, h, I, wq_p, nw, 1e-6, b, c, s_, slots, kv_len, kv_a, 0, Hq, counter, before, err)
+        except RuntimeError as e:
+            if "(-5)" in str(e) and it == 0:
+                pytest.skip(f"the two grids ({H // 16} + {N // 16} blocks) do not fit this chip at once: {e}")
+            raise
+        before += H // 16
+        assert int(err[0]) == 0, "a consumer block gave up waiting"
+        assert int(counter[0]) == before
+        assert torch.equal(h, h_ref) and torch.equal(st, st_ref), f"iteration {it}: residual stream / statistics differ"
+        assert torch.equal(q, q_ref), f"iteration {it}: rotated q differs (stale residual row?)"
+        assert torch.equal(kv_a.buf, kv_b.buf), f"iteration {it}: appended K/V rows differ"
