@@ -76,11 +76,12 @@ int lcc_debug_set_fused_tails(int on);
  * per layer (always used with fp8 weights and for larger batches).  Merging the attention key splits inside the o_proj GEMV as well (5 launches) was
  * measured slower: 4-wave attention blocks 10.0 us + o_proj 9.8 us vs 7.3 + 4.9 + 6.8 us. */
 int lcc_debug_set_decode_path(int path);
-/* 1 (default): pipeline v2 launches down_proj of layer l and the q/k/v GEMV of layer l+1 as ONE chained launch (5 launches per layer):
+/* 1: pipeline v2 launches down_proj of layer l and the q/k/v GEMV of layer l+1 as ONE chained launch (5 launches per layer; default 0:
+ * measured slower on MI355X, 3.1-3.2 vs 2.99 ms per decode step -- see csrc/engine.hip):
  * the q/k/v blocks are resident next to the down_proj blocks, request their weights at once and then wait -- bounded -- for the
  * down_proj blocks to publish the residual stream (write-through stores + a monotonic counter, Guideline 16 R1), so the HBM stream
  * does not drain at the hand-off.  Used only when both grids fit the chip at once (LiveCC-7B: 224 + 288 blocks of 512 threads = 2 per
- * CU) and for <= 2 streams; 0 = separate launches.  A hand-off that times out fails the call (lcc_slot_read_tokens) and disables it. */
+ * CU) and for <= 2 streams; 0 (default) = separate launches.  A hand-off that times out fails the call (lcc_slot_read_tokens) and disables it. */
 int lcc_debug_set_decode_chain(int on);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order

@@ -23,6 +23,7 @@
 // All of it is HBM-bound weight streaming (same packed fragment order, nontemporal 16-byte loads, 2-stage software pipeline as
 // gemv_skinny_kernel); MFMA is only the multiply unit.  Algorithmic bytes per layer are unchanged (466 MB at 7B).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -44,7 +45,9 @@ enum { DG_EPI_BF16 = 0, DG_EPI_SWIGLU = 1, DG_EPI_RESID = 2, DG_EPI_ROPE = 3 };
 // spin is bounded (a block that gives up raises *err and the engine fails the call).  Deadlock-free by construction: the launch is
 // only used when producer + consumer blocks fit the chip at once, and producer blocks never wait.
 enum { DG_CHAIN_NONE = 0, DG_CHAIN_SIGNAL = 1, DG_CHAIN_WAIT = 2 };
-struct DgChain { unsigned* flag; unsigned target; unsigned* err; };
+struct DgChain { unsigned* flag; unsigned target; unsigned* err; int delay_us; };   // delay_us: no polling for about that long (the
+// producer streams its weights for a known time: 288 lanes polling one word across the fabric from the first microsecond on cost the
+// producer a third of its bandwidth -- 43.6 us for the chained launch against 25.5 + 10.7 us for the two launches)
 
 LCC_DEVICE u32x4 ld16_agent(const void* p) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
@@ -165,10 +168,11 @@ LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f3
     load_w(c + STEP, sb);
     __builtin_amdgcn_sched_barrier(0);
     if (threadIdx.x == 0) {
+      for (int i = 0; i < ch.delay_us; ++i) __builtin_amdgcn_s_sleep(36);      // ~1 us each (64 x 36 cycles): memory-silent wait
       int spins = 0;
       while ((int)(__hip_atomic_load(ch.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.target) < 0) {
-        if (++spins > 400000) { __hip_atomic_fetch_or(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        __builtin_amdgcn_s_sleep(16);
+        if (++spins > 200000) { __hip_atomic_fetch_or(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(36);
       }
     }
     __syncthreads();
@@ -344,7 +348,7 @@ template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR = 4>
 __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI, NW, MR>())) void dgemv_kernel(DgArgs a) {
   __shared__ f32x4 red[NW - 1][NTILE][64];
   extern __shared__ __attribute__((aligned(16))) bf16_t s_x[];   // PRO_NORM: M * K bf16 (dynamic: 7 KB for one stream at 7B)
-  dgemv_body<NTILE, PRO, EPI, NW, UNR, MR, DG_CHAIN_NONE>(a, DgChain{nullptr, 0u, nullptr}, blockIdx.x, red, s_x);
+  dgemv_body<NTILE, PRO, EPI, NW, UNR, MR, DG_CHAIN_NONE>(a, DgChain{nullptr, 0u, nullptr, 0}, blockIdx.x, red, s_x);
 }
 
 // down_proj of layer l (blocks [0, nb_down): producer, publishes the residual stream + its tile statistics) and the q/k/v GEMV of
@@ -426,7 +430,9 @@ int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
 // o_proj / down_proj: x plain, residual add in place + per-tile sums of squares
 int dgemv_resid(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
-  dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
+  static const int unr3 = [] { const char* v = getenv("LCC_RESID_UNR3"); return v ? atoi(v) : 0; }();   // diagnostic A/B
+  if (unr3) dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 3><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
+  else dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
   return 0;
 }
 // chained launch: down_proj of one layer + q/k/v of the next (see dgemv_down_qkv_kernel).  `blocks_capacity` = co-resident 512-thread
@@ -450,7 +456,10 @@ int dgemv_down_qkv(const DgArgs& down, const DgArgs& qkv, unsigned* flag, unsign
   const int nb_down = down.N / 16, nb_qkv = qkv.N / 16;
   // M <= 2 only: the 3-4 row variant of the q/k/v part needs 140 VGPRs and would spill under the two-blocks-per-CU register budget
   if (qkv.M > 2 || down.M != qkv.M || nb_down + nb_qkv > dgemv_chain_capacity() || (size_t)qkv.M * qkv.K * 2 > 16 * 1024) return LCC_ERR_STATE;
-  const DgChain ch{flag, target, err};
+  // silent wait before the first poll: ~80 % of the producer's streaming time at 5.3 TB/s (LCC_CHAIN_DELAY_US overrides)
+  static const int forced = [] { const char* v = getenv("LCC_CHAIN_DELAY_US"); return v ? atoi(v) : -1; }();
+  const double prod_us = (double)down.N * down.K * 2.0 / 5.3e6;
+  const DgChain ch{flag, target, err, forced >= 0 ? forced : (int)(0.8 * prod_us)};
   dgemv_down_qkv_kernel<2><<<dim3(nb_down + nb_qkv), dim3(512), (size_t)qkv.M * qkv.K * 2, st>>>(down, qkv, ch, nb_down);
   return 0;
 }

@@ -24,8 +24,14 @@
 
 using namespace lcc;
 
-// 1: decode pipeline v2 launches down_proj(l) + q/k/v(l+1) as ONE chained launch where both grids fit the chip at once (decode_v2.hip)
-static int g_decode_chain = 1;
+// 1: decode pipeline v2 launches down_proj(l) + q/k/v(l+1) as ONE chained launch where both grids fit the chip at once (decode_v2.hip).
+// Measured on MI355X (LiveCC-7B, one stream, no ViT prefetch; profiles/r03/decode_chain_ab.jsonl): bit-identical, but SLOWER --
+// 3105-3229 us per decode step against 2989 us for the two launches (the chained kernel 43.6 us vs 25.5 + 10.7 us).  The consumer's
+// 33 MB of weights are served at the START of the launch (total HBM bytes are the same), and what the hand-off then exposes after the
+// producer is the consumer's whole serial tail (flag -> statistics -> normalise -> LDS -> 14 MFMAs -> reduce -> RoPE epilogue, ~5 us)
+// that a stand-alone launch hides under its own weight stream -- as much as the removed kernel boundary was worth.  Kept as a tested
+// variant (lcc_debug_set_decode_chain(1)); default off.
+static int g_decode_chain = 0;
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
