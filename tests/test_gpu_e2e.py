@@ -771,3 +771,23 @@ def test_decode_variants_on_a_long_cache_run_the_intended_kernels_and_match_hf(d
             pass
         record(f"long_cache_decode_counts[{name}]", c)
     assert len(compared) <= 2, "the decode variants differ only in fp32 summation order: at most a near-tie may flip one token"
+
+
+def test_chained_decode_launch_gives_bit_identical_logits(dev, tiny_models):
+    """lcc_debug_set_decode_chain(1): down_proj(l) + q/k/v(l+1) as one launch with an in-launch hand-off (default off: measured slower on
+    MI355X).  Same kernels, same fp32 summation order -> bit-identical logits and tokens to the separate launches; the hand-off error
+    word must stay clear (a timed-out hand-off would fail the call)."""
+    from livecc_amd import _lib, protocol
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=77, layout="TCHW"))
+    outs = []
+    for chain in (0, 1, 1, 0):
+        _lib.load().lcc_debug_set_decode_chain(chain)
+        try:
+            outs.append(_replay_native(native, cfg, frames, protocol.TurnBuilder(cfg, seed=77), max_new_tokens=8, repetition_penalty=1.05, max_turns=2))
+        finally:
+            _lib.load().lcc_debug_set_decode_chain(0)
+    for o in outs[1:]:
+        for ta, tb in zip(outs[0], o):
+            assert ta["new_tokens"] == tb["new_tokens"]
+            assert torch.equal(ta["logits"], tb["logits"]), "chained and separate launches must be bit-identical"
