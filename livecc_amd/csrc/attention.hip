@@ -908,7 +908,7 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
                   const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_tiles,
                   int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, hipStream_t st) {
   if (n_tiles <= 0) return 0;
-  if (g_attn_variant == 2 && n_groups > 0) {
+  if (g_attn_variant >= 2 && n_groups > 0) {
     constexpr size_t lds = (size_t)4 * (6 + 5) * 1024;
     static bool once = false;
     if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0, 4>, lds); set_lds_attr(attn_shared_kernel<80, 1, 0, 8>, lds); once = true; }

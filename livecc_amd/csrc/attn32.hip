@@ -41,8 +41,132 @@ LCC_DEVICE float xor32_sum(float x) {
 
 __device__ unsigned int lcc_attn32_zero_page[256];
 
-// grid = (query tiles, KV heads, key splits); NWAVE waves: wave w < G computes query head hk * G + w, every wave feeds the DMA ring.
-// Tile tables as attn_prefill_kernel: stream slot, first row in q, valid rows (<= 32), cache index of row 0.
+// ------------------------------------------------------------------------------------------------------------------------------
+// The key loop shared by the LLM prefill kernel (D = 128) and the ViT kernel (D = 80): software pipeline, one key tile per REGION.
+// The softmax of tile t (vector pipe: ~70 VALU instructions) is issued next to the MFMAs that do not depend on it -- the P . V of tile
+// t-1 and the K . Q^T of tile t+1 (matrix pipe: 16 x 32 cycles at D = 128) -- in ONE scheduling region, interleaved by
+// sched_group_barrier: a wave always has matrix AND vector work in flight.  (With one tile at a time per wave the two waves of a SIMD
+// ran the same phase in lock step behind the block barrier: the first version of the D = 128 kernel, 0.57 PF at 8 x 386 rows x 6k
+// keys against 0.54 for the 16x16x32 kernel; pipelined: 0.76 PF, 1.36 vs 1.93 ms for a 4,096-row piece against 20k keys.)
+//
+// Ring of NSTAGE = 10 tile stages = five pair-stages (the register budget allows one block per CU anyway).  At the top of the
+// iteration of pair P = (t, t+1): pairs P-1 (its second tile still owes its P.V), P and P+1 have landed (counted vmcnt: only pair P+2,
+// issued one iteration ago, may still be in flight; barrier: every wave's pieces), every wave is done with pair P-2, whose stages
+// receive pair P+3.  The iteration enters with sc_a = K.Q^T of tile t and leaves with sc_a = K.Q^T of tile t+2.
+// LDS image of a stage: KP = D/16 K pieces (32 keys x 16 d each, rows in swap23 order) then VP = 2 * ceil(D/32) V^T pieces
+// (32 d rows x 16 keys each), every piece 1 KB in MFMA fragment (lane) order.
+//   mlim: tiles reaching past it need the mask (causal diagonal / end of the key range); lim: this lane's effective key limit.
+template <int D, int PW, class Issue>
+LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf)[D / 16], int tb, int te, int mlim, int lim, float scale_log2e,
+                                bool active, int lane, int hh, f32x16 (&o)[(D + 31) / 32], float& m_run, float& l_run) {
+  constexpr int KP = D / 16, DT = (D + 31) / 32, VP = 2 * DT, NP = KP + VP, NSTAGE = 10;
+  auto stage_of = [&](int t) { return alds + ((t - tb) % NSTAGE) * (NP * 64); };
+  bf16x8 p_prev[2];                                     // P of the previous tile, its P . V still pending
+  p_prev[0] = as_bf16x8((u32x4){0u, 0u, 0u, 0u});
+  p_prev[1] = p_prev[0];
+  const u32x4* v_prev = alds;                           // V stage of that tile (while nothing is pending P = 0: any landed stage will do)
+  f32x16 sc_a, sc_b;
+
+  auto region = [&](auto masked_tag, int t, f32x16& sc_cur, f32x16& sc_nxt) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const u32x4* vs = v_prev;
+    const u32x4* kn = stage_of(t + 1);
+    // matrix pipe: P.V of tile t-1 ...
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(vs[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
+    // ... and K.Q^T of tile t+1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc_nxt[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) sc_nxt = mfma32(as_bf16x8(kn[ks * 64 + lane]), as_bf16x8(qf[ks]), sc_nxt);
+    // vector pipe: softmax of tile t
+    const int kb = t * 32;
+    if (MASKED) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc_cur[r] = (kb + 16 * (r >> 3) + 8 * hh + (r & 7)) < lim ? sc_cur[r] : -INFINITY;
+    }
+    float mx = vmax3(sc_cur[0], sc_cur[1], sc_cur[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = vmax3(mx, sc_cur[r], sc_cur[r + 1]);
+    mx = vmax(mx, sc_cur[15]);
+    mx = xor32_max(mx);
+    const float m_new = vmax(m_run, mx * scale_log2e);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);       // m_run = -inf -> 0
+    m_run = m_new;
+    float p[16], psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(sc_cur[r], scale_log2e, -m_use));   // masked scores are -inf -> 0
+      psum += p[r];
+    }
+    l_run = l_run * alpha + psum;
+    bf16x8 pn[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+      pn[ss] = as_bf16x8((u32x4){pack2(p[8 * ss + 0], p[8 * ss + 1]), pack2(p[8 * ss + 2], p[8 * ss + 3]),
+                                 pack2(p[8 * ss + 4], p[8 * ss + 5]), pack2(p[8 * ss + 6], p[8 * ss + 7])});
+    // keep the exponentials and the packing of P INSIDE this region: P is only consumed by the next region's MFMAs, and LLVM otherwise
+    // sinks its computation behind the rescale branch below, where no matrix work is left to hide it
+    {
+      u32x4 w0 = as_u32x4(pn[0]), w1 = as_u32x4(pn[1]);
+      asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(l_run));
+      pn[0] = as_bf16x8(w0); pn[1] = as_bf16x8(w1);
+    }
+    // issue order: a few fragment reads ahead, then per MFMA one more read and a handful of vector instructions
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < NP - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, (MASKED ? 7 : 5) * 16 / NP, 0);
+    }
+    // region boundary: the accumulators now hold tiles <= t-1 at the OLD maximum; bring them to the new one before tile t's P.V.
+    // Lazy: once the running maximum has settled alpha is exactly 1.0 in every lane and the multiplies are skipped (x * 1.0f is
+    // exact: bit-identical to always rescaling)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    p_prev[0] = pn[0]; p_prev[1] = pn[1];
+    v_prev = stage_of(t);
+  };
+
+  issue(tb); issue(tb + 1); issue(tb + 2); issue(tb + 3); issue(tb + 4); issue(tb + 5);
+  for (int t = tb; t < te; t += 2) {
+    if (PW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (PW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(t + 6); issue(t + 7);
+    if (!active) continue;
+    if (t == tb) {
+      const u32x4* k0 = stage_of(tb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc_a[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KP; ++ks) sc_a = mfma32(as_bf16x8(k0[ks * 64 + lane]), as_bf16x8(qf[ks]), sc_a);
+    }
+    if ((t + 1) * 32 > mlim) region(std::true_type{}, t, sc_a, sc_b); else region(std::false_type{}, t, sc_a, sc_b);
+    if ((t + 2) * 32 > mlim) region(std::true_type{}, t + 1, sc_b, sc_a); else region(std::false_type{}, t + 1, sc_b, sc_a);
+  }
+  if (active && te > tb) {     // the last tile's P.V (an empty key range never filled the ring: nothing to flush, and 0 x garbage = NaN)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(v_prev[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this block may land after it has left the CU
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// LLM prefill (causal, GQA): grid = (query tiles, KV heads, key splits); NWAVE waves: wave w < G computes query head hk * G + w, every
+// wave feeds the DMA ring.  Tile tables as attn_prefill_kernel: stream slot, first row in q, valid rows (<= 32), cache index of row 0.
 template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
     const bf16_t* __restrict__ q, bf16_t* __restrict__ out, const int32_t* __restrict__ tile_stream,
@@ -112,121 +236,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
   int min_limit = key_limit;                             // wave-wide minimum of the key limits: tiles entirely below it need no mask
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_limit = min(min_limit, __shfl_xor(min_limit, off, 64));
-
-  // ---- software pipeline, one key tile per REGION: the softmax of tile t (vector pipe: ~70 VALU instructions) is issued next to 16
-  //      MFMAs (matrix pipe: 512 cycles) that do not depend on it -- the P . V of tile t-1 and the K . Q^T of tile t+1 -- in ONE
-  //      scheduling region, interleaved by sched_group_barrier.  A wave then always has matrix AND vector work in flight (with one
-  //      tile at a time per wave, the two waves of a SIMD ran the same phase in lock step behind the block barrier: the first version
-  //      of this kernel, 0.57 PF at 8 x 386 rows x 6k keys vs 0.54 for the 16x16x32 kernel).
-  auto stage_of = [&](int t) { return alds + ((t - tb) % NSTAGE) * (NP * 64); };
-  const int mlim = min(min_limit, te * 32);             // tiles reaching past it need the mask (causal diagonal / end of this split)
-  const int lim = min(key_limit, te * 32);              // this lane's effective key limit
-  bf16x8 p_prev[2];                                     // P of the previous tile, its P . V still pending
-  p_prev[0] = as_bf16x8((u32x4){0u, 0u, 0u, 0u});
-  p_prev[1] = p_prev[0];
-  const u32x4* v_prev = alds;                           // V stage of that tile (while nothing is pending P = 0: any landed stage will do)
-  f32x16 sc_a, sc_b;
-
-  auto region = [&](auto masked_tag, int t, f32x16& sc_cur, f32x16& sc_nxt) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-    const u32x4* vs = v_prev;
-    const u32x4* kn = stage_of(t + 1);
-    // matrix pipe: P.V of tile t-1 ...
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(vs[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
-    // ... and K.Q^T of tile t+1
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc_nxt[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KP; ++ks) sc_nxt = mfma32(as_bf16x8(kn[ks * 64 + lane]), as_bf16x8(qf[ks]), sc_nxt);
-    // vector pipe: softmax of tile t
-    const int kb = t * 32;
-    if (MASKED) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc_cur[r] = (kb + 16 * (r >> 3) + 8 * hh + (r & 7)) < lim ? sc_cur[r] : -INFINITY;
-    }
-    float mx = vmax3(sc_cur[0], sc_cur[1], sc_cur[2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = vmax3(mx, sc_cur[r], sc_cur[r + 1]);
-    mx = vmax(mx, sc_cur[15]);
-    mx = xor32_max(mx);
-    const float m_new = vmax(m_run, mx * scale_log2e);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);       // m_run = -inf -> 0
-    m_run = m_new;
-    float p[16], psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = __builtin_amdgcn_exp2f(fmaf(sc_cur[r], scale_log2e, -m_use));   // masked scores are -inf -> 0
-      psum += p[r];
-    }
-    l_run = l_run * alpha + psum;
-    bf16x8 pn[2];
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss)
-      pn[ss] = as_bf16x8((u32x4){pack2(p[8 * ss + 0], p[8 * ss + 1]), pack2(p[8 * ss + 2], p[8 * ss + 3]),
-                                 pack2(p[8 * ss + 4], p[8 * ss + 5]), pack2(p[8 * ss + 6], p[8 * ss + 7])});
-    // keep the exponentials and the packing of P INSIDE this region: P is only consumed by the next region's MFMAs, and LLVM otherwise
-    // sinks its computation behind the rescale branch below, where no matrix work is left to hide it
-    {
-      u32x4 w0 = as_u32x4(pn[0]), w1 = as_u32x4(pn[1]);
-      asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(l_run));
-      pn[0] = as_bf16x8(w0); pn[1] = as_bf16x8(w1);
-    }
-    // issue order: a few fragment reads ahead, then per MFMA one more read and a handful of vector instructions
-    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 13) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, MASKED ? 7 : 5, 0);
-    }
-    // region boundary: the accumulators now hold tiles <= t-1 at the OLD maximum; bring them to the new one before tile t's P.V.
-    // Lazy: once the running maximum has settled alpha is exactly 1.0 in every lane and the 64 multiplies are skipped (x * 1.0f is
-    // exact: bit-identical to always rescaling)
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    p_prev[0] = pn[0]; p_prev[1] = pn[1];
-    v_prev = stage_of(t);
-  };
-
-  // Ring of NSTAGE = 10 tile stages = five pair-stages (160 KB: the whole LDS of the CU; the register budget allows one block per
-  // CU anyway).  At the top of the iteration of pair P = (t, t+1): pairs P-1 (its second tile still owes its P.V), P and P+1 have
-  // landed (counted vmcnt: only pair P+2, issued one iteration ago, may still be in flight; barrier: every wave's pieces), every
-  // wave is done with pair P-2, whose stages receive pair P+3 -- every DMA has TWO iterations to land (with one iteration of lead
-  // the loop ran at the DMA round trip: 2.2 us per pair at 8 x 386 rows x 6k keys against 1 us of MFMA work).
-  // The iteration enters with sc_a = K.Q^T of tile t and leaves with sc_a = K.Q^T of tile t+2.
-  issue(tb); issue(tb + 1); issue(tb + 2); issue(tb + 3); issue(tb + 4); issue(tb + 5);
-  for (int t = tb; t < te; t += 2) {
-    if (PW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(t + 6); issue(t + 7);
-    if (!active) continue;
-    if (t == tb) {
-      const u32x4* k0 = stage_of(tb);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sc_a[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KP; ++ks) sc_a = mfma32(as_bf16x8(k0[ks * 64 + lane]), as_bf16x8(qf[ks]), sc_a);
-    }
-    if ((t + 1) * 32 > mlim) region(std::true_type{}, t, sc_a, sc_b); else region(std::false_type{}, t, sc_a, sc_b);
-    if ((t + 2) * 32 > mlim) region(std::true_type{}, t + 1, sc_b, sc_a); else region(std::false_type{}, t + 1, sc_b, sc_a);
-  }
-  if (active && te > tb) {     // the last tile's P.V (an empty key range never filled the ring: nothing to flush, and 0 x garbage = NaN)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(v_prev[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA of this block may land after it has left the CU
+  attn32_key_loop<D, PW>(alds, issue, qf, tb, te, min(min_limit, te * 32), min(key_limit, te * 32), scale_log2e, active, lane, hh, o, m_run, l_run);
   if (!active) return;
 
   float l = xor32_sum(l_run);
@@ -255,6 +265,102 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
         st8(op + dt * 32 + 8 * r4 + 4 * hh, (u32x2){pack2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv),
                                                    pack2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv)});
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// ViT attention (Q2VL:375-417: non-causal inside each temporal slice, d = 80) on the same key loop.  grid = (groups of NWAVE x 32
+// query rows of ONE segment, heads): wave w owns the 32 rows q0 + 32 w of the group, all waves share the segment's K / V^T tiles of
+// this head through the ring.  d = 80 is 5 k-steps of the 32x32x16 MFMA for K.Q^T (no padding; the 16x16x32 kernel pads 80 -> 96)
+// and 3 d-tiles for O^T (the third half empty: its V^T rows 80..95 come from a zero page).  qkv = [P, 3E] with q, k rotated in place,
+// vt = V blocked-transposed [head][32-key block][80][32] (vit_rope_vt_kernel); keys past the segment end are masked, and the K rows of
+// the last (partial) tile are clamped into the segment (the next segment's rows are NOT part of this attention).
+template <int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const int32_t* __restrict__ grp_seg,
+    const int32_t* __restrict__ grp_q0, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+    const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e) {
+  constexpr int D = 80, KP = 5, DT = 3, VP = 6, NP = KP + VP, NSTAGE = 10, PW = (NP + NWAVE - 1) / NWAVE;
+  extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, hh = lane >> 5;
+  const int grp = blockIdx.x, h = blockIdx.y, E = heads * D, ld = 3 * E;
+  const int sg = grp_seg[grp], q0 = grp_q0[grp] + wave * 32;
+  const int s0 = seg_start[sg], sl = seg_len[sg];
+  const bf16_t* kbase = qkv + (size_t)s0 * ld + E + h * D;
+  const bf16_t* vbase = vt + ((size_t)h * total_blocks + seg_blk_start[sg]) * (D * 32);
+  const int nkeys = sl, ntile = (nkeys + 31) / 32;
+  const bool active = q0 < sl;
+  const int nq = max(0, min(32, sl - q0));
+  const int qrow = min(q0 + min(col, max(nq - 1, 0)), sl - 1);      // clamped: inactive waves / surplus columns read a valid row
+
+  u32x4 qf[KP];
+  {
+    const bf16_t* qp = qkv + (size_t)(s0 + qrow) * ld + h * D + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) qf[ks] = ld16(qp + ks * 16);
+  }
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn32_zero_page) + lane * 8;
+  const bf16_t* pbase[PW];
+  size_t pstride[PW];
+  int pkrow[PW];                                         // K pieces: this lane's key row inside a tile (-1: not a K piece)
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int p = min(j * NWAVE + wave, NP - 1);
+    if (p < KP) {
+      pkrow[j] = swap23(col);
+      pbase[j] = kbase + (size_t)pkrow[j] * ld + p * 16 + hh * 8;
+      pstride[j] = (size_t)32 * ld;
+    } else {
+      const int dt = (p - KP) >> 1, s = (p - KP) & 1, d = dt * 32 + col;
+      pkrow[j] = -1;
+      pbase[j] = d < D ? vbase + (size_t)d * 32 + s * 16 + hh * 8 : zp;
+      pstride[j] = d < D ? (size_t)D * 32 : 0;
+    }
+  }
+  auto issue = [&](int t) {
+    const int tc = min(t, ntile - 1);
+    u32x4* sbase = alds + (t % NSTAGE) * (NP * 64);
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int p = min(j * NWAVE + wave, NP - 1);
+      const bf16_t* src = pbase[j] + (size_t)tc * pstride[j];
+      if (pkrow[j] >= 0 && tc == ntile - 1)              // last tile: rows past the segment end are clamped (and masked)
+        src = kbase + (size_t)min(tc * 32 + pkrow[j], nkeys - 1) * ld + p * 16 + hh * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
+    }
+  };
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  attn32_key_loop<D, PW>(alds, issue, qf, 0, ntile, sl, sl, scale_log2e, active, lane, hh, o, m_run, l_run);
+  const float l = xor32_sum(l_run);
+  if (!active || col >= nq) return;
+  const float inv = 1.f / l;
+  bf16_t* op = out + (size_t)(s0 + q0 + col) * E + h * D;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int d = dt * 32 + 8 * r4 + 4 * hh;
+      if (d < D)
+        st8(op + d, (u32x2){pack2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv), pack2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv)});
+    }
+}
+
+int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
+                      const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
+                      int total_blocks, float scale_log2e, hipStream_t st) {
+  if (n_groups <= 0) return 0;
+  constexpr size_t lds = (size_t)10 * 11 * 1024;
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  attn_vit32_kernel<8><<<dim3(n_groups, heads), dim3(512), lds, st>>>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads,
+                                                                      total_blocks, scale_log2e);
+  return 0;
 }
 
 // launcher: 32-row tiles only; the caller (attention.hip: attn_prefill_bf16) runs the split merge

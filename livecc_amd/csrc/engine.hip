@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -277,7 +278,7 @@ extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
   const size_t S = e->lim.max_new_rows, P = e->lim.max_patches, B = e->lim.max_slots;
   const size_t llm = (7 * S + 4 * (S / 16 + B + 1) + 4 * B + 64) * 4;
-  const size_t vit = (P + 7 * (P / 16 + 64) + 64) * 4;
+  const size_t vit = (P + 8 * (P / 16 + 64) + 64) * 4;
   return align_up(std::max(llm, vit) + 4096, 4096) * META_RING;
 }
 
@@ -306,7 +307,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
 extern "C" size_t lcc_engine_vit_workspace_bytes(const lcc_engine* e) { return e->vit_ws_bytes(); }
 extern "C" size_t lcc_engine_vit_meta_bytes(const lcc_engine* e) {
   const size_t P = e->lim.max_patches;
-  return align_up((P + 7 * (P / 16 + 64) + 64) * 4 + 4096, 4096) * 2;
+  return align_up((P + 8 * (P / 16 + 64) + 64) * 4 + 4096, 4096) * 2;
 }
 extern "C" int lcc_engine_bind_vit_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* meta_dev, void* meta_host_pinned,
                                            size_t meta_bytes) {
@@ -485,7 +486,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   hipStream_t st = (hipStream_t)stream;
   const int E = e->E, heads = e->c.vit_heads, MLP = e->c.vit_mlp, H = e->c.hidden_size, PD = e->c.patch_dim;
   // segment tables
-  std::vector<int32_t> seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0, grp_seg, grp_q0;
+  std::vector<int32_t> seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0, grp_seg, grp_q0, g8_seg, g8_q0;
   int P = 0, blocks = 0;
   for (int ci = 0; ci < n_clips; ++ci) {
     const lcc_clip& c = clips[ci];
@@ -497,6 +498,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
       seg_start.push_back(P); seg_len.push_back(n); seg_blk.push_back(blocks);
       for (int q = 0; q < n; q += 32) { tile_seg.push_back(sg); tile_q0.push_back(q); }
       for (int q = 0; q < n; q += 128) { grp_seg.push_back(sg); grp_q0.push_back(q); }
+      for (int q = 0; q < n; q += 256) { g8_seg.push_back(sg); g8_q0.push_back(q); }     // attention variant 3: 8 waves x 32 rows
       seg_of_patch.insert(seg_of_patch.end(), n, sg);
       P += n; blocks += (n + 31) / 32;
     }
@@ -526,11 +528,13 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   } else {
     LCC_TRY(meta_begin(e, &mw));
   }
-  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0, *d_grp_seg, *d_grp_q0;
+  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0, *d_grp_seg, *d_grp_q0, *d_g8_seg, *d_g8_q0;
+  const int n_groups8 = (int)g8_seg.size();
   if (!mw.put(seg_start.data(), n_seg, &d_seg_start) || !mw.put(seg_len.data(), n_seg, &d_seg_len) ||
       !mw.put(seg_blk.data(), n_seg, &d_seg_blk) || !mw.put(seg_of_patch.data(), P, &d_seg_of_patch) ||
       !mw.put(tile_seg.data(), n_tiles, &d_tile_seg) || !mw.put(tile_q0.data(), n_tiles, &d_tile_q0) ||
-      !mw.put(grp_seg.data(), n_groups, &d_grp_seg) || !mw.put(grp_q0.data(), n_groups, &d_grp_q0))
+      !mw.put(grp_seg.data(), n_groups, &d_grp_seg) || !mw.put(grp_q0.data(), n_groups, &d_grp_q0) ||
+      !mw.put(g8_seg.data(), n_groups8, &d_g8_seg) || !mw.put(g8_q0.data(), n_groups8, &d_g8_q0))
     return fail(LCC_ERR_STATE, "meta ring slot too small");
   if (own) HIP_TRY(hipMemcpyAsync(mw.dev, mw.host, mw.off, hipMemcpyHostToDevice, st));
   else LCC_TRY(meta_commit(&mw, st));
@@ -561,8 +565,15 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
     LCC_TRY(gemm_bf16(g, st));
     LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));
-    LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, d_grp_seg, d_grp_q0,
-                          n_groups, st));
+    // 32x32x16 kernel (8 waves x 32 rows per block) once its grid fills the chip: 8 streams' chunks = 768 blocks, 170 vs 359 us per
+    // block of the tower; ONE 2-frame chunk is only 6 groups x 16 heads = 96 blocks (49 us) -- there the 16-row-per-wave LDS-shared
+    // kernel with twice the blocks stays (41 us)
+    if (get_attn_variant() == 3 && e->vit_hd == 80 && (long)n_groups8 * heads >= 224)
+      LCC_TRY(attn_vit32_launch(qkv, vt, attn, d_g8_seg, d_g8_q0, d_seg_start, d_seg_len, d_seg_blk, n_groups8, heads, blocks,
+                                1.4426950408889634f / sqrtf(80.f), st));
+    else
+      LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, d_grp_seg, d_grp_q0,
+                            n_groups, st));
     g = GemmArgs(); g.w_packed = 1; g.A = attn; g.lda = E; g.W = L.proj_w; g.ldw = E; g.bias = L.proj_b; g.residual = x; g.ldr = E; g.C = x; g.ldc = E;
     g.M = P; g.N = E; g.K = E; g.epilogue = LCC_EPI_RESIDUAL;
     LCC_TRY(gemm_bf16(g, st));
@@ -1166,6 +1177,13 @@ extern "C" int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, con
   if (n_groups > 0 && (!grp_seg || !grp_q0)) return fail(LCC_ERR_ARG, "null group table");
   OP_RET(attn_vit_bf16((const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, tile_seg, tile_q0, seg_start, seg_len, seg_blk_start, n_tiles,
                        heads, total_blocks, grp_seg, grp_q0, n_groups, (hipStream_t)stream), "lcc_attn_vit_bf16");
+}
+extern "C" int lcc_attn_vit32_bf16(const void* qkv, const void* vt, void* out, const int32_t* grp_seg, const int32_t* grp_q0,
+                                   const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
+                                   int total_blocks, void* stream) {
+  if (!qkv || !vt || !out || !grp_seg || !grp_q0 || !seg_start || !seg_len || !seg_blk_start) return fail(LCC_ERR_ARG, "null pointer");
+  OP_RET(attn_vit32_launch((const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads,
+                           total_blocks, 1.4426950408889634f / sqrtf(80.f), (hipStream_t)stream), "lcc_attn_vit32_bf16");
 }
 extern "C" int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream) {
   if (!pos3 || !inv_freq || !cos || !sin) return fail(LCC_ERR_ARG, "null pointer");

@@ -105,6 +105,10 @@ int gather_rows_bf16(const bf16_t* in, const int32_t* rows, bf16_t* out, int n, 
 // ---- attention (attention.hip) ----
 void set_attn_variant(int v);
 int get_attn_variant();
+// ViT attention on 32x32x16 MFMAs (attn32.hip): groups of 8 x 32 query rows of one segment (grp_seg / grp_q0, 256-row groups)
+int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
+                      const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
+                      int total_blocks, float scale_log2e, hipStream_t st);
 // LLM prefill attention on 32-row tiles / 32x32x16 MFMAs (attn32.hip); partials in the layout of attn_prefill_combine_kernel
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,

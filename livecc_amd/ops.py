@@ -120,8 +120,12 @@ def launch_counts(reset: bool = False) -> dict:
     return {k: int(buf[i]) for i, k in enumerate(LAUNCH_COUNTERS)}
 
 
+_ATTN_VARIANT = [ATTN_DEFAULT_VARIANT]
+
+
 def set_attn_variant(v: int) -> None:
     _lib.load().lcc_debug_set_attn_variant(int(v))
+    _ATTN_VARIANT[0] = int(v)
 
 
 def set_gemm_variant(v: int) -> None:
@@ -196,6 +200,7 @@ def _i32(a, device) -> torch.Tensor:
 def vit_segments(grids: Sequence[Sequence[int]], device):
     """Segment / tile tables of the ViT attention for clips with grids (t,h,w): one segment per temporal slice."""
     seg_start, seg_len, seg_blk, seg_of_patch, tile_seg, tile_q0, grp_seg, grp_q0 = [], [], [], [], [], [], [], []
+    g8_seg, g8_q0 = [], []        # groups of 8 x 32 rows (attention variant 3, attn_vit32_kernel)
     P = blocks = 0
     for t, h, w in grids:
         n = h * w
@@ -206,11 +211,14 @@ def vit_segments(grids: Sequence[Sequence[int]], device):
                 tile_seg.append(sg); tile_q0.append(q)
             for q in range(0, n, 128):
                 grp_seg.append(sg); grp_q0.append(q)
+            for q in range(0, n, 256):
+                g8_seg.append(sg); g8_q0.append(q)
             seg_of_patch += [sg] * n
             P += n; blocks += (n + 31) // 32
     d = dict(seg_start=_i32(seg_start, device), seg_len=_i32(seg_len, device), seg_blk=_i32(seg_blk, device),
              seg_of_patch=_i32(seg_of_patch, device), tile_seg=_i32(tile_seg, device), tile_q0=_i32(tile_q0, device),
              grp_seg=_i32(grp_seg, device), grp_q0=_i32(grp_q0, device), n_groups=len(grp_seg),
+             g8_seg=_i32(g8_seg, device), g8_q0=_i32(g8_q0, device), n_groups8=len(g8_seg),
              P=P, blocks=blocks, n_tiles=len(tile_seg))
     return d
 
@@ -226,6 +234,11 @@ def vit_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, grids
                                         _chk(sin, torch.float32, "sin"), seg["seg_of_patch"].data_ptr(),
                                         seg["seg_start"].data_ptr(), seg["seg_blk"].data_ptr(), vt.data_ptr(), P, heads,
                                         seg["blocks"], _st(qkv)), "lcc_vit_rope_vt_bf16")
+    if _ATTN_VARIANT[0] == 3:
+        _lib.check(lib.lcc_attn_vit32_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg["g8_seg"].data_ptr(), seg["g8_q0"].data_ptr(),
+                                           seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(), seg["seg_blk"].data_ptr(), seg["n_groups8"],
+                                           heads, seg["blocks"], _st(qkv)), "lcc_attn_vit32_bf16")
+        return out
     _lib.check(lib.lcc_attn_vit_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg["tile_seg"].data_ptr(),
                                      seg["tile_q0"].data_ptr(), seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(),
                                      seg["seg_blk"].data_ptr(), seg["n_tiles"], heads, seg["blocks"], seg["grp_seg"].data_ptr(),

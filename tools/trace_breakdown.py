@@ -62,6 +62,36 @@ def breakdown(rows, n_layers=28):
     for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
         out["kernels"][name] = dict(calls_per_step=round(c / n, 2), avg_us=round(t / c, 2), us_per_step=round(t / n, 2))
     out["prefill"] = prefill
+    out["vit"] = vit_breakdown(rows)
+    return out
+
+
+def vit_breakdown(rows):
+    """Vision-tower calls on the main stream (bench --no-prefetch): from `patchify_norm_kernel` (or the fp32 -> bf16 cast of
+    pixel_values) to the last kernel before the next `seen_set_kernel` (= the start of the LLM prefill that consumes the embeddings)."""
+    calls, cur = [], None
+    for s, e, name, q in rows:
+        if cur is None and name.startswith(("patchify_norm_kernel", "cast_f32_bf16")):
+            cur = dict(queue=q, kernels=[])
+        if cur is not None and q == cur["queue"]:
+            if name.startswith("seen_set_kernel"):
+                calls.append(cur)
+                cur = None
+            else:
+                cur["kernels"].append((s, e, name))
+    per_kernel = defaultdict(lambda: [0, 0.0])
+    wall = busy = 0.0
+    for c in calls:
+        ks = c["kernels"]
+        wall += (ks[-1][1] - ks[0][0]) / 1e3
+        for s, e, name in ks:
+            per_kernel[name][0] += 1
+            per_kernel[name][1] += (e - s) / 1e3
+            busy += (e - s) / 1e3
+    n = max(1, len(calls))
+    out = dict(vit_calls=len(calls), avg_call_us=round(wall / n, 1), avg_kernel_time_per_call_us=round(busy / n, 1), kernels={})
+    for name, (c, t) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:16]:
+        out["kernels"][name] = dict(calls_per_vit=round(c / n, 2), avg_us=round(t / c, 2), us_per_vit=round(t / n, 1))
     return out
 
 
