@@ -186,22 +186,27 @@ int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode use
 
 /* ---- decode pipeline v2 (csrc/decode_v2.hip): one new token per stream (M <= 4 rows), the elementwise stages of the decoder layer
  * run INSIDE the weight-streaming GEMVs.  Residual stream h [M,K] bf16 + `stats` fp32 [M, K/16]: per-16-channel sums of squares of h,
- * the input of the RMSNorm prologue (Q2VL:96-110) of the next GEMV; K % 64 == 0, K <= 8192, M*K <= 16384.  W = MFMA-fragment-packed. */
+ * the input of the RMSNorm prologue (Q2VL:96-110) of the next GEMV; K % 64 == 0, K <= 8192, M*K <= 16384.  W = MFMA-fragment-packed bf16
+ * (`wscale` NULL) or, round 3, OCP e4m3 bytes in the PACKED8 order of lcc_gemm_w8_bf16 with `wscale` = fp32 scale per STORED row
+ * (for the row-permuted q|k|v decode copy: the permuted scales): e4m3 -> bf16 exactly in registers, bf16 MFMA, fp32 accumulate,
+ * scale applied to the fp32 sum before the epilogue -- the fp8 weight path (BASELINE configs[4]) on the 6-launch decode layer. */
 /* step prologue (was seen_set + embed_gather + mrope_table_decode): marks cur_tok[slot] in the slot's seen-id bitmap (unless done),
  * h[b] = embedding row (Q2VL:1160) + its stats, cos/sin[b] = M-RoPE row of pos[slot] (Q2VL:1349-1351: one position on all axes) */
 int lcc_decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_t* done, uint32_t* seen, int words_per_stream,
                           const void* embed_table, void* h, float* stats, int dim, const int32_t* pos, const float* inv_freq,
                           void* cos, void* sin, int B, void* stream);
 /* C = Linear(RMSNorm(h) * norm_w) (+bias); swiglu = 1: W rows interleaved [16 gate | 16 up], C[:, N/2] = silu(g) * u (Q2VL:453-466) */
-int lcc_dgemv_norm_linear(const void* W_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
-                          void* C, int ldc, int M, int N, int K, int swiglu, void* stream);
+int lcc_dgemv_norm_linear(const void* W_packed, const float* wscale, const void* h, const float* stats, const void* norm_w, float eps,
+                          const void* bias, void* C, int ldc, int M, int N, int K, int swiglu, void* stream);
 /* h += Linear(x) in place (HF rounding: Linear output -> bf16, residual add -> bf16, Q2VL:594-612); stats_out [M, N/16] of the new h.
  * o_proj and down_proj: no inter-block K split, 8 waves per 16-row block. */
-int lcc_dgemv_resid(const void* W_packed, const void* x, int ldx, void* h, float* stats_out, int M, int N, int K, void* stream);
+int lcc_dgemv_resid(const void* W_packed, const float* wscale, const void* x, int ldx, void* h, float* stats_out, int M, int N, int K,
+                    void* stream);
 /* q|k|v Linear of RMSNorm(h) + bias + M-RoPE (Q2VL:180-222) + in-place KV append at kv_len[tok_stream[m]] (cache_utils.py:127-146),
  * rotated q -> q_out [M, Hq*128].  W_dec = the q|k|v weight with rows permuted inside every 128-row head so that each 16-row tile
  * holds 8 channels and their rotation partners: stored row j*16 + half*8 + i = logical row half*64 + j*8 + i (weights.py). */
-int lcc_dgemv_qkv_rope(const void* W_dec_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
+int lcc_dgemv_qkv_rope(const void* W_dec_packed, const float* wscale, const void* h, const float* stats, const void* norm_w, float eps,
+                       const void* bias,
                        const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* kv_len, void* const* kv_base,
                        lcc_kv_layout lay, int layer, void* q_out, int n_q_heads, int M, int K, void* stream);
 /* the chained launch as an operator (tests): h += Linear_down(x) with its tile statistics, then q|k|v of RMSNorm(h) as

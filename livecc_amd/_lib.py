@@ -119,9 +119,9 @@ def load():
                                             C.POINTER(f32), vp]),
         "lcc_embed_gather_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
         "lcc_decode_step_begin": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
-        "lcc_dgemv_norm_linear": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]),
-        "lcc_dgemv_resid": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, vp]),
-        "lcc_dgemv_qkv_rope": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp]),
+        "lcc_dgemv_norm_linear": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "lcc_dgemv_resid": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
+        "lcc_dgemv_qkv_rope": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp]),
         "lcc_seen_set": (i32, [vp, i32, vp, vp, i32, vp]),
         "lcc_sample_greedy": (i32, [vp, i32, i32, i32, vp, i32, vp, f32, i32, i32, f32, i32, i32, i32, vp, vp, vp, i32, vp,
                                     vp, vp, vp]),

@@ -45,6 +45,13 @@ LCC_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// 8 OCP e4m3 bytes (two dwords) -> 8 bf16 (exact): v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32
+LCC_DEVICE bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
+  const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
+  const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
+  return as_bf16x8((u32x4){pack2(a0[0], a0[1]), pack2(a1[0], a1[1]), pack2(b0[0], b0[1]), pack2(b1[0], b1[1])});
+}
+
 // wave-wide reductions (64 lanes)
 LCC_DEVICE float wave_sum(float v) {
 #pragma unroll

@@ -82,7 +82,7 @@ constexpr int dgemv_min_waves_per_simd() {
   return MR > 2 ? 1 : ((NTILE == 2 && PRO == DG_PRO_NORM && NW == 4) ? 5 : ((EPI == DG_EPI_ROPE && NW == 8) ? 4 : 1));
 }
 
-template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR, int CHAIN>
+template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR, int CHAIN, bool W8 = false>
 LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f32x4 (*red)[NTILE][64], bf16_t* s_x) {
   static_assert(EPI != DG_EPI_SWIGLU || NTILE == 2, "swiglu needs the gate and the up tile in one block");
   static_assert(EPI == DG_EPI_SWIGLU || NTILE == 1, "one tile per block");
@@ -97,25 +97,35 @@ LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f3
   const int nchunk = (K + 63) >> 6, K32 = (K + 31) >> 5;
   const int xm = min(li, M - 1);
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_v2) + g * 8;
-  const bf16_t* xp = PRO == DG_PRO_PLAIN ? a.X + (size_t)xm * a.ldx + g * 8 : nullptr;
+  // fp8 weights (W8): a 64-k chunk of a 16-row tile is ONE 1-KB fragment (lane (g, row) owns the 16 bytes k = c*64 + g*16 .. +15), fed
+  // to two MFMAs (bytes 0-7, 8-15) whose activation fragments follow the same k assignment: x[c*64 + g*16 + h*8 .. +8]
+  const bf16_t* xp = PRO == DG_PRO_PLAIN ? a.X + (size_t)xm * a.ldx + (W8 ? g * 16 : g * 8) : nullptr;
   const bf16_t* wp[NTILE];
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) wp[t] = a.W + (size_t)((n0 >> 4) + t) * K32 * 512 + lane * 8;
+  for (int t = 0; t < NTILE; ++t)
+    wp[t] = W8 ? reinterpret_cast<const bf16_t*>(reinterpret_cast<const uint8_t*>(a.W) + (size_t)((n0 >> 4) + t) * nchunk * 1024 + lane * 16)
+               : a.W + (size_t)((n0 >> 4) + t) * K32 * 512 + lane * 8;
 
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  struct Stage { u32x4 w[UNR][2][NTILE]; u32x4 x[XLDS ? 1 : UNR][2]; };
+  struct Stage { u32x4 w[UNR][W8 ? 1 : 2][NTILE]; u32x4 x[XLDS ? 1 : UNR][2]; };
   auto load_w = [&](int c0, Stage& s) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int cc = c0 + u * NW;
+      if (W8) {
+        const int ccl = min(cc, nchunk - 1);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int kbc = min(2 * cc + h, K32 - 1);
+        for (int t = 0; t < NTILE; ++t) s.w[u][0][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)ccl * 512));   // 1 KB per chunk
+      } else {
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) s.w[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)kbc * 512));
+        for (int h = 0; h < 2; ++h) {
+          const int kbc = min(2 * cc + h, K32 - 1);
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) s.w[u][W8 ? 0 : h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)kbc * 512));
+        }
       }
     }
   };
@@ -127,9 +137,9 @@ LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f3
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kb = 2 * cc + h;
-        const bool ok = cc < nchunk && kb < K32;              // wave-uniform: an absent block multiplies by a zero activation
+        const bool ok = cc < nchunk && (W8 || kb < K32);      // wave-uniform: an absent block multiplies by a zero activation
         const int kbc = min(kb, K32 - 1);
-        s.x[u][h] = ld16(ok ? xp + kbc * 32 : zp);
+        s.x[u][h] = ld16(ok ? (W8 ? xp + min(cc, nchunk - 1) * 64 + h * 8 : xp + kbc * 32) : zp);
       }
     }
   };
@@ -141,12 +151,14 @@ LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f3
         u32x4 xf;
         if (XLDS) {
           const int cc = c0 + u * NW, kb = 2 * cc + h;
-          xf = (cc < nchunk && kb < K32) ? *reinterpret_cast<const u32x4*>(s_x + (size_t)xm * K + kb * 32 + g * 8) : (u32x4){0u, 0u, 0u, 0u};
+          const int xo = W8 ? cc * 64 + g * 16 + h * 8 : kb * 32 + g * 8;
+          xf = (cc < nchunk && (W8 || kb < K32)) ? *reinterpret_cast<const u32x4*>(s_x + (size_t)xm * K + xo) : (u32x4){0u, 0u, 0u, 0u};
         } else {
           xf = s.x[XLDS ? 0 : u][h];
         }
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(s.w[u][h][t]), as_bf16x8(xf), acc[t]);
+        for (int t = 0; t < NTILE; ++t)
+          acc[t] = mfma16(W8 ? fp8x8_to_bf16x8(s.w[u][0][t][2 * h], s.w[u][0][t][2 * h + 1]) : as_bf16x8(s.w[u][W8 ? 0 : h][t]), as_bf16x8(xf), acc[t]);
       }
   };
 
@@ -262,9 +274,11 @@ LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f3
   __syncthreads();
   if (wave > 0) return;
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t)
+  for (int t = 0; t < NTILE; ++t) {
 #pragma unroll
     for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
+    if (W8) acc[t] *= *reinterpret_cast<const f32x4*>(a.wscale + min(n0 + t * 16 + g * 4, N - 4));   // per-stored-row dequantisation scale
+  }
 
   if (EPI == DG_EPI_BF16) {
     if (li >= M) return;
@@ -344,11 +358,11 @@ LCC_DEVICE void dgemv_body(const DgArgs& a, const DgChain& ch, const int bid, f3
   }
 }
 
-template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR = 4>
+template <int NTILE, int PRO, int EPI, int NW, int UNR, int MR = 4, bool W8 = false>
 __global__ __launch_bounds__(NW * 64, (dgemv_min_waves_per_simd<NTILE, PRO, EPI, NW, MR>())) void dgemv_kernel(DgArgs a) {
   __shared__ f32x4 red[NW - 1][NTILE][64];
   extern __shared__ __attribute__((aligned(16))) bf16_t s_x[];   // PRO_NORM: M * K bf16 (dynamic: 7 KB for one stream at 7B)
-  dgemv_body<NTILE, PRO, EPI, NW, UNR, MR, DG_CHAIN_NONE>(a, DgChain{nullptr, 0u, nullptr, 0}, blockIdx.x, red, s_x);
+  dgemv_body<NTILE, PRO, EPI, NW, UNR, MR, DG_CHAIN_NONE, W8>(a, DgChain{nullptr, 0u, nullptr, 0}, blockIdx.x, red, s_x);
 }
 
 // down_proj of layer l (blocks [0, nb_down): producer, publishes the residual stream + its tile statistics) and the q/k/v GEMV of
@@ -408,6 +422,7 @@ int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_
 static int dg_check(const DgArgs& a, int pro, int epi) {
   g_launch_counts[LC_DGEMV_V2]++;
   if (a.M < 1 || a.M > 16 || (a.N & 15) || (a.K & 31) || a.W == nullptr) return LCC_ERR_SHAPE;
+  if (a.wscale != nullptr && (a.K & 63)) return LCC_ERR_SHAPE;       // fp8 weights: whole 64-k fragments
   if (pro == DG_PRO_PLAIN && (a.X == nullptr || (a.ldx & 7))) return LCC_ERR_ARG;
   if (pro == DG_PRO_NORM && (a.H == nullptr || a.stats == nullptr || a.norm_w == nullptr || a.n_stat != (a.K >> 4) || (a.n_stat & 3) ||
                              a.M > 4 || a.M * a.K > 16384 || a.n_stat > 512)) return LCC_ERR_ARG;
@@ -423,6 +438,11 @@ static int dg_check(const DgArgs& a, int pro, int epi) {
 // [RMSNorm] q/k/v Linear [bias + M-RoPE + KV append]: W = the row-permuted decode copy of the fused q|k|v weight
 int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_ROPE)) return rc;
+  if (a.wscale != nullptr) {     // fp8 weights (half the bytes per chunk: UNR 4 is 4 KB in flight per wave and stage)
+    if (a.M <= 2) dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 2, true><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
+    else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 4, true><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
+    return 0;
+  }
   if (a.M <= 2) dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 2><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
   else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 4><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
@@ -430,6 +450,7 @@ int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
 // o_proj / down_proj: x plain, residual add in place + per-tile sums of squares
 int dgemv_resid(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
+  if (a.wscale != nullptr) { dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4, 4, true><<<dim3(a.N / 16), dim3(512), 0, st>>>(a); return 0; }
   static const int unr3 = [] { const char* v = getenv("LCC_RESID_UNR3"); return v ? atoi(v) : 0; }();   // diagnostic A/B
   if (unr3) dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 3><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
   else dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
@@ -466,6 +487,11 @@ int dgemv_down_qkv(const DgArgs& down, const DgArgs& qkv, unsigned* flag, unsign
 // [RMSNorm] gate/up Linear [SwiGLU]
 int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_SWIGLU)) return rc;
+  if (a.wscale != nullptr) {     // fp8: two chunks per stage keep the bytes in flight of the bf16 kernel
+    if (a.M <= 2) dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 2, 2, true><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+    else dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 2, 4, true><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+    return 0;
+  }
   if (a.M <= 2) dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 1, 2><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
   else dgemv_kernel<2, DG_PRO_NORM, DG_EPI_SWIGLU, 4, 1, 4><<<dim3(a.N / 32), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
@@ -473,6 +499,11 @@ int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st) {
 // [final RMSNorm] lm_head
 int dgemv_norm_bf16(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_NORM, DG_EPI_BF16)) return rc;
+  if (a.wscale != nullptr) {
+    if (a.M <= 2) dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 2, 2, true><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+    else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 2, 4, true><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
+    return 0;
+  }
   if (a.M <= 2) dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 1, 2><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
   else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_BF16, 4, 1, 4><<<dim3(a.N / 16), dim3(256), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;

@@ -89,6 +89,7 @@ struct LlmLayerW {
   const bf16_t *in_norm, *qkv_w, *qkv_b, *o_w, *post_norm, *gate_up_w, *down_w;
   const bf16_t* qkv_w_dec;   // optional row-permuted decode copy of qkv_w (decode pipeline v2), nullptr when absent
   const float *qkv_s, *o_s, *gate_up_s, *down_s;   // fp8 weights: per-output-row scales (nullptr for bf16 weights)
+  const float* qkv_s_dec;                          // scales of the row-permuted decode copy (fp8 arenas with decode copies)
 };
 
 struct Carver {  // bump allocator over a caller-provided region
@@ -363,8 +364,9 @@ static int resolve_weights(lcc_engine* e, std::string* missing) {
     L.in_norm = get(p + "in_norm"); L.qkv_w = get(p + "qkv_w"); L.qkv_b = get(p + "qkv_b"); L.o_w = get(p + "o_w");
     L.post_norm = get(p + "post_norm"); L.gate_up_w = get(p + "gate_up_w"); L.down_w = get(p + "down_w");
     { auto it = e->w.find(p + "qkv_w_dec"); L.qkv_w_dec = it == e->w.end() ? nullptr : (const bf16_t*)it->second; }
-    L.qkv_s = L.o_s = L.gate_up_s = L.down_s = nullptr;
+    L.qkv_s = L.o_s = L.gate_up_s = L.down_s = L.qkv_s_dec = nullptr;
     if (e->c.llm_fp8) {
+      { auto it = e->w.find(p + "qkv_w_dec.scale"); L.qkv_s_dec = it == e->w.end() ? nullptr : (const float*)it->second; }
       L.qkv_s = (const float*)get(p + "qkv_w.scale"); L.o_s = (const float*)get(p + "o_w.scale");
       L.gate_up_s = (const float*)get(p + "gate_up_w.scale"); L.down_s = (const float*)get(p + "down_w.scale");
     }
@@ -772,9 +774,10 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
 
 int g_decode_path = 1;   // 1: decode pipeline v2 (decode_v2.hip: 6 launches per layer) where eligible; 0: the round-1 launch sequence
 bool decode_v2_ok(const lcc_engine* e) {
-  if (g_decode_path != 1 || e->c.llm_fp8) return false;
+  if (g_decode_path != 1) return false;
   if ((e->c.hidden_size & 63) || e->c.hidden_size > 8192 || (e->c.intermediate_size & 31) || (e->qd & 31)) return false;
-  for (const LlmLayerW& L : e->llm) if (L.qkv_w_dec == nullptr) return false;
+  if (e->c.llm_fp8 && ((e->c.intermediate_size & 63) || (e->qd & 63))) return false;     // fp8: whole 64-k fragments
+  for (const LlmLayerW& L : e->llm) if (L.qkv_w_dec == nullptr || (e->c.llm_fp8 && L.qkv_s_dec == nullptr)) return false;
   return true;
 }
 // the 28 decoder layers of ONE decode step over B rows, v2 launch sequence.  On entry b.h / b.stats / b.cos / b.sin come from
@@ -792,28 +795,28 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
   // (a tap copy between the two halves would have to sit inside the launch).
   auto qkv_args = [&](int l) {
     const LlmLayerW& L = e->llm[l];
-    DgArgs a; a.W = L.qkv_w_dec; a.M = B; a.N = e->qkvd; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.in_norm;
+    DgArgs a; a.W = L.qkv_w_dec; a.wscale = L.qkv_s_dec; a.M = B; a.N = e->qkvd; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.in_norm;
     a.eps = eps; a.bias = L.qkv_b; a.cs = b.cos; a.sn = b.sin; a.tok_stream = d_slots; a.kv_len = e->d_kv_len; a.kv_base = e->d_kv_base;
     a.lay = e->lay; a.layer = l; a.q_out = b.q; a.n_q_heads = e->c.n_q_heads;
     return a;
   };
-  const bool chain = g_decode_chain && B <= 2 && e->c.n_layers <= 127 && !e->llm_taps && (long)B * H * 2 <= 16 * 1024 &&
+  const bool chain = g_decode_chain && !e->c.llm_fp8 && B <= 2 && e->c.n_layers <= 127 && !e->llm_taps && (long)B * H * 2 <= 16 * 1024 &&
                      H / 16 + e->qkvd / 16 <= dgemv_chain_capacity();
   for (int l = 0; l < e->c.n_layers; ++l) {
     const LlmLayerW& L = e->llm[l];
     DgArgs a;
     if (l == 0 || !chain) LCC_TRY(dgemv_qkv_rope(qkv_args(l), st));     // otherwise launched together with the previous layer's down_proj
     LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
-    a = DgArgs(); a.W = L.o_w; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
+    a = DgArgs(); a.W = L.o_w; a.wscale = L.o_s; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
     LCC_TRY(dgemv_resid(a, st));
     if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 1) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
-    a = DgArgs(); a.W = L.gate_up_w; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
+    a = DgArgs(); a.W = L.gate_up_w; a.wscale = L.gate_up_s; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
     a.eps = eps; a.C = b.act; a.ldc = I;
     const bool prof = e->prof_on && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();   // one sample per step
     if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
     LCC_TRY(dgemv_norm_swiglu(a, st));
     if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
-    a = DgArgs(); a.W = L.down_w; a.M = B; a.N = H; a.K = I; a.X = b.act; a.ldx = I; a.Hres = b.h; a.stats_out = b.stats;
+    a = DgArgs(); a.W = L.down_w; a.wscale = L.down_s; a.M = B; a.N = H; a.K = I; a.X = b.act; a.ldx = I; a.Hres = b.h; a.stats_out = b.stats;
     if (chain && l + 1 < e->c.n_layers) {
       const unsigned target = ++e->chain_epoch[l] * (unsigned)(H / 16);     // monotonic counter: every launch adds H/16 arrivals
       LCC_TRY(dgemv_down_qkv(a, qkv_args(l + 1), e->d_chain + l, target, e->d_chain + 128, st));
@@ -831,7 +834,7 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   bf16_t* logits = b.logits;
   if (sp && sp->logits_out) logits = (bf16_t*)sp->logits_out + (size_t)step_index * B * V;
   if (xn_rows == nullptr) {   // decode v2: final RMSNorm of b.h as the prologue of the lm_head GEMV
-    DgArgs a; a.W = e->lm_head; a.M = B; a.N = V; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = e->final_norm;
+    DgArgs a; a.W = e->lm_head; a.wscale = e->lm_head_s; a.M = B; a.N = V; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = e->final_norm;
     a.eps = e->c.rms_eps; a.C = logits; a.ldc = V;
     LCC_TRY(dgemv_norm_bf16(a, st));
   } else {
@@ -1359,25 +1362,27 @@ extern "C" int lcc_decode_step_begin(const int32_t* slots, const int32_t* cur_to
   OP_RET(decode_step_begin(slots, cur_tok, done, seen, words_per_stream, (const bf16_t*)embed_table, (bf16_t*)h, stats, dim, pos, inv_freq,
                            (bf16_t*)cos, (bf16_t*)sin, B, (hipStream_t)stream), "lcc_decode_step_begin");
 }
-extern "C" int lcc_dgemv_norm_linear(const void* W_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
-                                     void* C, int ldc, int M, int N, int K, int swiglu, void* stream) {
+extern "C" int lcc_dgemv_norm_linear(const void* W_packed, const float* wscale, const void* h, const float* stats, const void* norm_w, float eps,
+                                     const void* bias, void* C, int ldc, int M, int N, int K, int swiglu, void* stream) {
   if (!W_packed || !h || !stats || !norm_w || !C) return fail(LCC_ERR_ARG, "null pointer");
-  DgArgs a; a.W = (const bf16_t*)W_packed; a.M = M; a.N = N; a.K = K; a.H = (const bf16_t*)h; a.stats = stats; a.n_stat = K / 16;
+  DgArgs a; a.W = (const bf16_t*)W_packed; a.wscale = wscale; a.M = M; a.N = N; a.K = K; a.H = (const bf16_t*)h; a.stats = stats; a.n_stat = K / 16;
   a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.bias = (const bf16_t*)bias; a.C = (bf16_t*)C; a.ldc = ldc;
   if (swiglu) OP_RET(dgemv_norm_swiglu(a, (hipStream_t)stream), "lcc_dgemv_norm_linear");
   OP_RET(dgemv_norm_bf16(a, (hipStream_t)stream), "lcc_dgemv_norm_linear");
 }
-extern "C" int lcc_dgemv_resid(const void* W_packed, const void* x, int ldx, void* h, float* stats_out, int M, int N, int K, void* stream) {
+extern "C" int lcc_dgemv_resid(const void* W_packed, const float* wscale, const void* x, int ldx, void* h, float* stats_out, int M, int N, int K,
+                               void* stream) {
   if (!W_packed || !x || !h || !stats_out) return fail(LCC_ERR_ARG, "null pointer");
-  DgArgs a; a.W = (const bf16_t*)W_packed; a.M = M; a.N = N; a.K = K; a.X = (const bf16_t*)x; a.ldx = ldx; a.Hres = (bf16_t*)h; a.stats_out = stats_out;
+  DgArgs a; a.W = (const bf16_t*)W_packed; a.wscale = wscale; a.M = M; a.N = N; a.K = K; a.X = (const bf16_t*)x; a.ldx = ldx; a.Hres = (bf16_t*)h; a.stats_out = stats_out;
   OP_RET(dgemv_resid(a, (hipStream_t)stream), "lcc_dgemv_resid");
 }
-extern "C" int lcc_dgemv_qkv_rope(const void* W_dec_packed, const void* h, const float* stats, const void* norm_w, float eps, const void* bias,
+extern "C" int lcc_dgemv_qkv_rope(const void* W_dec_packed, const float* wscale, const void* h, const float* stats, const void* norm_w, float eps,
+                                  const void* bias,
                                   const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* kv_len, void* const* kv_base,
                                   lcc_kv_layout lay, int layer, void* q_out, int n_q_heads, int M, int K, void* stream) {
   if (!W_dec_packed || !h || !stats || !norm_w || !bias || !cos || !sin || !tok_stream || !kv_len || !kv_base || !q_out) return fail(LCC_ERR_ARG, "null pointer");
-  DgArgs a; a.W = (const bf16_t*)W_dec_packed; a.M = M; a.N = (n_q_heads + 2 * lay.n_kv_heads) * 128; a.K = K; a.H = (const bf16_t*)h; a.stats = stats;
-  a.n_stat = K / 16; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.bias = (const bf16_t*)bias; a.cs = (const bf16_t*)cos; a.sn = (const bf16_t*)sin;
+  DgArgs a; a.W = (const bf16_t*)W_dec_packed; a.wscale = wscale; a.M = M; a.N = (n_q_heads + 2 * lay.n_kv_heads) * 128; a.K = K; a.H = (const bf16_t*)h;
+  a.stats = stats; a.n_stat = K / 16; a.norm_w = (const bf16_t*)norm_w; a.eps = eps; a.bias = (const bf16_t*)bias; a.cs = (const bf16_t*)cos; a.sn = (const bf16_t*)sin;
   a.tok_stream = tok_stream; a.kv_len = kv_len; a.kv_base = (bf16_t* const*)kv_base; a.lay = to_lay(lay); a.layer = layer; a.q_out = (bf16_t*)q_out;
   a.n_q_heads = n_q_heads;
   OP_RET(dgemv_qkv_rope(a, (hipStream_t)stream), "lcc_dgemv_qkv_rope");

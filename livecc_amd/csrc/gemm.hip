@@ -27,13 +27,6 @@ namespace lcc {
 
 __device__ unsigned int lcc_zero_page[256];  // 1 KB of zeros: operand source of absent K chunks (address select, no branch)
 
-// 8 OCP e4m3 bytes (two dwords) -> 8 bf16 (exact): v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32
-LCC_DEVICE bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
-  const f32x2_t a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
-  const f32x2_t b0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
-  return as_bf16x8((u32x4){pack2(a0[0], a0[1]), pack2(a1[0], a1[1]), pack2(b0[0], b0[1]), pack2(b1[0], b1[1])});
-}
-
 // epilogue shared by the tiled kernels.  acc[i][j][r] = C[mbase + i*16 + li][nbase + j*16 + g*4 + r] (swapped operands).
 template <int EPI, int MT, int NT, int AM = MT, int AN = NT>   // the first MT x NT tiles of an AM x AN accumulator array
 LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[AM][AN], int mbase, int nbase, int ocbase, int li, int g,

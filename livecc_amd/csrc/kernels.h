@@ -146,6 +146,7 @@ int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, 
 // ---- decode layer pipeline v2 (decode_v2.hip): elementwise stages fused into the weight-streaming GEMVs ----
 struct DgArgs {
   const bf16_t* W = nullptr; int M = 0, N = 0, K = 0;
+  const float* wscale = nullptr;   // non-null: W = OCP e4m3 bytes in the PACKED8 order [N/16][K/64][4 g][16 rows][16 k] + this fp32 scale per stored row
   const bf16_t* X = nullptr; int ldx = 0;                                      // plain activation rows [M, K]
   const bf16_t* H = nullptr; const float* stats = nullptr; int n_stat = 0; const bf16_t* norm_w = nullptr; float eps = 0.f;  // RMSNorm prologue
   const bf16_t* bias = nullptr; bf16_t* C = nullptr; int ldc = 0;              // bf16 / SwiGLU epilogue

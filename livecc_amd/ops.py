@@ -405,34 +405,39 @@ def tile_stats(h: torch.Tensor) -> torch.Tensor:
     return h.float().pow(2).view(M, K // 16, 16).sum(-1).contiguous()
 
 
+def _w_ptr(w: torch.Tensor, wscale: Optional[torch.Tensor]) -> int:
+    """weight pointer of the dgemv operators: packed bf16, or (with `wscale`) e4m3 bytes in the PACKED8 order"""
+    return _chk(w, torch.uint8 if wscale is not None else torch.bfloat16, "w")
+
+
 def dgemv_norm_linear(w_packed: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, norm_w: torch.Tensor, eps: float, shape: Tuple[int, int],
-                      bias: Optional[torch.Tensor] = None, swiglu: bool = False) -> torch.Tensor:
+                      bias: Optional[torch.Tensor] = None, swiglu: bool = False, wscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     N, K = shape
     M = h.shape[0]
     out = torch.empty(M, N // 2 if swiglu else N, dtype=torch.bfloat16, device=h.device)
-    _lib.check(_lib.load().lcc_dgemv_norm_linear(_chk(w_packed, torch.bfloat16, "w"), _chk(h, torch.bfloat16, "h"), _chk(stats, torch.float32, "stats"),
+    _lib.check(_lib.load().lcc_dgemv_norm_linear(_w_ptr(w_packed, wscale), _chk(wscale, torch.float32, "wscale"), _chk(h, torch.bfloat16, "h"), _chk(stats, torch.float32, "stats"),
                                                  _chk(norm_w, torch.bfloat16, "norm_w"), float(eps), _chk(bias, torch.bfloat16, "bias"),
                                                  out.data_ptr(), out.shape[1], M, N, K, 1 if swiglu else 0, _st(h)), "lcc_dgemv_norm_linear")
     return out
 
 
-def dgemv_resid_(w_packed: torch.Tensor, x: torch.Tensor, h: torch.Tensor, shape: Tuple[int, int]) -> torch.Tensor:
+def dgemv_resid_(w_packed: torch.Tensor, x: torch.Tensor, h: torch.Tensor, shape: Tuple[int, int], wscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """h += Linear(x) in place; returns the per-tile sums of squares of the new h."""
     N, K = shape
     M = x.shape[0]
     stats = torch.empty(M, N // 16, dtype=torch.float32, device=h.device)
-    _lib.check(_lib.load().lcc_dgemv_resid(_chk(w_packed, torch.bfloat16, "w"), _chk(x, torch.bfloat16, "x"), x.shape[1], _chk(h, torch.bfloat16, "h"),
+    _lib.check(_lib.load().lcc_dgemv_resid(_w_ptr(w_packed, wscale), _chk(wscale, torch.float32, "wscale"), _chk(x, torch.bfloat16, "x"), x.shape[1], _chk(h, torch.bfloat16, "h"),
                                            stats.data_ptr(), M, N, K, _st(h)), "lcc_dgemv_resid")
     return stats
 
 
 def dgemv_qkv_rope(w_dec_packed: torch.Tensor, h: torch.Tensor, stats: torch.Tensor, norm_w: torch.Tensor, eps: float, bias: torch.Tensor,
                    cos: torch.Tensor, sin: torch.Tensor, tok_stream: torch.Tensor, kv_len: torch.Tensor, kv: "KvArena", layer: int,
-                   n_q_heads: int) -> torch.Tensor:
+                   n_q_heads: int, wscale: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, K = h.shape
     q = torch.empty(M, n_q_heads * 128, dtype=torch.bfloat16, device=h.device)
     _lib.check(_lib.load().lcc_dgemv_qkv_rope(
-        _chk(w_dec_packed, torch.bfloat16, "w"), _chk(h, torch.bfloat16, "h"), _chk(stats, torch.float32, "stats"), _chk(norm_w, torch.bfloat16, "norm_w"),
+        _w_ptr(w_dec_packed, wscale), _chk(wscale, torch.float32, "wscale"), _chk(h, torch.bfloat16, "h"), _chk(stats, torch.float32, "stats"), _chk(norm_w, torch.bfloat16, "norm_w"),
         float(eps), _chk(bias, torch.bfloat16, "bias"), _chk(cos, torch.bfloat16, "cos"), _chk(sin, torch.bfloat16, "sin"),
         _chk(tok_stream, torch.int32, "tok_stream"), _chk(kv_len, torch.int32, "kv_len"), kv.ptrs.data_ptr(), kv.lay, layer, q.data_ptr(),
         n_q_heads, M, K, _st(h)), "lcc_dgemv_qkv_rope")

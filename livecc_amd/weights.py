@@ -101,7 +101,7 @@ def fp8_weight_names(cfg: LiveCCConfig) -> List[str]:
     """The LLM Linear weights stored as fp8 when the arena is built with llm_fp8=True (ViT, embeddings, norms stay bf16)."""
     out = []
     for i in range(cfg.num_hidden_layers):
-        out += [f"llm.{i}.qkv_w", f"llm.{i}.o_w", f"llm.{i}.gate_up_w", f"llm.{i}.down_w"]
+        out += [f"llm.{i}.qkv_w", f"llm.{i}.qkv_w_dec", f"llm.{i}.o_w", f"llm.{i}.gate_up_w", f"llm.{i}.down_w"]
     return out + ["lm_head"]
 
 
@@ -117,7 +117,7 @@ class WeightArena:
         """llm_fp8: the LLM Linear weights + lm_head are stored as OCP e4m3 bytes (PACKED8 order) followed by their fp32 row
         scales (`<name>.scale`) -- 1 byte per parameter instead of 2 (72B: 73 GB instead of 147 GB; BASELINE configs[4])."""
         self.cfg, self.device, self.llm_fp8 = cfg, torch.device(device), bool(llm_fp8)
-        self.shapes = weight_shapes(cfg, decode_copies=not llm_fp8)    # the fp8 decode path keeps the round-1 launch sequence
+        self.shapes = weight_shapes(cfg, decode_copies=True)           # round 3: the fp8 arena carries the decode copies too (pipeline v2)
         self.fp8 = set(fp8_weight_names(cfg)) if llm_fp8 else set()
         offs, total = {}, 0          # offsets / sizes in bf16 (2-byte) units
         for name, shp in self.shapes:
@@ -192,7 +192,13 @@ class WeightArena:
         g = torch.Generator(device=self.device).manual_seed(seed)
         for name, shp in self.shapes:
             v = self.view(name)
-            if name in self.fp8:   # quantised in row blocks so that the fp32 staging stays below ~1 GB at 72B shapes
+            if name in self.fp8 and name.endswith("qkv_w_dec"):
+                # row quantisation commutes with the row permutation: the decode copy = permuted fp8 rows + permuted scales
+                perm = qkv_decode_row_permutation(self.cfg).to(self.device)
+                src = name[:-4]
+                v.copy_(pack_weight_fp8(unpack_weight_fp8(self.view(src))[perm].contiguous()))
+                self.view(name + ".scale").copy_(self.view(src + ".scale")[perm])
+            elif name in self.fp8:   # quantised in row blocks so that the fp32 staging stays below ~1 GB at 72B shapes
                 N, K = shp
                 rows = max(16, (1 << 27) // K // 16 * 16)
                 sc = self.view(name + ".scale")

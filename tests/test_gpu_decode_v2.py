@@ -179,3 +179,91 @@ def test_chained_down_qkv_launch_is_bit_identical_to_the_two_launches(dev, Hq, H
         assert torch.equal(h, h_ref) and torch.equal(st, st_ref), f"iteration {it}: residual stream / statistics differ"
         assert torch.equal(q, q_ref), f"iteration {it}: rotated q differs (stale residual row?)"
         assert torch.equal(kv_a.buf, kv_b.buf), f"iteration {it}: appended K/V rows differ"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp8 (e4m3 + row scale) weights on the pipeline-v2 GEMVs (round 3): against the SAME kernels on the exactly dequantised bf16 weights
+# ---------------------------------------------------------------------------------------------------------------------
+def _w8(dev, N, K, seed):
+    from livecc_amd import ops
+    from livecc_amd.weights import dequantize_fp8_rows, quantize_fp8_rows
+    w = _rand((N, K), dev, 0.03, seed).float()
+    q, sc = quantize_fp8_rows(w)
+    wd = dequantize_fp8_rows(q, sc)                       # fp32 = e4m3 value x scale
+    w8, sc2 = ops.quantize_fp8(w)
+    assert torch.equal(sc, sc2)
+    return w8, sc.contiguous(), wd
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("N,K", [(37888, 3584), (59136, 8192), (1024, 256)])
+def test_fp8_norm_swiglu_gemv(dev, M, N, K):
+    from livecc_amd import ops
+    if M * K > 16384:
+        pytest.skip("M * K beyond the LDS-staged rows")
+    h, nw = _rand((M, K), dev, 2.0, 1), (1.0 + 0.1 * _rand((K,), dev, 1.0, 3).float()).to(torch.bfloat16)
+    w8, sc, wd = _w8(dev, N, K, 2)
+    got = ops.dgemv_norm_linear(w8, h, ops.tile_stats(h), nw, 1e-6, (N, K), swiglu=True, wscale=sc)
+    ref, atol = _ref_linear(_rmsnorm_ref(h, nw, 1e-6).to(torch.bfloat16), wd, None, 4, with_atol=True)
+    assert_bf16_close(got, ref, f"dgemv_w8_norm_swiglu[{M}x{N}x{K}]", max_ulp=1.0, max_frac=1e-2, atol=atol)
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("N,K", [(152064, 3584), (2048, 256)])
+def test_fp8_norm_linear_gemv_lm_head(dev, M, N, K):
+    from livecc_amd import ops
+    h, nw = _rand((M, K), dev, 2.0, 4), (1.0 + 0.1 * _rand((K,), dev, 1.0, 6).float()).to(torch.bfloat16)
+    w8, sc, wd = _w8(dev, N, K, 5)
+    got = ops.dgemv_norm_linear(w8, h, ops.tile_stats(h), nw, 1e-6, (N, K), wscale=sc)
+    ref, atol = _ref_linear(_rmsnorm_ref(h, nw, 1e-6).to(torch.bfloat16), wd, None, with_atol=True)
+    assert_bf16_close(got, ref, f"dgemv_w8_norm_linear[{M}x{N}x{K}]", max_ulp=1.0, max_frac=1e-2, atol=atol)
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("N,K", [(3584, 18944), (3584, 3584), (8192, 29568), (256, 512)])
+def test_fp8_residual_gemv_and_tile_statistics(dev, M, N, K):
+    from livecc_amd import ops
+    if K % 64:
+        pytest.skip("fp8 fragments are 64 k wide")
+    x, h0 = _rand((M, K), dev, 1.0, 7), _rand((M, N), dev, 2.0, 9)
+    w8, sc, wd = _w8(dev, N, K, 8)
+    h = h0.clone()
+    stats = ops.dgemv_resid_(w8, x, h, (N, K), wscale=sc)
+    ref, atol = _ref_linear(x, wd, None, 3, h0, with_atol=True)
+    assert_bf16_close(h, ref, f"dgemv_w8_resid[{M}x{N}x{K}]", max_ulp=1.0, max_frac=1e-2, atol=atol)
+    assert torch.allclose(stats, ops.tile_stats(h), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("Hq,Hkv,K", [(28, 4, 3584), (64, 8, 8192), (2, 1, 256)])
+@pytest.mark.parametrize("M", [1, 2])
+def test_fp8_qkv_gemv_with_rope_and_kv_append(dev, Hq, Hkv, K, M):
+    """fp8 decode copy (rows AND scales permuted) in one launch against the round-1 fp8 chain on the un-permuted weight: RMSNorm ->
+    fp8 split-K GEMV slabs (lcc_gemm_w8_bf16) -> rope_kv_append.  Same e4m3 values and scales on both sides; they differ only by the
+    fp32 summation order of the GEMV."""
+    from livecc_amd import ops
+    from livecc_amd.config import LiveCCConfig
+    from livecc_amd.weights import pack_weight_fp8, quantize_fp8_rows, qkv_decode_row_permutation
+    if M * K > 16384:
+        pytest.skip("M * K beyond the LDS-staged rows")
+    D = 128
+    N = (Hq + 2 * Hkv) * D
+    cfg = LiveCCConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=K)
+    h, b = _rand((M, K), dev, 2.0, 11), _rand((N,), dev, 0.2, 13)
+    w = _rand((N, K), dev, 0.03, 12).float()
+    nw = (1.0 + 0.1 * _rand((K,), dev, 1.0, 14).float()).to(torch.bfloat16)
+    perm = qkv_decode_row_permutation(cfg).to(dev)
+    q, sc = quantize_fp8_rows(w)
+    w8, w8_dec, sc_dec = pack_weight_fp8(q), pack_weight_fp8(q[perm].contiguous()), sc[perm].contiguous()
+    lens = [37, 100][:M]
+    kv_a, kv_b = ops.KvArena(M, 1, Hkv, 256, dev), ops.KvArena(M, 1, Hkv, 256, dev)
+    slots = torch.arange(M, dtype=torch.int32, device=dev)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+    pos3 = torch.tensor([[l + 3 for l in lens]] * 3, dtype=torch.int32)
+    _, _, inv = _hf_mrope_ref(pos3)
+    c, s_ = ops.mrope_table(pos3.to(dev), inv.to(dev), [16, 24, 24])
+    q_got = ops.dgemv_qkv_rope(w8_dec, h, ops.tile_stats(h), nw, 1e-6, b, c, s_, slots, kv_len, kv_a, 0, Hq, wscale=sc_dec)
+    xn = _rmsnorm_ref(h, nw, 1e-6).to(torch.bfloat16)
+    part = ops.linear_w8(xn, w8, sc.contiguous(), nsplit=min(8, ops.gemv_num_splits(N, K)))
+    q_ref = ops.rope_kv_append(None, c, s_, slots, None, kv_b, 0, Hq, partial=part, bias=b, kv_len=kv_len)
+    assert_bf16_close(q_got, q_ref, f"dgemv_w8_qkv_rope.q[{Hq},{Hkv},{K},M{M}]", max_ulp=2.0, max_frac=2e-2, atol=2e-2)
+    assert_bf16_close(kv_a.buf, kv_b.buf, "dgemv_w8_qkv_rope.kv", max_ulp=2.0, max_frac=2e-2, atol=2e-2)
