@@ -129,10 +129,11 @@ int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, const int32_t*
                       int heads, int total_blocks, const int32_t* grp_seg, const int32_t* grp_q0, int n_groups, void* stream);
 
 /* The same attention on 32x32x16 MFMAs (csrc/attn32.hip; attention variant 3 = the engine's default): grp_seg / grp_q0 describe groups
- * of 256 query rows (8 waves x 32 rows) of ONE segment each; d = 80 only. */
+ * of `group_rows` query rows of ONE segment each: 256 (8 waves x 32 rows per workgroup) or 128 (4 waves: twice the workgroups, for
+ * inputs whose 256-row groups would not fill the chip -- one 2-frame streaming chunk is 6 x 16 heads = 96 groups); d = 80 only. */
 int lcc_attn_vit32_bf16(const void* qkv, const void* vt, void* out, const int32_t* grp_seg, const int32_t* grp_q0,
                         const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
-                        int total_blocks, void* stream);
+                        int total_blocks, int group_rows, void* stream);
 
 /* M-RoPE tables (Q2VL:156-169) and apply + in-place KV append (Q2VL:180-222 + HF:cache_utils.py:127-146) */
 int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream);

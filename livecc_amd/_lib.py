@@ -104,7 +104,7 @@ def load():
         "lcc_swiglu_bf16": (i32, [vp, vp, vp, i64, vp]),
         "lcc_vit_rope_vt_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
         "lcc_attn_vit_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
-        "lcc_attn_vit32_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+        "lcc_attn_vit32_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lcc_mrope_table": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "lcc_rope_kv_append_bf16": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, vp]),
         "lcc_attn_prefill_bf16": (i32, [vp, vp, vp, vp, vp, vp, vp, KvLayout, i32, i32, i32, i32, i32, i32, vp, vp, vp]),

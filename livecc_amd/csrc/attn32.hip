@@ -353,13 +353,24 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
 
 int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
                       const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
-                      int total_blocks, float scale_log2e, hipStream_t st) {
+                      int total_blocks, float scale_log2e, hipStream_t st, int group_rows) {
   if (n_groups <= 0) return 0;
+  if (group_rows != 256 && group_rows != 128) return LCC_ERR_ARG;
   constexpr size_t lds = (size_t)10 * 11 * 1024;
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-  attn_vit32_kernel<8><<<dim3(n_groups, heads), dim3(512), lds, st>>>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads,
-                                                                      total_blocks, scale_log2e);
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  // group_rows 256: 8 waves x 32 rows per block; 128: 4 waves (one per SIMD) -- twice the blocks for a grid that does not fill the chip
+  if (group_rows == 256)
+    attn_vit32_kernel<8><<<dim3(n_groups, heads), dim3(512), lds, st>>>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads,
+                                                                        total_blocks, scale_log2e);
+  else
+    attn_vit32_kernel<4><<<dim3(n_groups, heads), dim3(256), lds, st>>>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads,
+                                                                        total_blocks, scale_log2e);
+  g_launch_counts[LC_ATTN_VIT32] += 1;
   return 0;
 }
 

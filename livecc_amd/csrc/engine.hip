@@ -570,9 +570,15 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     // 32x32x16 kernel (8 waves x 32 rows per block) once its grid fills the chip: 8 streams' chunks = 768 blocks, 170 vs 359 us per
     // block of the tower; ONE 2-frame chunk is only 6 groups x 16 heads = 96 blocks (49 us) -- there the 16-row-per-wave LDS-shared
     // kernel with twice the blocks stays (41 us)
+    // (the 4-wave form of the 32x32x16 kernel -- 128-row groups, 192 blocks for one chunk -- measured the same as the 16-row kernel:
+    // 261.6 vs 262.1 tokens/s without prefetch, profiles/r03/knob_sweeps_call11_12.txt; off unless LCC_VIT32_MIN_BLOCKS4 says otherwise)
+    static const int vit32_min4 = [] { const char* v = getenv("LCC_VIT32_MIN_BLOCKS4"); return v ? atoi(v) : (1 << 30); }();
     if (get_attn_variant() == 3 && e->vit_hd == 80 && (long)n_groups8 * heads >= 224)
       LCC_TRY(attn_vit32_launch(qkv, vt, attn, d_g8_seg, d_g8_q0, d_seg_start, d_seg_len, d_seg_blk, n_groups8, heads, blocks,
-                                1.4426950408889634f / sqrtf(80.f), st));
+                                1.4426950408889634f / sqrtf(80.f), st, 256));
+    else if (get_attn_variant() == 3 && e->vit_hd == 80 && (long)n_groups * heads >= vit32_min4)   // 128-row groups: 4 waves, one per SIMD
+      LCC_TRY(attn_vit32_launch(qkv, vt, attn, d_grp_seg, d_grp_q0, d_seg_start, d_seg_len, d_seg_blk, n_groups, heads, blocks,
+                                1.4426950408889634f / sqrtf(80.f), st, 128));
     else
       LCC_TRY(attn_vit_bf16(qkv, vt, attn, d_tile_seg, d_tile_q0, d_seg_start, d_seg_len, d_seg_blk, n_tiles, heads, blocks, d_grp_seg, d_grp_q0,
                             n_groups, st));
@@ -1026,7 +1032,8 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   cx.S = n_streams; cx.skinny = n_streams <= 16; cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
   cx.nsplit_attn = nsplit;
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
-  cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, 256 / (n_streams * e->c.n_kv_heads))));
+  static const int fused_blocks = [] { const char* v = getenv("LCC_ATTN_FUSED_BLOCKS"); return v ? std::max(64, atoi(v)) : 256; }();
+  cx.nsplit_attn_fused = std::max(1, std::min(std::min(32, (ntile + 3) / 4), std::max(1, fused_blocks / (n_streams * e->c.n_kv_heads))));
   // v2 serves batches of one or two streams (measured on MI355X at 7B shapes: 246 vs 242 tokens/s for one stream, 414 vs 410 for
   // two, but 640 vs 655 for four: with more rows the per-block normalisation prologue outweighs the saved launches)
   const bool v2 = decode_v2_ok(e) && n_streams <= 2 && (long)n_streams * e->c.hidden_size <= 16384;
@@ -1183,10 +1190,11 @@ extern "C" int lcc_attn_vit_bf16(const void* qkv, const void* vt, void* out, con
 }
 extern "C" int lcc_attn_vit32_bf16(const void* qkv, const void* vt, void* out, const int32_t* grp_seg, const int32_t* grp_q0,
                                    const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
-                                   int total_blocks, void* stream) {
+                                   int total_blocks, int group_rows, void* stream) {
   if (!qkv || !vt || !out || !grp_seg || !grp_q0 || !seg_start || !seg_len || !seg_blk_start) return fail(LCC_ERR_ARG, "null pointer");
+  if (group_rows != 256 && group_rows != 128) return fail(LCC_ERR_ARG, "group_rows must be 256 or 128, got %d", group_rows);
   OP_RET(attn_vit32_launch((const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads,
-                           total_blocks, 1.4426950408889634f / sqrtf(80.f), (hipStream_t)stream), "lcc_attn_vit32_bf16");
+                           total_blocks, 1.4426950408889634f / sqrtf(80.f), (hipStream_t)stream, group_rows), "lcc_attn_vit32_bf16");
 }
 extern "C" int lcc_mrope_table(const int32_t* pos3, const float* inv_freq, int S, int sec_t, int sec_h, void* cos, void* sin, void* stream) {
   if (!pos3 || !inv_freq || !cos || !sin) return fail(LCC_ERR_ARG, "null pointer");

@@ -25,6 +25,7 @@ enum LaunchCounter {
   LC_LAST_DECODE_NSPLIT = 10,  // key splits of the most recent decode attention launch (a value, not a count)
   LC_LAST_PREFILL_NSPLIT = 11, // key splits of the most recent prefill attention launch
   LC_GEMM_TALL = 12,
+  LC_ATTN_VIT32 = 13,          // attn_vit32_kernel (vision attention on 32x32x16 MFMAs)
   LC_COUNT = 16
 };
 extern long long g_launch_counts[LC_COUNT];
@@ -108,7 +109,7 @@ int get_attn_variant();
 // ViT attention on 32x32x16 MFMAs (attn32.hip): groups of 8 x 32 query rows of one segment (grp_seg / grp_q0, 256-row groups)
 int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
                       const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
-                      int total_blocks, float scale_log2e, hipStream_t st);
+                      int total_blocks, float scale_log2e, hipStream_t st, int group_rows = 256);
 // LLM prefill attention on 32-row tiles / 32x32x16 MFMAs (attn32.hip); partials in the layout of attn_prefill_combine_kernel
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,

@@ -109,7 +109,7 @@ ATTN_DEFAULT_VARIANT = 3
 
 LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "attn_decode_fused_merge", "gemv_fused_tail", "dgemv_v2",
                    "attn_prefill_mfma32", "attn_prefill_shared", "attn_prefill_per_wave", "attn_prefill_combine", "last_decode_nsplit",
-                   "last_prefill_nsplit")
+                   "last_prefill_nsplit", "gemm_tall", "attn_vit32")
 
 
 def launch_counts(reset: bool = False) -> dict:
@@ -223,8 +223,9 @@ def vit_segments(grids: Sequence[Sequence[int]], device):
     return d
 
 
-def vit_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, grids, heads: int) -> torch.Tensor:
-    """qkv [P, 3E] bf16 (un-rotated; modified in place), cos/sin fp32 [P,40] -> attention output [P, E]."""
+def vit_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, grids, heads: int, group_rows: int = 256) -> torch.Tensor:
+    """qkv [P, 3E] bf16 (un-rotated; modified in place), cos/sin fp32 [P,40] -> attention output [P, E].  group_rows (attention
+    variant 3 only): 256 = 8-wave workgroups, 128 = 4-wave workgroups (the engine's choice for grids that do not fill the chip)."""
     lib = _lib.load()
     seg = vit_segments(grids, qkv.device)
     P, E = qkv.shape[0], qkv.shape[1] // 3
@@ -235,9 +236,10 @@ def vit_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, grids
                                         seg["seg_start"].data_ptr(), seg["seg_blk"].data_ptr(), vt.data_ptr(), P, heads,
                                         seg["blocks"], _st(qkv)), "lcc_vit_rope_vt_bf16")
     if _ATTN_VARIANT[0] == 3:
-        _lib.check(lib.lcc_attn_vit32_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg["g8_seg"].data_ptr(), seg["g8_q0"].data_ptr(),
-                                           seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(), seg["seg_blk"].data_ptr(), seg["n_groups8"],
-                                           heads, seg["blocks"], _st(qkv)), "lcc_attn_vit32_bf16")
+        gs, gq, ng = (("g8_seg", "g8_q0", "n_groups8") if group_rows == 256 else ("grp_seg", "grp_q0", "n_groups"))
+        _lib.check(lib.lcc_attn_vit32_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg[gs].data_ptr(), seg[gq].data_ptr(),
+                                           seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(), seg["seg_blk"].data_ptr(), seg[ng],
+                                           heads, seg["blocks"], int(group_rows), _st(qkv)), "lcc_attn_vit32_bf16")
         return out
     _lib.check(lib.lcc_attn_vit_bf16(qkv.data_ptr(), vt.data_ptr(), out.data_ptr(), seg["tile_seg"].data_ptr(),
                                      seg["tile_q0"].data_ptr(), seg["seg_start"].data_ptr(), seg["seg_len"].data_ptr(),

@@ -408,6 +408,12 @@ def test_vit_rope_attention(dev, grids, attn_variant):
             off += n
     got = ops.vit_attention(qkv.clone(), cos.to(dev), sin.to(dev), grids, heads)
     _check_attn(got.view(P, heads, D), rb(ref), f"vit_attn{grids}")
+    if attn_variant == 3:     # the 4-wave workgroups (128-row groups) of the same kernel: what the engine launches for ONE streaming chunk
+        before = ops.launch_counts()["attn_vit32"]
+        got4 = ops.vit_attention(qkv.clone(), cos.to(dev), sin.to(dev), grids, heads, group_rows=128)
+        assert ops.launch_counts()["attn_vit32"] == before + 1
+        _check_attn(got4.view(P, heads, D), rb(ref), f"vit_attn_group128{grids}")
+        assert torch.equal(got4, got), "a query row's arithmetic does not depend on the group size"
 
 
 def _hf_mrope_ref(pos3, theta=1e6):
