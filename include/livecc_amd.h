@@ -83,6 +83,10 @@ int lcc_debug_set_decode_path(int path);
  * does not drain at the hand-off.  Used only when both grids fit the chip at once (LiveCC-7B: 224 + 288 blocks of 512 threads = 2 per
  * CU) and for <= 2 streams; 0 (default) = separate launches.  A hand-off that times out fails the call (lcc_slot_read_tokens) and disables it. */
 int lcc_debug_set_decode_chain(int on);
+/* Block shape of the o_proj / down_proj decode GEMV (lcc_dgemv_resid): 0 = 8 waves per block, 1 (default) = 16 waves for bf16 weights with
+ * K >= 8192 (the down projection: half the dependent chain of load stages per wave), 2 = 16 waves for every call.  Returns the old mode.
+ * The K split across the waves of a block -- and so the fp32 summation order -- differs between the two shapes. */
+int lcc_debug_set_resid_waves(int mode);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
  * [N/16][K/64][4 g][16 rows][16 k] (lane (g,row) owns 16 consecutive k), wscale = fp32 [N] per-output-row scale:

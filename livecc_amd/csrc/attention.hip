@@ -701,17 +701,18 @@ LCC_DEVICE void store_sc1_f32x4(float* p, f32x4 v) {   // write-through (sc1) 16
   __hip_atomic_store(p8 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int NS, int TAIL>
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(
+template <int NS, int TAIL, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attn_decode_fused_kernel(
     const float* __restrict__ qkv_part, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ cs_tab,
     const bf16_t* __restrict__ sn_tab, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
     bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int B, int n_q_heads, int nsplit,
     float* __restrict__ ws_o, float* __restrict__ ws_ml, int32_t* __restrict__ counters, bf16_t* __restrict__ out,
     float scale_log2e) {
-  constexpr int D = 128, KS = 4, NQ = 1, NW = 4;
+  constexpr int D = 128, KS = 4, NQ = 1;
   // LDS: per wave, per query column (16): 128 o values + m + l (row stride 528 B keeps the 16-byte o accesses aligned);
   // the first 512 bytes double as the staging area of the new token's K row / V column and later as the merge flag
-  __shared__ __attribute__((aligned(16))) float sm[NW][16][D + 4];
+  extern __shared__ __attribute__((aligned(16))) float sm_dyn[];     // NW * 16 * (D + 4) floats (8 waves: 67.6 KB, above the static limit)
+  float (*sm)[16][D + 4] = reinterpret_cast<float (*)[16][D + 4]>(sm_dyn);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int hkv = lay.n_kv_heads, G = n_q_heads / hkv;
@@ -806,9 +807,9 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
   if (g == 0) { sm[wave][li][D] = acc.m[0]; sm[wave][li][D + 1] = l; }
   __syncthreads();
 
-  // ---- merge the 4 waves: item = (query head j, 4 consecutive d) ----
+  // ---- merge the NW waves: item = (query head j, 4 consecutive d) ----
   const bool single = nsplit == 1;
-  for (int item = threadIdx.x; item < G * 32; item += 256) {
+  for (int item = threadIdx.x; item < G * 32; item += NW * 64) {
     const int j = item >> 5, d4 = (item & 31) * 4;
     float M = -INFINITY;
 #pragma unroll
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(
   }
   __syncthreads();
   if (flag[0] == 0.f) return;
-  for (int item = threadIdx.x; item < G * 32; item += 256) {
+  for (int item = threadIdx.x; item < G * 32; item += NW * 64) {
     const int j = item >> 5, d4 = (item & 31) * 4;
     const size_t slot0 = (((size_t)b * hkv + hk) * nsplit) * 16 + j;
     float M = -INFINITY, den = 0.f;
@@ -1011,18 +1012,27 @@ int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias
   if (B <= 0) return 0;
   if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads % lay.n_kv_heads || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
   if (nsplit < 1 || nsplit > 64 || ns_qkv < 1 || ns_qkv > 8) return LCC_ERR_ARG;
-  const dim3 grid(nsplit, lay.n_kv_heads, B), blk(256);
+  // LCC_ATTN_FUSED_WAVES=8: 512-thread blocks (two waves per SIMD, half the key tiles per wave); only with the separate combine launch
+  static const int waves = [] { const char* v = getenv("LCC_ATTN_FUSED_WAVES"); return (v && atoi(v) == 8) ? 8 : 4; }();
   const int tail = g_attn_fused_tail;
+  const int nw = (waves == 8 && tail != 0) ? 8 : 4;
+  const dim3 grid(nsplit, lay.n_kv_heads, B), blk(nw * 64);
+  const size_t lds = (size_t)nw * 16 * (128 + 4) * sizeof(float);
   g_launch_counts[tail == 0 ? LC_ATTN_DECODE_FUSED_MERGE : LC_ATTN_DECODE_FUSED]++; g_launch_counts[LC_LAST_DECODE_NSPLIT] = nsplit;
   if (tail != 0 && nsplit > 1) g_launch_counts[LC_ATTN_DECODE_COMBINE]++;
 #define LCC_ADF(NS)                                                                                                              \
   case NS:                                                                                                                       \
     if (tail == 0)                                                                                                               \
-      attn_decode_fused_kernel<NS, 0><<<grid, blk, 0, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,       \
-                                                            n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));      \
-    else                                                                                                                         \
-      attn_decode_fused_kernel<NS, 1><<<grid, blk, 0, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,       \
-                                                            n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));      \
+      attn_decode_fused_kernel<NS, 0><<<grid, blk, lds, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,     \
+                                                              n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));    \
+    else if (nw == 8) {                                                                                                          \
+      static bool attr = false;                                                                                                  \
+      if (!attr) { set_lds_attr(attn_decode_fused_kernel<NS, 1, 8>, lds); attr = true; }                                         \
+      attn_decode_fused_kernel<NS, 1, 8><<<grid, blk, lds, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,  \
+                                                                 n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128)); \
+    } else                                                                                                                       \
+      attn_decode_fused_kernel<NS, 1><<<grid, blk, lds, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,     \
+                                                              n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));    \
     break;
   switch (ns_qkv) {
     LCC_ADF(1) LCC_ADF(2) LCC_ADF(3) LCC_ADF(4) LCC_ADF(5) LCC_ADF(6) LCC_ADF(7) LCC_ADF(8)

@@ -447,17 +447,26 @@ int dgemv_qkv_rope(const DgArgs& a, hipStream_t st) {
   else dgemv_kernel<1, DG_PRO_NORM, DG_EPI_ROPE, 8, 4, 4><<<dim3(a.N / 16), dim3(512), (size_t)a.M * a.K * 2, st>>>(a);
   return 0;
 }
+static int g_resid_waves = [] { const char* v = getenv("LCC_RESID_WAVES16"); return v ? atoi(v) : 1; }();
+int set_resid_waves(int mode) { const int old = g_resid_waves; g_resid_waves = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return old; }
 // o_proj / down_proj: x plain, residual add in place + per-tile sums of squares
 int dgemv_resid(const DgArgs& a, hipStream_t st) {
   if (int rc = dg_check(a, DG_PRO_PLAIN, DG_EPI_RESID)) return rc;
-  if (a.wscale != nullptr) { dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4, 4, true><<<dim3(a.N / 16), dim3(512), 0, st>>>(a); return 0; }
   // A block owns 16 rows x the whole K, so its waves' dependent chain of load stages is K / (64 NW UNR) round trips long: with 8 waves
   // the 7B down_proj (K = 18944) costs 12.7-14.6 us before / after its stream (tools/bench_dgemv_intercept.py: t = fixed + bytes / rate).
   // 1024-thread blocks (16 waves, UNR 3: 120 VGPRs at 4 waves per SIMD) halve that chain: 27.7 -> 25.1 us stand-alone, decode step
   // 2977 -> 2935 us, 270.5 -> 274.1 tokens/s (profiles/r03/dgemv_resid_16waves.txt); o_proj (K = 3584: 7 chunks per wave already) does
-  // not gain (2971 us).  LCC_RESID_WAVES16: 0 = 8 waves always, 1 (default) = 16 waves for K >= 8192, 2 = 16 waves for every call.
-  static const int w16 = [] { const char* v = getenv("LCC_RESID_WAVES16"); return v ? atoi(v) : 1; }();
-  if (w16 == 2 || (w16 == 1 && a.K >= 8192)) dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 16, 3><<<dim3(a.N / 16), dim3(1024), 0, st>>>(a);
+  // not gain (2971 us), and neither do fp8 weights (7B: 2036 vs 2017 us per step, 72B: 13.73 vs 13.49 ms -- half the bytes per chunk).
+  // Mode (lcc_debug_set_resid_waves; initial value from LCC_RESID_WAVES16): 0 = 8 waves always, 1 (default) = 16 waves for bf16 weights
+  // with K >= 8192, 2 = 16 waves for every call.
+  const int w16 = g_resid_waves;
+  const bool wide = w16 == 2 || (w16 == 1 && a.K >= 8192 && a.wscale == nullptr);
+  if (a.wscale != nullptr) {
+    if (wide) dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 16, 4, 4, true><<<dim3(a.N / 16), dim3(1024), 0, st>>>(a);
+    else dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4, 4, true><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
+    return 0;
+  }
+  if (wide) dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 16, 3><<<dim3(a.N / 16), dim3(1024), 0, st>>>(a);
   else dgemv_kernel<1, DG_PRO_PLAIN, DG_EPI_RESID, 8, 4><<<dim3(a.N / 16), dim3(512), 0, st>>>(a);
   return 0;
 }

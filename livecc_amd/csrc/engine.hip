@@ -571,7 +571,7 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     // block of the tower; ONE 2-frame chunk is only 6 groups x 16 heads = 96 blocks (49 us) -- there the 16-row-per-wave LDS-shared
     // kernel with twice the blocks stays (41 us)
     // (the 4-wave form of the 32x32x16 kernel -- 128-row groups, 192 blocks for one chunk -- measured the same as the 16-row kernel:
-    // 261.6 vs 262.1 tokens/s without prefetch, profiles/r03/knob_sweeps_call11_12.txt; off unless LCC_VIT32_MIN_BLOCKS4 says otherwise)
+    // 261.6 vs 262.1 tokens/s without prefetch, profiles/r03/knob_sweeps_call11_13.txt; off unless LCC_VIT32_MIN_BLOCKS4 says otherwise)
     static const int vit32_min4 = [] { const char* v = getenv("LCC_VIT32_MIN_BLOCKS4"); return v ? atoi(v) : (1 << 30); }();
     if (get_attn_variant() == 3 && e->vit_hd == 80 && (long)n_groups8 * heads >= 224)
       LCC_TRY(attn_vit32_launch(qkv, vt, attn, d_g8_seg, d_g8_q0, d_seg_start, d_seg_len, d_seg_blk, n_groups8, heads, blocks,
@@ -1086,6 +1086,7 @@ extern "C" int lcc_debug_launch_counts(int64_t* out, int n, int reset) {
 }
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_chain(int on) { g_decode_chain = on ? 1 : 0; return 0; }
+extern "C" int lcc_debug_set_resid_waves(int mode) { return set_resid_waves(mode); }
 extern "C" int lcc_debug_set_decode_path(int path) {
   if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
   g_decode_path = path;

@@ -159,6 +159,7 @@ int decode_step_begin(const int32_t* slots, const int32_t* cur_tok, const int32_
                       bf16_t* h, float* stats, int dim, const int32_t* pos, const float* inv_freq, bf16_t* cs, bf16_t* sn, int B,
                       hipStream_t st);
 int dgemv_qkv_rope(const DgArgs& a, hipStream_t st);      // [RMSNorm] q|k|v Linear (row-permuted decode copy) [bias + M-RoPE + KV append]
+int set_resid_waves(int mode);   // 0: 8-wave blocks, 1: 16 waves for bf16 weights with K >= 8192 (default), 2: 16 waves always; returns the old mode
 int dgemv_resid(const DgArgs& a, hipStream_t st);         // o_proj / down_proj [residual add in place + per-tile sums of squares]
 int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st);   // [RMSNorm] gate/up Linear [SwiGLU]
 // chained launch: down_proj of layer l + q/k/v of layer l+1, the consumer's weights prefetched under the producer (decode_v2.hip)

@@ -41,9 +41,18 @@ def test_norm_linear_gemv_lm_head(dev, M, N, K):
     assert_bf16_close(got, ref, f"dgemv_norm_linear[{M}x{N}x{K}]", max_ulp=1.0, max_frac=1e-2, atol=atol)
 
 
+@pytest.fixture(params=[0, 2], ids=["blocks_of_8_waves", "blocks_of_16_waves"])
+def resid_waves(request):
+    """Both block shapes of lcc_dgemv_resid (the engine's default picks 16 waves for bf16 weights with K >= 8192)."""
+    from livecc_amd import _lib
+    old = _lib.load().lcc_debug_set_resid_waves(request.param)
+    yield request.param
+    _lib.load().lcc_debug_set_resid_waves(old)
+
+
 @pytest.mark.parametrize("M", [1, 2, 4])
 @pytest.mark.parametrize("N,K", [(3584, 18944), (3584, 3584), (1536, 8960), (256, 512), (896, 2432), (8192, 8192)])
-def test_residual_gemv_and_tile_statistics(dev, M, N, K):
+def test_residual_gemv_and_tile_statistics(dev, M, N, K, resid_waves):
     """h += Linear(x): HF rounds the Linear output to bf16, then the residual sum to bf16; stats = per-16-channel sums of squares."""
     from livecc_amd import ops
     x, w, h0 = _rand((M, K), dev, 1.0, 7), _rand((N, K), dev, 0.03, 8), _rand((M, N), dev, 2.0, 9)
@@ -135,7 +144,7 @@ def test_decode_step_begin(dev):
 
 @pytest.mark.parametrize("Hq,Hkv,H,I", [(28, 4, 3584, 18944), (12, 2, 1536, 8960), (7, 1, 896, 2432)])
 @pytest.mark.parametrize("M", [1, 2])
-def test_chained_down_qkv_launch_is_bit_identical_to_the_two_launches(dev, Hq, Hkv, H, I, M):
+def test_chained_down_qkv_launch_is_bit_identical_to_the_two_launches(dev, request, Hq, Hkv, H, I, M):
     """Round 3: down_proj of layer l and q/k/v of layer l+1 as ONE launch (the q/k/v blocks prefetch their weights, then wait for the
     down_proj blocks' write-through residual rows: csrc/decode_v2.hip) must give bit-identical h, tile statistics, rotated q and KV
     rows to lcc_dgemv_resid followed by lcc_dgemv_qkv_rope -- repeated 20 times on the same monotonic counter with a fresh residual
@@ -158,6 +167,11 @@ def test_chained_down_qkv_launch_is_bit_identical_to_the_two_launches(dev, Hq, H
     counter = torch.zeros(1, dtype=torch.int32, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     before = 0
+    # the chained kernel's producer part is the 8-wave down_proj; the stand-alone default for K >= 8192 is the 16-wave block shape, whose
+    # K split across waves (fp32 summation order) differs -- compare like with like
+    from livecc_amd import _lib
+    old_mode = _lib.load().lcc_debug_set_resid_waves(0)
+    request.addfinalizer(lambda: _lib.load().lcc_debug_set_resid_waves(old_mode))
     for it in range(20):
         x, h0 = _rand((M, I), dev, 1.0, 40 + it), _rand((M, H), dev, 2.0, 80 + it)
         kv_a, kv_b = ops.KvArena(M, 1, Hkv, 128, dev), ops.KvArena(M, 1, Hkv, 128, dev)
@@ -221,7 +235,7 @@ def test_fp8_norm_linear_gemv_lm_head(dev, M, N, K):
 
 @pytest.mark.parametrize("M", [1, 2])
 @pytest.mark.parametrize("N,K", [(3584, 18944), (3584, 3584), (8192, 29568), (256, 512)])
-def test_fp8_residual_gemv_and_tile_statistics(dev, M, N, K):
+def test_fp8_residual_gemv_and_tile_statistics(dev, M, N, K, resid_waves):
     from livecc_amd import ops
     if K % 64:
         pytest.skip("fp8 fragments are 64 k wide")

@@ -781,12 +781,14 @@ def test_chained_decode_launch_gives_bit_identical_logits(dev, tiny_models):
     cfg, hf16, hf32, native = tiny_models
     frames = torch.from_numpy(protocol.synth_frames(8, 56, 84, seed=77, layout="TCHW"))
     outs = []
+    old_waves = _lib.load().lcc_debug_set_resid_waves(0)     # the chained kernel's down_proj part has the 8-wave block shape
     for chain in (0, 1, 1, 0):
         _lib.load().lcc_debug_set_decode_chain(chain)
         try:
             outs.append(_replay_native(native, cfg, frames, protocol.TurnBuilder(cfg, seed=77), max_new_tokens=8, repetition_penalty=1.05, max_turns=2))
         finally:
             _lib.load().lcc_debug_set_decode_chain(0)
+    _lib.load().lcc_debug_set_resid_waves(old_waves)
     for o in outs[1:]:
         for ta, tb in zip(outs[0], o):
             assert ta["new_tokens"] == tb["new_tokens"]
