@@ -53,7 +53,12 @@ def test_decode_copy_is_the_row_permuted_qkv_weight():
     for arena in (WeightArena(cfg, "cpu").fill_tiled(2), WeightArena(cfg, "cpu").fill_random(2)):
         for l in range(cfg.num_hidden_layers):
             assert torch.equal(arena.logical(f"llm.{l}.qkv_w_dec"), arena.logical(f"llm.{l}.qkv_w")[perm])
-    assert not any(n.endswith("qkv_w_dec") for n in WeightArena(cfg, "cpu", llm_fp8=True).names())
+    # fp8 arenas (round 3: the W8 GEMVs of decode pipeline v2) carry the decode copy too: the SAME e4m3 bytes and row scales, permuted
+    a8 = WeightArena(cfg, "cpu", llm_fp8=True).fill_random(2)
+    assert any(n.endswith("qkv_w_dec") for n in a8.names()) and any(n.endswith("qkv_w_dec.scale") for n in a8.names())
+    for l in range(cfg.num_hidden_layers):
+        assert torch.equal(a8.logical(f"llm.{l}.qkv_w_dec"), a8.logical(f"llm.{l}.qkv_w")[perm])
+        assert torch.equal(a8.view(f"llm.{l}.qkv_w_dec.scale"), a8.view(f"llm.{l}.qkv_w.scale")[perm])
 
 
 def test_arena_from_hf_state_dict_cpu():

@@ -20,6 +20,17 @@ if "--gemm" in sys.argv:
         x = torch.randn(M, H, device=dev).to(torch.bfloat16)
         for i in range(6):
             ops.linear(x, ws[i % 2], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
+    # the other LLM prefill GEMMs of ONE streaming chunk (M = 386) as the engine launches them: split-K slabs on the 128 x 256 tiles --
+    # q/k/v (N = 4608, 3 splits), o_proj (N = K = 3584, 4 splits), down_proj (N = 3584, K = 18944, 4 splits)
+    x = torch.randn(386, H, device=dev).to(torch.bfloat16)
+    xi = torch.randn(386, I, device=dev).to(torch.bfloat16)
+    wq = ops.pack_weight((torch.randn(4608, H, device=dev) * 0.02).to(torch.bfloat16))
+    wo = ops.pack_weight((torch.randn(H, H, device=dev) * 0.02).to(torch.bfloat16))
+    wd = ops.pack_weight((torch.randn(H, I, device=dev) * 0.02).to(torch.bfloat16))
+    for i in range(6):
+        ops.linear_partial(x, wq, 3, packed_shape=(4608, H))
+        ops.linear_partial(x, wo, 4, packed_shape=(H, H))
+        ops.linear_partial(xi, wd, 4, packed_shape=(H, I))
     torch.cuda.synchronize()
     print("ok")
     sys.exit(0)

@@ -33,6 +33,11 @@ for f in glob.glob(os.path.join(out, "pmc_gemm_*", "**", "*counter_collection.cs
         if "gemm_big_kernel" not in kn and "gemm_tall_kernel" not in kn:
             continue
         key = "M386_gemm_tall_kernel" if "gemm_tall_kernel" in kn else ("M3088_gemm_big_kernel_256" if "<256" in kn else "M386_gemm_big_kernel_128")
+        if "<128, 5" in kn:      # split-K slabs at M = 386: grid (tiles, splits) x 512 threads tells q/k/v (72 x 3) from o / down (56 x 4);
+            grid = int(r.get("Grid_Size", 0)) // 512      # o and down share a grid: told apart by the duration of the dispatch
+            dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+            key = "M386_qkv_splitk3" if grid == 216 else ("M386_down_splitk4" if dur > 45.0 else "M386_o_splitk4")
+            gemm.setdefault(key, {}).setdefault("duration_us_under_pmc", []).append(dur)
         gemm.setdefault(key, {}).setdefault(r.get("Counter_Name"), []).append(float(r["Counter_Value"]))
 d["gemm_counters_mean_per_dispatch"] = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in gemm.items()}
 d["gemm_note"] = ("MfmaUtil = rocprofv3 derived metric reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum)/(reduce(GRBM_GUI_ACTIVE,max)*SIMD_NUM)*100 (gfx94x formula); "
