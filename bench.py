@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--decode-chain", type=int, default=None, choices=[0, 1], help="debug A/B: lcc_debug_set_decode_chain")
     ap.add_argument("--fused-attn", type=int, default=None, help="debug A/B: lcc_debug_set_fused_attn (bit 0 fused decode attention for "
                                                                   ">= 16 (stream, KV head) pairs, bit 2 always, bit 1 in-launch split merge)")
+    ap.add_argument("--main-stream-priority", choices=["default", "high"], default="default",
+                    help="A/B: run the LLM phases on a high-priority HIP stream (the prefetched vision tower stays on the lowest-priority one)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: do not overlap the next turn's vision tower with this turn's decode steps")
     ap.add_argument("--cpu-baseline", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--cpu-config", default=None, help="shapes of the CPU baseline (default: same as --config)")
@@ -441,6 +443,17 @@ def main():
     else:
         def run_once():
             return replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, pf)
+    if args.main_stream_priority == "high" and dev.type == "cuda":
+        # the LLM phases on a HIGH-priority stream: the prefetched vision tower of the next turn (lowest-priority side stream,
+        # modeling._side_stream) then only takes what the decode kernels leave
+        lo, hi = torch.cuda.Stream.priority_range()
+        hp = torch.cuda.Stream(device=dev, priority=min(lo, hi))
+        sync()
+        inner = run_once
+
+        def run_once():
+            with torch.cuda.stream(hp):
+                return inner()
     for _ in range(args.warmup):
         run_once()
     if model.engine is not None:

@@ -61,7 +61,9 @@ int lcc_debug_set_gemv_variant(int variant);
  * shape (default: 8-wave 256x256 / 128x256 LDS-DMA kernel where its grid fills the chip, else the 4-wave kernels), 3 / 4 = force the
  * 8-wave kernel with 256 / 128 rows where eligible, 5 / 6 = the same with the compiler's fragment-read schedule, 7 = 2 without the
  * 8-wave kernel, 8 = force the "tall" kernel (one block row covers all of M <= 448, 448x160 tiles) wherever it is legal; the default
- * takes it when 256 < M <= 448 and ceil(N/160) fills 75-100 % of one round of the chip (LiveCC-7B gate/up of a streaming chunk) */
+ * takes it when 256 < M <= 448 and ceil(N/160) fills 75-100 % of one round of the chip (LiveCC-7B gate/up of a streaming chunk);
+ * 9 = the tall tile with an LDS ring of four 32-k half tiles instead of two whole k-tiles (three half tiles in flight across every
+ * barrier; bit-identical results; measured equal-to-slower: the L2 -> LDS DMA is throughput-bound) */
 int lcc_debug_set_gemm_variant(int variant);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
  * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs

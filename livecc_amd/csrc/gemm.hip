@@ -408,10 +408,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
 
   auto issue = [&](int kt, int stage) {
     u32x4* sbase = dsmem + stage * STAGE;
+    if (SCHED != 5) {      // (SCHED 4 / 5: timing diagnostics, only the activation / only the W half of the DMA ring)
 #pragma unroll
     for (int q = 0; q < A_PER_WAVE; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + kt * BK),
                                        (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+    }
+    if (SCHED != 4)
 #pragma unroll
     for (int q = 0; q < B_PER_WAVE; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * (W8 ? 512 : 1024)),
@@ -447,12 +450,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
-    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt0) % NSTAGE);
+    if (SCHED != 2 && kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt0) % NSTAGE);   // SCHED 2: timing diagnostic, no DMA
     const u32x4* s = dsmem + ((kt - kt0) % NSTAGE) * STAGE;
     // ragged last row tile (e.g. M = 386 = 3 x 128 + 2): a wave whose WM rows are all past M skips the multiply and only keeps
     // feeding the DMA ring and the barriers (wave-uniform branch around the whole k-tile body; a finer per-16-row predicate
     // made hipcc if-convert the accumulators and spill)
-    if (!wave_has_rows) {
+    if (!wave_has_rows || SCHED >= 3) {      // SCHED 3-5: timing diagnostics, DMA ring (or half of it) + barriers only
     } else if (SCHED == 0) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -636,6 +639,128 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
   else { if (mt_live <= 4) run(I4{}, I4{}); else run(I7{}, I4{}); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tall GEMM, 4-stage ring of 32-k HALF tiles (round 3)
+// ------------------------------------------------------------------------------------------------
+// Hypothesis tested: with two stages the DMA of tile kt+1 can only be issued once tile kt-1 is released, so if one L2 -> LDS round trip
+// were as long as a tile's MFMAs every k-step would pay max(MFMA, round trip) plus the barrier.  The tall tile cannot hold a third
+// 76-KB stage, so here the stage is a 32-k HALF tile (38 KB: 448 rows x 64 B of activations + 10 W fragment sub-tiles), four of them in
+// the same 152 KB: three half tiles (1.5 k-tiles) are in flight across every barrier and the accumulation order over k is unchanged
+// (bit-identical to gemm_tall_kernel).  RESULT: not faster (see g_tall_ring below: the DMA is throughput-bound) -- kept as variant 9.
+//   * A half image: [448 rows][4 x 16 B]; a DMA instruction copies 16 rows x 64 B; the 16-byte chunk of row r sits at position
+//     chunk ^ ((r >> 1) & 3) -- measured conflict-free for ds_read_b128 on gfx950 (tools/probes/lds_b128_probe.hip: 4.3 clk per wave
+//     instruction like the linear W read; unswizzled 64-byte rows or chunk ^ (r >> 2) take 8.0); applied to the per-lane DMA source
+//     and again on the fragment read.
+//   * every wave issues exactly 5 DMA instructions per half tile (28 activation pieces + 10 W sub-tiles + 2 repeats), so ONE counted
+//     s_waitcnt vmcnt(10) leaves the two later half tiles in flight.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tall4_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K) {
+  constexpr int BM = 448, BN = 160, BK = 32, WM = 112, MT = 7, NT0 = 6, NSTAGE = 4, PW = 5;
+  constexpr int A_UNITS = BM * 4;                 // 16-byte units of the A half image (64 B per row)
+  constexpr int A_PIECES = BM / 16;               // 28 DMA pieces of 16 rows
+  constexpr int B_SUB = BN / 16;                  // 10 fragment sub-tiles of 1 KB (one 32-k block each)
+  constexpr int STAGE = A_UNITS + B_SUB * 64;     // 2432 units = 38,912 B
+  extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
+
+  const int n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int li = lane & 15, g = lane >> 4;
+  const int K32 = K >> 5, nfrag = N >> 4;
+  const int rows_left = M - wm * WM;                                     // wave-uniform
+  const int mt_live = rows_left <= 0 ? 0 : min(MT, (rows_left + 15) >> 4);
+
+  // DMA pieces of this wave: p = wave * 5 + q; p < 28: activation rows 16p..16p+15; 28 <= p < 38: W sub-tile p - 28; else a repeat
+  const bf16_t* src[PW];
+  int dst[PW], kstep[PW];                          // LDS unit inside a stage; source advance per half tile (elements)
+#pragma unroll
+  for (int q = 0; q < PW; ++q) {
+    int p = wave * PW + q;
+    if (p >= A_PIECES + B_SUB) p -= A_PIECES + B_SUB;        // pieces 38, 39 repeat pieces 0, 1 (same bytes to the same place)
+    if (p < A_PIECES) {
+      const int rl = lane >> 2, c = (lane & 3) ^ ((rl >> 1) & 3);
+      src[q] = A + (size_t)min(p * 16 + rl, M - 1) * lda + c * 8;
+      dst[q] = p * 64;
+      kstep[q] = BK;
+    } else {
+      const int st = p - A_PIECES;
+      const int fr = min((n0 >> 4) + st, nfrag - 1);
+      src[q] = W + (size_t)fr * K32 * 512 + lane * 8;
+      dst[q] = A_UNITS + st * 64;
+      kstep[q] = 512;
+    }
+  }
+  auto issue = [&](int kt, int stage) {
+    u32x4* sbase = dsmem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < PW; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (size_t)kt * kstep[q]),
+                                       (__attribute__((address_space(3))) void*)(sbase + dst[q]), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][NT0];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (p < nkt) issue(p, p);
+  const int aoff = (wm * WM + li) * 4 + (g ^ ((li >> 1) & 3));
+  const int boff = A_UNITS + (wn * NT0) * 64 + lane;
+
+  // one half tile of this wave: the NTW W fragments are read up front, the activation fragments stream through a 3-register ring two
+  // row tiles ahead of their MFMAs
+  auto htile = [&](const u32x4* s, auto mtw_c, auto ntw_c) {
+    constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
+    bf16x8 fb[NTW], fa[3];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) fb[j] = as_bf16x8(s[boff + j * 64]);
+    fa[0] = as_bf16x8(s[aoff]);
+    if (MTW > 1) fa[1] = as_bf16x8(s[aoff + 64]);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      if (i + 2 < MTW) fa[(i + 2) % 3] = as_bf16x8(s[aoff + (i + 2) * 64]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(fb[j], fa[i % 3], acc[i][j]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NTW + (MTW > 1 ? 2 : 1), 0);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      if (i + 2 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I4 = std::integral_constant<int, 4>;
+  using I6 = std::integral_constant<int, 6>;
+  using I7 = std::integral_constant<int, 7>;
+  const int nbase = n0 + wn * NT0 * 16;
+  auto run = [&](auto mtw_c, auto ntw_c) {
+    constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
+    for (int kt = 0; kt < nkt; ++kt) {
+      // this wave's pieces of half tile kt have landed; up to two later half tiles stay in flight across the barrier
+      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // half tile kt complete in LDS; every wave is done reading half tile kt-1 (= the stage refilled next)
+      if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) & (NSTAGE - 1));
+      if constexpr (MTW > 0) htile(dsmem + (kt & (NSTAGE - 1)) * STAGE, mtw_c, ntw_c);
+    }
+    if constexpr (MTW > 0)
+      tile_epilogue<EPI, (MTW > 0 ? MTW : 1), (MTW > 0 ? NTW : 2), MT, NT0>(acc, wm * WM, nbase, nbase / 2, li, g, bias, residual, ldr, C, ldc, M, N,
+                                                                        nullptr, nullptr);
+  };
+  if (mt_live == 0) run(I0{}, I4{});                 // no rows: DMA + barriers only
+  else if (wn == 0) { if (mt_live <= 4) run(I4{}, I6{}); else run(I7{}, I6{}); }
+  else { if (mt_live <= 4) run(I4{}, I4{}); else run(I7{}, I4{}); }
+}
+
 // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel; 2 (default): measured best per tile shape --
 // 64-row tiles (72 KB ring, 2 blocks/CU) take the LDS-DMA kernel (1.5-1.6x), 128-row tiles keep the register-staged
 // kernel (64 KB, 2 blocks/CU; the 96 KB ring would leave 1 block/CU and measured 0.75x).
@@ -680,6 +805,14 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
 }
 template <int BM, int EPI>
 static void launch_big(const GemmArgs& a, hipStream_t st) {
+  if constexpr (BM == 256 && EPI == EPI_SWIGLU) {
+    // LCC_GEMM_DIAG (tools/bench_gemm_diag.py; results are WRONG by construction): 2 = no DMA after the prologue, 3 = no MFMAs
+    static const int diag = [] { const char* v = getenv("LCC_GEMM_DIAG"); return v ? atoi(v) : 0; }();
+    if (diag == 2 && !a.w_fp8) return launch_big_s<BM, EPI, 2, false>(a, st);
+    if (diag == 3 && !a.w_fp8) return launch_big_s<BM, EPI, 3, false>(a, st);
+    if (diag == 4 && !a.w_fp8) return launch_big_s<BM, EPI, 4, false>(a, st);
+    if (diag == 5 && !a.w_fp8) return launch_big_s<BM, EPI, 5, false>(a, st);
+  }
   if (a.w_fp8) launch_big_s<BM, EPI, 1, true>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
@@ -717,13 +850,27 @@ static int big_tile_rows(const GemmArgs& a, int S) {
 static bool tall_legal(const GemmArgs& a) { return big_eligible(a) && !a.w_fp8 && a.M <= 448 && (a.N & 15) == 0; }
 static bool tall_wanted(const GemmArgs& a) {
   if (!tall_legal(a)) return false;
-  if (g_gemm_variant == 8) return true;
+  if (g_gemm_variant == 8 || g_gemm_variant == 9) return true;
   if (g_gemm_variant != 2) return false;
   const int blocks = (a.N + 159) / 160;
   return a.M > 256 && blocks >= 192 && blocks <= 256;
 }
+// ring of the tall tile: 2 whole k-tiles (default) or 4 half tiles (LCC_TALL_RING=4 / variant 9).  Measured equal-to-slower on MI355X
+// (122.5 vs 125.2 us at M = 386 on random operands, 278.6 vs 277.2 tokens/s end to end, profiles/r03/gemm_tall_ring.txt): the L2 -> LDS
+// DMA is THROUGHPUT-bound, not round-trip-bound -- in gemm_big_kernel<256> the activation half of the ring alone takes 327 us, the W
+// half alone 374 us, both 580 us (~12 TB/s chip-wide, ~25 B/clk/CU) against 654 us for the MFMAs alone and 830 us for the kernel
+// (LCC_GEMM_DIAG 0-5, profiles/r03/gemm_diag.jsonl) -- so a deeper ring has nothing to hide.
+static int g_tall_ring = [] { const char* v = getenv("LCC_TALL_RING"); return (v && atoi(v) == 4) ? 4 : 2; }();
 template <int EPI>
 static void launch_tall(const GemmArgs& a, hipStream_t st) {
+  g_launch_counts[LC_GEMM_TALL]++;
+  if (g_tall_ring == 4 || g_gemm_variant == 9) {     // variant 9 forces the tall tile with the 4-stage ring of half tiles (A/B, tests)
+    constexpr size_t lds4 = (size_t)4 * (448 * 4 + 10 * 64) * 16;   // 155,648 B
+    static bool attr4 = false;   // per instantiation
+    if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_tall4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr4 = true; }
+    gemm_tall4_kernel<EPI><<<dim3((a.N + 159) / 160), dim3(512), lds4, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
+    return;
+  }
   constexpr size_t lds = (size_t)2 * (448 * 8 + 20 * 64) * 16;   // 155,648 B
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {

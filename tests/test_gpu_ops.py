@@ -103,20 +103,24 @@ def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
 @pytest.mark.parametrize("M", [17, 113, 225, 337, 386, 448])
 @pytest.mark.parametrize("N,K", [(160, 64), (352, 256), (4608, 3584)])
 @pytest.mark.parametrize("epi", [0, 1, 3, 4])
-def test_gemm_tall_kernel(dev, M, N, K, epi):
-    """Variant 8 forces `gemm_tall_kernel` (one block row covers all of M <= 448, 448 x 160 tiles, 4 x 2 waves with 6 + 4 column
-    tiles): every live-row-tile path of the last M-wave (M = 337: one row tile, 386: four, 448: seven), M-waves without rows
-    (M = 17, 113, 225), a ragged last column block (N = 352), bias / quick-GELU / residual / SwiGLU epilogues."""
+@pytest.mark.parametrize("variant", [8, 9], ids=["ring_of_2_tiles", "ring_of_4_half_tiles"])
+def test_gemm_tall_kernel(dev, M, N, K, epi, variant):
+    """Variants 8 / 9 force the tall tile (one block row covers all of M <= 448, 448 x 160 tiles, 4 x 2 waves with 6 + 4 column
+    tiles) with the 2-stage ring of whole k-tiles (`gemm_tall_kernel`, the default) / the 4-stage ring of 32-k half tiles
+    (`gemm_tall4_kernel`, a measured variant): every live-row-tile path of the last M-wave (M = 337: one row tile, 386: four, 448: seven), M-waves without
+    rows (M = 17, 113, 225), a ragged last column block (N = 352), bias / quick-GELU / residual / SwiGLU epilogues."""
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
     res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
-    ops.set_gemm_variant(8)
+    ops.set_gemm_variant(variant)
     try:
+        before = ops.launch_counts()["gemm_tall"]
         got = ops.linear(x, ops.pack_weight(w), None if epi == 4 else b, epi, res, packed_shape=(N, K))
+        assert ops.launch_counts()["gemm_tall"] == before + 1
     finally:
         ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     ref, atol = _ref_linear(x, w, None if epi == 4 else b, epi, res, with_atol=True)
-    assert_bf16_close(got, ref, f"gemm_tall[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+    assert_bf16_close(got, ref, f"gemm_tall[{M}x{N}x{K},epi{epi},v{variant}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
 def test_gemm_auto_choice_at_the_7b_chunk_shape_is_the_tall_kernel_and_matches(dev):
@@ -131,11 +135,14 @@ def test_gemm_auto_choice_at_the_7b_chunk_shape_is_the_tall_kernel_and_matches(d
     ops.set_gemm_variant(8)
     try:
         tall = ops.linear(x, wp, None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
+        ops.set_gemm_variant(9)
+        tall2 = ops.linear(x, wp, None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
         ops.set_gemm_variant(4)
         big = ops.linear(x, wp, None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
     finally:
         ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     assert torch.equal(got, tall), "the default variant must be the tall kernel at this shape"
+    assert torch.equal(tall, tall2), "the half-tile ring (variant 9) keeps the accumulation order over k: bit-identical to the 2-stage ring"
     ref, atol = _ref_linear(x, w, None, 4, with_atol=True)
     assert_bf16_close(got, ref, "gemm_tall_7b_gate_up", max_ulp=1.0, max_frac=5e-3, atol=atol)
     assert_bf16_close(big, ref, "gemm_big128_7b_gate_up", max_ulp=1.0, max_frac=5e-3, atol=atol)
