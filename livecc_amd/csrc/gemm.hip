@@ -450,12 +450,15 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
-    if (SCHED != 2 && kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt0) % NSTAGE);   // SCHED 2: timing diagnostic, no DMA
+    // SCHED 6 issues the same pieces one at a time between the row tiles of MFMAs below (a burst of 8 DMA instructions right after the
+    // barrier holds the wave's issue port for ~60-100 cycles each while BOTH waves of the SIMD are at the same point)
+    if (SCHED != 2 && SCHED != 6 && kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt0) % NSTAGE);   // SCHED 2: timing diagnostic, no DMA
     const u32x4* s = dsmem + ((kt - kt0) % NSTAGE) * STAGE;
     // ragged last row tile (e.g. M = 386 = 3 x 128 + 2): a wave whose WM rows are all past M skips the multiply and only keeps
     // feeding the DMA ring and the barriers (wave-uniform branch around the whole k-tile body; a finer per-16-row predicate
     // made hipcc if-convert the accumulators and spill)
-    if (!wave_has_rows || SCHED >= 3) {      // SCHED 3-5: timing diagnostics, DMA ring (or half of it) + barriers only
+    if (!wave_has_rows || (SCHED >= 3 && SCHED <= 5)) {      // SCHED 3-5: timing diagnostics, DMA ring (or half of it) + barriers only
+      if (SCHED == 6 && kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1 - kt0) % NSTAGE);   // no MFMA stream to spread them over
     } else if (SCHED == 0) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -492,20 +495,35 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       }
       fa[0] = as_bf16x8(s[aoff[0]]);
       fa[1] = as_bf16x8(s[aoff[0] + 128]);
+      // SCHED 6: piece t of the NEXT ring tile goes out after row-tile step t.  Unconditional (a branch would cut the scheduling
+      // region): past the last tile the source is clamped and the copy lands in a stage nobody reads any more.
+      const int kt_dma = min(kt + NSTAGE - 1, nkt - 1);
+      u32x4* dma_base = dsmem + ((kt + NSTAGE - 1 - kt0) % NSTAGE) * STAGE;
 #pragma unroll
       for (int t = 0; t < 2 * MT; ++t) {
         if (t + 2 < 2 * MT) fa[(t + 2) % 3] = as_bf16x8(s[aoff[(t + 2) / MT] + ((t + 2) % MT) * 128]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[t % MT][j] = mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
+        if (SCHED == 6 && t < G) {
+          if (t < A_PER_WAVE)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t < A_PER_WAVE ? t : 0] + kt_dma * BK),
+                                             (__attribute__((address_space(3))) void*)(dma_base + (wave * A_PER_WAVE + t) * 64), 16, 0, 0);
+          else
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(bsrc[t >= A_PER_WAVE ? t - A_PER_WAVE : 0] + (size_t)kt_dma * (W8 ? 512 : 1024)),
+                (__attribute__((address_space(3))) void*)(dma_base + A_UNITS + (wave * B_PER_WAVE + (t - A_PER_WAVE)) * 64), 16, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_group_barrier(0x100, (W8 ? NT : 2 * NT) + 2, 0);
 #pragma unroll
       for (int t = 0; t < 2 * MT; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        if (SCHED == 6 && t < G) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one VMEM (the LDS-DMA piece)
       }
     }
   }
+  if (SCHED == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies of the last iterations
   tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
@@ -574,6 +592,22 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
                                          (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (st0 + q) * 64), 16, 0, 0);
   };
 
+  // SCHED 2: the 10 pieces of a wave (7 activation + 3 W; waves 4-7 repeat their second W sub-tile as the third) go out ONE at a time
+  // between the row-tile steps of the MFMA stream instead of as a burst behind the barrier (every LDS-DMA instruction holds the wave's
+  // issue port for ~60-100 cycles, and right after the barrier both waves of a SIMD are at the same point)
+  auto issue_piece = [&](int kt, int stage, int q) {
+    u32x4* sbase = dsmem + stage * STAGE;
+    if (q < A_PER_WAVE)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoffs[q < A_PER_WAVE ? q : 0] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+    else {
+      const int qq = min(q - A_PER_WAVE, nb - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[qq] + (size_t)kt * 1024),
+                                       (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (st0 + qq) * 64), 16, 0, 0);
+    }
+  };
+  constexpr int NPIECE = A_PER_WAVE + 3;
+
   f32x4 acc[MT][NT0];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -589,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
 
   // one k-tile of this wave: MTW live row tiles x NTW column tiles.  Per 32-k half: the NTW W fragments are read up front, the
   // activation fragments stream through a 3-register ring two row tiles ahead of their MFMAs.
-  auto ktile = [&](const u32x4* s, auto mtw_c, auto ntw_c) {
+  auto ktile = [&](const u32x4* s, auto mtw_c, auto ntw_c, int kt_dma, int st_dma) {
     constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -603,15 +637,21 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
         if (i + 2 < MTW) fa[(i + 2) % 3] = as_bf16x8(s[aoff[kk] + (i + 2) * 128]);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(fb[j], fa[i % 3], acc[i][j]);
+        if (SCHED == 2 && kk * MTW + i < NPIECE) issue_piece(kt_dma, st_dma, kk * MTW + i);
       }
-      if (SCHED == 1) {   // pin the issue order: the fragment reads up front, then one activation read per row tile of MFMAs
+      if (SCHED >= 1) {   // pin the issue order: the fragment reads up front, then one activation read per row tile of MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, NTW + (MTW > 1 ? 2 : 1), 0);
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
           if (i + 2 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
+          if (SCHED == 2 && kk * MTW + i < NPIECE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
       }
+    }
+    if (SCHED == 2) {     // fewer row-tile steps than pieces (the 4-row-tile wave: 8 steps): the rest behind the last MFMAs
+#pragma unroll
+      for (int q = 2 * MTW; q < NPIECE; ++q) issue_piece(kt_dma, st_dma, q);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -627,9 +667,12 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
     for (int kt = 0; kt < nkt; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
-      if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-      if constexpr (MTW > 0) ktile(dsmem + (kt & 1) * STAGE, mtw_c, ntw_c);
+      // SCHED 2 (waves with rows): the pieces go out inside ktile, unconditionally -- past the last tile the source is clamped and the
+      // copy lands in the stage nobody reads any more
+      if ((SCHED != 2 || MTW == 0) && kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+      if constexpr (MTW > 0) ktile(dsmem + (kt & 1) * STAGE, mtw_c, ntw_c, min(kt + 1, nkt - 1), (kt + 1) & 1);
     }
+    if (SCHED == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (MTW > 0)
       tile_epilogue<EPI, (MTW > 0 ? MTW : 1), (MTW > 0 ? NTW : 2), MT, NT0>(acc, wm * WM, nbase, nbase / 2, li, g, bias, residual, ldr, C, ldc, M, N,
                                                                         nullptr, nullptr);
@@ -813,7 +856,9 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
     if (diag == 4 && !a.w_fp8) return launch_big_s<BM, EPI, 4, false>(a, st);
     if (diag == 5 && !a.w_fp8) return launch_big_s<BM, EPI, 5, false>(a, st);
   }
+  static const int spread = [] { const char* v = getenv("LCC_GEMM_SCHED"); return (v && atoi(v) == 6) ? 1 : 0; }();
   if (a.w_fp8) launch_big_s<BM, EPI, 1, true>(a, st);
+  else if (g_gemm_sched && spread) launch_big_s<BM, EPI, 6, false>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
 }
@@ -876,10 +921,13 @@ static void launch_tall(const GemmArgs& a, hipStream_t st) {
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  static const int sched = [] { const char* v = getenv("LCC_TALL_SCHED"); return v ? atoi(v) : 0; }();   // 0 compiler order, 1 pinned
-  if (sched == 1)
+  static const int sched = [] { const char* v = getenv("LCC_TALL_SCHED"); return v ? atoi(v) : 0; }();   // 0 compiler order, 1 pinned, 2 pinned + spread DMA
+  if (sched == 2)
+    gemm_tall_kernel<EPI, 2><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
+  else if (sched == 1)
     gemm_tall_kernel<EPI, 1><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
   else
     gemm_tall_kernel<EPI, 0><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);

@@ -40,9 +40,10 @@ def _visual(model):
 
 @torch.inference_mode()
 def probe(model, cfg: LiveCCConfig, input_ids: np.ndarray, pixel_values: Optional[torch.Tensor], grid_thw,
-          overrides: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+          overrides: Optional[Dict[str, torch.Tensor]] = None, light: bool = False) -> Dict[str, torch.Tensor]:
     """One prefill forward (no cache) with recording / replacing hooks.  Tensors come back in the model's dtype, on CPU:
-    vit_* [depth, P, E], llm_* [L, S, H], final_in [S, H], logits [V] (fp32), vit_merged [P/4, H]."""
+    vit_* [depth, P, E], llm_* [L, S, H], final_in [S, H], logits [V] (fp32), vit_merged [P/4, H].
+    light=True: no hooks at all -- only `logits` of the last position (a plain free-running forward)."""
     dtype = next(model.parameters()).dtype
     ov = overrides or {}
     rec: Dict[str, list] = {k: [] for k in ("vit_in", "vit_out", "llm_in", "llm_mid", "llm_out")}
@@ -72,6 +73,15 @@ def probe(model, cfg: LiveCCConfig, input_ids: np.ndarray, pixel_values: Optiona
         return hook
 
     vis, txt = _visual(model), _text_model(model)
+    if light:
+        ids = torch.as_tensor(np.asarray(input_ids), dtype=torch.long).view(1, -1)
+        kwargs = dict(input_ids=ids, use_cache=False, logits_to_keep=1,
+                      mm_token_type_ids=torch.as_tensor(protocol.mm_token_type_ids(ids.numpy(), cfg)))
+        if pixel_values is not None:
+            kwargs["pixel_values_videos"] = pixel_values.to(dtype)
+            kwargs["video_grid_thw"] = torch.as_tensor([list(grid_thw)], dtype=torch.long)
+        model.model.rope_deltas = None
+        return dict(logits=model(**kwargs).logits[0, -1].float().clone())
     for l, blk in enumerate(vis.blocks):
         handles.append(blk.register_forward_pre_hook(pre_replace("vit_in", l), with_kwargs=True))
         handles.append(blk.register_forward_hook(post_record("vit_out")))

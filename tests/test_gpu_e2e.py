@@ -390,13 +390,14 @@ def test_one_shot_long_clip_decode_positions_follow_last_row(dev, tiny_models):
 
 
 @pytest.mark.skipif(__import__("os").environ.get("LCC_SKIP_SLOW") == "1", reason="LCC_SKIP_SLOW=1")
-def test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference(dev):
+def test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference(dev, slow_budget):
     """BASELINE.json configs[0]: Qwen2-VL-2B (real shapes: 28 layers, hidden 1536, 12/2 heads, tied 151936-row lm_head, full
     32-block ViT), one 8-frame 392x728 clip = chunks 6 + 2, greedy, repetition_penalty 1.05, 16 tokens per turn -- the native
     path against the reference's CPU path (HF bf16 on the host cores, teacher-forced along the native tokens).  Only the bf16
     oracle is run at this size (the fp32 twin would double the host time); with random weights and a 152k vocabulary many
     top-1/top-2 margins are below one bf16 ulp, so free-running identity is required for half of the steps and the
     margin-aware rule for all of them."""
+    slow_budget(150)
     from livecc_amd import protocol
     from livecc_amd.config import qwen2vl_2b
     from livecc_amd.modeling import LiveCCForConditionalGeneration
