@@ -856,7 +856,10 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
     if (diag == 4 && !a.w_fp8) return launch_big_s<BM, EPI, 4, false>(a, st);
     if (diag == 5 && !a.w_fp8) return launch_big_s<BM, EPI, 5, false>(a, st);
   }
-  static const int spread = [] { const char* v = getenv("LCC_GEMM_SCHED"); return (v && atoi(v) == 6) ? 1 : 0; }();
+  // pinned fragment-read pipeline with the LDS-DMA pieces spread between the row-tile steps (SCHED 6, default since round 3:
+  // bit-identical to the burst-behind-the-barrier order SCHED 1 -- tools/gemm_checksum.py -- and 1.6-3.3 % faster on the prefill
+  // GEMMs, +0.6 / +0.8 % tokens/s at 1 / 8 streams, profiles/r03/gemm_sched_spread_dma.txt); LCC_GEMM_SCHED=1 restores SCHED 1
+  static const int spread = [] { const char* v = getenv("LCC_GEMM_SCHED"); return (v && atoi(v) == 1) ? 0 : 1; }();
   if (a.w_fp8) launch_big_s<BM, EPI, 1, true>(a, st);
   else if (g_gemm_sched && spread) launch_big_s<BM, EPI, 6, false>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
