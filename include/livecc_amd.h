@@ -74,8 +74,10 @@ int lcc_debug_set_attn_variant(int variant);
 int lcc_debug_set_fused_tails(int on);
 /* decode launch sequence of the engine: 1 (default) = pipeline v2 where eligible (bf16 weights, the row-permuted decode copy
  * "llm.<i>.qkv_w_dec" of every q|k|v weight set): RMSNorm / bias + M-RoPE + KV append / residual add run inside the weight-streaming
- * GEMVs, 6 launches per layer, for the batch sizes the engine routes to it (see lcc_llm_decode); 0 = the round-1 sequence of 9 launches
- * per layer (always used with fp8 weights and for larger batches).  Merging the attention key splits inside the o_proj GEMV as well (5 launches) was
+ * GEMVs, 6 launches per layer, for decode batches of ONE or TWO streams (lcc_llm_decode: `n_streams <= 2`; measured: 640 vs 655 tokens/s
+ * at four streams, so larger batches keep the round-1 sequence; the MR = 4 forms of the kernels are reachable only through the
+ * lcc_dgemv_* operators below); bf16 weights, and since round 3 fp8 weights that carry the permuted decode copy + its scales;
+ * 0 = the round-1 sequence of 9 launches per layer.  Merging the attention key splits inside the o_proj GEMV as well (5 launches) was
  * measured slower: 4-wave attention blocks 10.0 us + o_proj 9.8 us vs 7.3 + 4.9 + 6.8 us. */
 int lcc_debug_set_decode_path(int path);
 /* 1: pipeline v2 launches down_proj of layer l and the q/k/v GEMV of layer l+1 as ONE chained launch (5 launches per layer; default 0:
@@ -191,7 +193,8 @@ int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode use
                                           KV head) pairs; bit 2: for every batch; bit 1: key splits merged in the same launch by the
                                           last-arriving block instead of a combine launch (default off) */
 
-/* ---- decode pipeline v2 (csrc/decode_v2.hip): one new token per stream (M <= 4 rows), the elementwise stages of the decoder layer
+/* ---- decode pipeline v2 (csrc/decode_v2.hip) as operators: one new token per stream (M <= 4 rows here; the ENGINE uses them for batches
+ * of one or two streams), the elementwise stages of the decoder layer
  * run INSIDE the weight-streaming GEMVs.  Residual stream h [M,K] bf16 + `stats` fp32 [M, K/16]: per-16-channel sums of squares of h,
  * the input of the RMSNorm prologue (Q2VL:96-110) of the next GEMV; K % 64 == 0, K <= 8192, M*K <= 16384.  W = MFMA-fragment-packed bf16
  * (`wscale` NULL) or, round 3, OCP e4m3 bytes in the PACKED8 order of lcc_gemm_w8_bf16 with `wscale` = fp32 scale per STORED row
