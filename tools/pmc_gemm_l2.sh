@@ -3,7 +3,8 @@
 # LDS-DMA ring come from?  The round-3 timing split says the ring is THROUGHPUT-bound at ~12 TB/s chip-wide (profiles/r03/gemm_diag.jsonl);
 # these passes ask whether that is the L2 (hit bandwidth, same-line contention), the fabric behind it (MALL / HBM misses), or the CU side
 # (TCP / TA).  One rocprofv3 pass per counter group (never combined with trace domains), kernel = gemm_big_kernel<256,...> at M = 3088
-# and the M = 386 kernels of tools/pmc_target.py --gemm.
+# and the M = 386 kernels of tools/pmc_target.py --gemm.  (Counter names checked against /opt/rocm/share/rocprofiler-sdk/counter_defs.yaml
+# for gfx950; a pass whose group cannot be scheduled together is reported and skipped.)
 #   tools/pmc_gemm_l2.sh <out_dir>
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -17,8 +18,10 @@ for C in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
          "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RD_UNCACHED_32B_sum TCC_BUBBLE_sum" \
          "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
          "TCC_TAG_STALL_sum TCC_BUSY_sum TCC_CYCLE_sum TCC_NORMAL_WRITEBACK_sum" \
-         "TA_BUSY_avr TA_BUFFER_LOAD_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
-         "SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
+         "TA_BUSY_avr TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
+         "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_GMI_32B_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_LEVEL_sum" \
+         "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCC_LATENCY_FIFO_FULL_sum TCC_SRC_FIFO_FULL_sum" \
+         "SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pass$i -o gemm -- python $R/tools/pmc_target.py --gemm > $O/pass$i.log 2>&1 || echo "pass $i ($C) failed: $(tail -n 1 $O/pass$i.log)"
   find $O/pass$i -name '*kernel_trace.csv' -delete
