@@ -324,6 +324,19 @@ def native_parity_turns(model, cfg, args, protocol, turns, dev):
     return np.asarray(toks), np.stack(logits)
 
 
+def pmc_traffic_if_current(path):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/roofline_traffic.json) -- or None when
+    the kernel's source file has changed since that pass (the file records its sha256: a counter of ANOTHER kernel version is not reported)."""
+    import hashlib
+    d = json.load(open(path))
+    src, want = d.get("kernel_source"), d.get("kernel_source_sha16")
+    if src and want:
+        with open(os.path.join(ROOT, src), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest()[:16] != want:
+                return None
+    return d.get("gemv_gate_up_hbm_bytes_per_launch")
+
+
 def parity_report(native_tokens, native_logits, ref, ref32=None):
     """ref / ref32: npz of oracle/cpu_baseline.py (`logits` [turns, N, V], `own_argmax` [turns, N]).  Only complete turns count."""
     lg, own = ref["logits"], ref["own_argmax"]
@@ -507,7 +520,7 @@ def main():
             if os.path.exists(tp):
                 try:   # the committed PMC pass measured the LiveCC-7B bf16 single-stream launch; other shapes have no counter data
                     if cfg.name == "livecc-7b" and spg == 1 and not fp8:
-                        traffic = json.load(open(tp)).get("gemv_gate_up_hbm_bytes_per_launch")
+                        traffic = pmc_traffic_if_current(tp)
                 except Exception:
                     traffic = None
             roof = dict(bound="hbm", kernel=("fp8 " if fp8 else "") + "decode gate/up weight-streaming GEMV + SwiGLU", achieved=round(ach, 1),

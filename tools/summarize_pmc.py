@@ -21,7 +21,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 fetch = res["FETCH_SIZE"]["mean_raw"]
 write = res["WRITE_SIZE"]["mean_raw"]
 alg = 2 * 18944 * 3584 * 2 + 3584 * 2 + 18944 * 2
-d = dict(kernel="dgemv_kernel<2,NORM,SWIGLU,4,1> ([RMSNorm] gate/up GEMV [SwiGLU]) M=1 N=37888 K=3584", algorithmic_bytes_per_launch=alg,
+import hashlib  # noqa: E402
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "livecc_amd", "csrc", "decode_v2.hip")
+d = dict(kernel="dgemv_kernel<2,NORM,SWIGLU,4,1> ([RMSNorm] gate/up GEMV [SwiGLU]) M=1 N=37888 K=3584",
+         kernel_source="livecc_amd/csrc/decode_v2.hip",      # bench.py nulls `roofline.traffic` when this file has changed since the PMC pass
+         kernel_source_sha16=hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16], algorithmic_bytes_per_launch=alg,
          fetch_size_kib_raw=fetch, write_size_kib_raw=write,
          gemv_gate_up_hbm_bytes_per_launch=(fetch * 1024 * 2 + (write or 0) * 1024) if fetch else None,
          note="FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024 (uncalibrated)", passes=res)
