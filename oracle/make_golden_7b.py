@@ -1,0 +1,86 @@
+"""ORACLE / TEST INFRASTRUCTURE: tests/golden/livecc7b_first_token.npz -- the executed HF reference at the REAL LiveCC-7B shapes.
+
+    python oracle/make_golden_7b.py            (build container: ~62 GB of host RAM, minutes on 8 cores)
+
+HF `Qwen2VLForConditionalGeneration` at LiveCC-7B shapes, filled with the seeded synthetic weights `tiled:0` (bit-identical to
+`WeightArena.fill_tiled(0)` on the GPU), runs the 6-frame first turn of BASELINE.json configs[1] (4,368 patches through the vision tower,
+a 1,131-token prefill) free-running, once in bf16 (the reference's dtype) and once in fp32 on the same bf16-representable weights (the
+truth).  Stored: the raw lm_head logits of the last prompt position = the distribution of the turn's first generated token, both runs
+(bf16 run exactly as uint16 bit patterns, fp32 as float32), the prompt ids, the grid and the seeds.  The GPU test
+(tests/test_gpu_golden.py::test_livecc7b_first_token_against_the_committed_hf_logits) compares the HIP path with these numbers WITHOUT
+running HF on the GPU box: a full-shape golden vector that travels.
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from livecc_amd import protocol  # noqa: E402
+from livecc_amd.config import get_config  # noqa: E402
+from oracle import hf_oracle as O, layer_probe as P  # noqa: E402
+
+SEED_IN, T, H, W = 1234, 6, 392, 728
+PATH = os.path.join(ROOT, "tests", "golden", "livecc7b_first_token.npz")
+
+
+def inputs(cfg):
+    frames = torch.from_numpy(protocol.synth_frames(T, H, W, seed=SEED_IN, layout="TCHW"))
+    pv, grid = O.patchify_normalize_ref(frames, cfg)
+    ids = protocol.TurnBuilder(cfg, seed=SEED_IN).turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    return frames, pv, grid, ids
+
+
+def generate():
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = get_config("livecc-7b")
+    frames, pv, grid, ids = inputs(cfg)
+    t0 = time.time()
+    hf = O.build_hf_model_synthetic(cfg, torch.bfloat16, "tiled:0")
+    print(f"built bf16 model in {time.time() - t0:.0f} s", flush=True)
+    t0 = time.time()
+    l16 = P.probe(hf, cfg, ids, pv, grid, light=True)["logits"]          # fp32 copy of bf16 values
+    print(f"bf16 forward {time.time() - t0:.0f} s", flush=True)
+    t0 = time.time()
+    hf = hf.float()
+    l32 = P.probe(hf, cfg, ids, pv, grid, light=True)["logits"]
+    print(f"fp32 convert + forward {time.time() - t0:.0f} s", flush=True)
+    b16 = l16.to(torch.bfloat16)
+    assert torch.equal(b16.float(), l16), "the bf16 run's logits are bf16 numbers"
+    return dict(logits_bf16_bits=b16.view(torch.int16).numpy().view(np.uint16), logits_fp32=l32.numpy().astype(np.float32),
+                ids=np.asarray(ids, dtype=np.int64), grid=np.asarray(grid, dtype=np.int64),
+                meta=np.asarray([SEED_IN, T, H, W, 0], dtype=np.int64))     # last entry: weight seed of tiled:<seed>
+
+
+def load(path=PATH):
+    d = dict(np.load(path))
+    bits = torch.from_numpy(d["logits_bf16_bits"].view(np.int16).copy())
+    d["logits_bf16"] = bits.view(torch.bfloat16).float().numpy()
+    return d
+
+
+def compare(native_logits: np.ndarray, fx: dict) -> dict:
+    """Statistics of the native first-token logits against the committed HF runs (numpy only: usable on the GPU box without HF)."""
+    n, b, t = native_logits.astype(np.float64).ravel(), fx["logits_bf16"].astype(np.float64).ravel(), fx["logits_fp32"].astype(np.float64).ravel()
+    scale = float(np.abs(t).max())
+    en, eb = n - t, b - t
+    srt = np.sort(t)
+    rep = dict(scale=scale, rms_err_native=float(np.sqrt((en ** 2).mean())), rms_err_ref16=float(np.sqrt((eb ** 2).mean())),
+               max_err_native=float(np.abs(en).max()), max_err_ref16=float(np.abs(eb).max()),
+               max_abs_native_vs_ref16=float(np.abs(n - b).max()), argmax_native=int(n.argmax()), argmax_ref16=int(b.argmax()),
+               argmax_fp32=int(t.argmax()), fp32_top1_margin=float(srt[-1] - srt[-2]))
+    rep["rms_ratio"] = rep["rms_err_native"] / max(rep["rms_err_ref16"], 1e-30)
+    rep["max_ratio"] = rep["max_err_native"] / max(rep["max_err_ref16"], 1e-30)
+    return rep
+
+
+if __name__ == "__main__":
+    out = generate()
+    np.savez_compressed(PATH, **out)
+    fx = load()
+    print("self-check (bf16 run as the 'native' side):", compare(fx["logits_bf16"], fx))
+    print("wrote", PATH, os.path.getsize(PATH), "bytes")

@@ -85,3 +85,35 @@ def test_native_stages_against_the_per_stage_golden_fixture(dev):
     frames = torch.from_numpy(protocol.synth_frames(10, H, W, seed=seed_in, layout="TCHW"))[:n_frames]
     nat = native_probe(native, cfg, g["ids"], frames.to(dev), a16)
     _compare("per_stage_golden_tiny", nat, a16, t32, cfg, g["ids"])
+
+
+def test_livecc7b_first_token_against_the_committed_hf_logits(dev):
+    """REAL LiveCC-7B shapes against a COMMITTED golden vector (tests/golden/livecc7b_first_token.npz, oracle/make_golden_7b.py: the
+    executed HF reference -- bf16 run and fp32 truth -- on the seeded `tiled:0` weights, 6-frame first turn of BASELINE configs[1],
+    4,368 patches + a 1,131-token prefill, free-running).  No HF forward on the GPU box: the native first-token logits must be as
+    close to the committed fp32 truth as the committed bf16 reference run is (rms over the 152,064 logits <= 1.25 x, worst logit
+    <= 1.5 x + 1e-3 x scale), within 6e-2 x scale of the bf16 run, and pick the fp32 argmax (its margin, 0.49, is 2.5 x the worst error)."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.weights import WeightArena
+    from oracle import make_golden_7b as G
+    fx = G.load()
+    seed_in, T, H, W, seed_w = (int(x) for x in fx["meta"])
+    cfg = get_config("livecc-7b")
+    frames = torch.from_numpy(protocol.synth_frames(T, H, W, seed=seed_in, layout="TCHW"))
+    ids = protocol.TurnBuilder(cfg, seed=seed_in).turn_ids(0, protocol.num_video_tokens(tuple(int(x) for x in fx["grid"]), cfg))
+    assert np.array_equal(np.asarray(ids), fx["ids"]), "the prompt of the fixture is rebuilt from its seeds"
+    arena = WeightArena(cfg, dev).fill_tiled(seed=seed_w)
+    native = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=1, max_kv_len=2048, max_new_rows=1280, max_patches=4608, max_history=4)
+    r = native.generate(input_ids=torch.from_numpy(np.asarray(ids)).view(1, -1), frames=frames.to(dev), frames_layout="TCHW", max_new_tokens=1,
+                        output_logits=True, do_sample=False)
+    n_log = r.logits[0].float().cpu().numpy().reshape(-1)
+    r.past_key_values.release()
+    rep = G.compare(n_log, fx)
+    record("livecc7b_first_token_vs_committed_golden", rep)
+    print("LiveCC-7B first token vs the committed HF logits:", rep)
+    assert rep["rms_ratio"] <= 1.25, rep
+    assert rep["max_err_native"] <= 1.5 * rep["max_err_ref16"] + 1e-3 * rep["scale"], rep
+    assert rep["max_abs_native_vs_ref16"] <= 6e-2 * rep["scale"], rep
+    assert rep["argmax_native"] == rep["argmax_fp32"] == rep["argmax_ref16"], rep

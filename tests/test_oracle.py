@@ -114,3 +114,26 @@ def test_layer_probe_reproduces_the_per_stage_fixture():
     # the bf16 reference's own per-layer error against the teacher-forced truth: the unit of the per-layer parity bound
     for r in P.layer_error_table(a_ref, a_ref, t_ref, ["vit_out", "llm_mid", "llm_out"]):
         assert 1e-4 < r["err_ref16_rms"] / r["scale_rms"] < 2e-2, r
+
+
+def test_livecc7b_golden_fixture_is_selfconsistent_and_rebuildable_from_its_seeds():
+    """tests/golden/livecc7b_first_token.npz (oracle/make_golden_7b.py: HF at the REAL LiveCC-7B shapes, bf16 run + fp32 truth): the
+    prompt ids are rebuilt from the stored seeds, the bf16 run is stored exactly (bit patterns), both runs pick the same token with a
+    margin well above their difference, and the comparison helper the GPU test uses reports the bf16 run against itself as ratio 1."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from oracle import make_golden_7b as G
+    fx = G.load()
+    cfg = get_config("livecc-7b")
+    seed_in, T, H, W, seed_w = (int(x) for x in fx["meta"])
+    assert (T, H, W, seed_w) == (6, 392, 728, 0)
+    grid = tuple(int(x) for x in fx["grid"])
+    assert grid == (3, 28, 52) and protocol.num_video_tokens(grid, cfg) == 1092
+    ids = protocol.TurnBuilder(cfg, seed=seed_in).turn_ids(0, 1092)
+    assert np.array_equal(np.asarray(ids), fx["ids"]) and len(ids) == 1131
+    assert fx["logits_fp32"].shape == (cfg.vocab_size,) and fx["logits_bf16"].shape == (cfg.vocab_size,)
+    assert np.array_equal(torch.from_numpy(fx["logits_bf16"]).to(torch.bfloat16).float().numpy(), fx["logits_bf16"])     # bf16 numbers
+    rep = G.compare(fx["logits_bf16"], fx)
+    assert rep["rms_ratio"] == 1.0 and rep["max_abs_native_vs_ref16"] == 0.0
+    assert rep["argmax_ref16"] == rep["argmax_fp32"] and rep["fp32_top1_margin"] > 2.0 * rep["max_err_ref16"]
+    assert 0.02 < rep["rms_err_ref16"] / 1.0 < 0.08 and 4.0 < rep["scale"] < 7.0          # 0.8 % of the logit scale: bf16 after 28 layers
