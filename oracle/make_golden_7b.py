@@ -78,9 +78,53 @@ def compare(native_logits: np.ndarray, fx: dict) -> dict:
     return rep
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--decisive" not in sys.argv:
     out = generate()
     np.savez_compressed(PATH, **out)
     fx = load()
     print("self-check (bf16 run as the 'native' side):", compare(fx["logits_bf16"], fx))
     print("wrote", PATH, os.path.getsize(PATH), "bytes")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the `decisive` weight set: HF's own free-running greedy tokens over two turns (north_star: "token-id exact under greedy")
+# ---------------------------------------------------------------------------------------------------------------------
+PATH_DECISIVE = os.path.join(ROOT, "tests", "golden", "livecc7b_decisive_stream.npz")
+TOPK = 8
+
+
+def generate_decisive(turns: int = 2, max_new: int = 16, penalty: float = 1.05):
+    """HF bf16 at LiveCC-7B shapes on the `decisive:0` weights (top-1 margins of tens of noise units: livecc_amd/weights.py), the
+    benchmark protocol's first `turns` turns (6 + 2 frames), 16 greedy tokens each with repetition_penalty 1.05, FREE-running: HF's own
+    tokens, and per step its top-8 raw logits (ids + values) and the logit scale -- enough for a GPU test to demand token identity and
+    to check that the decision was not made by rounding, without running HF on the GPU box."""
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = get_config("livecc-7b")
+    n_frames = 6 + 2 * (turns - 1)
+    frames = torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=SEED_IN, layout="TCHW"))
+    t0 = time.time()
+    hf = O.build_hf_model_synthetic(cfg, torch.bfloat16, "decisive:0")
+    print(f"built bf16 decisive model in {time.time() - t0:.0f} s", flush=True)
+    t0 = time.time()
+    res = O.replay_stream(hf, cfg, frames, protocol.TurnBuilder(cfg, seed=SEED_IN), max_new, penalty, max_turns=turns)
+    print(f"{turns} turns in {time.time() - t0:.0f} s", flush=True)
+    out = dict(n_turns=np.int64(len(res)), meta=np.asarray([SEED_IN, n_frames, H, W, max_new, 0], dtype=np.int64))
+    for ti, r in enumerate(res):
+        lg = torch.stack(r["logits"]).float()                          # [N, V] raw lm_head logits of every step
+        top = lg.topk(TOPK, dim=-1)
+        out[f"t{ti}_ids"] = np.asarray(r["turn_ids"], dtype=np.int64)
+        out[f"t{ti}_grid"] = np.asarray(r["grid"], dtype=np.int64)
+        out[f"t{ti}_tokens"] = np.asarray(r["new_tokens"], dtype=np.int64)
+        out[f"t{ti}_top_ids"] = top.indices.numpy().astype(np.int64)
+        out[f"t{ti}_top_vals"] = top.values.numpy().astype(np.float32)
+        out[f"t{ti}_scale"] = lg.abs().max(dim=-1).values.numpy().astype(np.float32)
+    return out
+
+
+if __name__ == "__main__" and "--decisive" in sys.argv:
+    out = generate_decisive()
+    np.savez_compressed(PATH_DECISIVE, **out)
+    for ti in range(int(out["n_turns"])):
+        m = out[f"t{ti}_top_vals"][:, 0] - out[f"t{ti}_top_vals"][:, 1]
+        print(f"turn {ti}: tokens {out[f't{ti}_tokens'].tolist()}  min raw top-1 margin / scale = {float((m / out[f't{ti}_scale']).min()):.3f}")
+    print("wrote", PATH_DECISIVE, os.path.getsize(PATH_DECISIVE), "bytes")

@@ -137,3 +137,28 @@ def test_livecc7b_golden_fixture_is_selfconsistent_and_rebuildable_from_its_seed
     assert rep["rms_ratio"] == 1.0 and rep["max_abs_native_vs_ref16"] == 0.0
     assert rep["argmax_ref16"] == rep["argmax_fp32"] and rep["fp32_top1_margin"] > 2.0 * rep["max_err_ref16"]
     assert 0.02 < rep["rms_err_ref16"] / 1.0 < 0.08 and 4.0 < rep["scale"] < 7.0          # 0.8 % of the logit scale: bf16 after 28 layers
+
+
+def test_livecc7b_decisive_golden_stream_is_decided_by_margin_and_rebuildable():
+    """tests/golden/livecc7b_decisive_stream.npz: HF's committed free-running greedy tokens on the decisive weights at LiveCC-7B shapes.
+    Every step's raw top-1 margin is tens of times the bf16 logit noise (>= 25 % of the logit scale against ~4 %), every emitted token is
+    the raw top-1 unless the repetition penalty demoted it, and the turn prompts are rebuilt from the seeds."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "livecc7b_decisive_stream.npz")))
+    cfg = get_config("livecc-7b")
+    seed_in, n_frames, H, W, max_new, seed_w = (int(x) for x in g["meta"])
+    assert (n_frames, H, W, max_new, seed_w, int(g["n_turns"])) == (8, 392, 728, 16, 0, 2)
+    b = protocol.TurnBuilder(cfg, seed=seed_in)
+    seen_all = []
+    for ti in range(2):
+        grid = tuple(int(x) for x in g[f"t{ti}_grid"])
+        assert np.array_equal(g[f"t{ti}_ids"], np.asarray(b.turn_ids(ti, protocol.num_video_tokens(grid, cfg))))
+        vals, idx, toks, scale = g[f"t{ti}_top_vals"], g[f"t{ti}_top_ids"], g[f"t{ti}_tokens"], g[f"t{ti}_scale"]
+        assert toks.shape == (16,) and vals.shape == (16, 8)
+        assert float(((vals[:, 0] - vals[:, 1]) / scale).min()) >= 0.25
+        seen_all += g[f"t{ti}_ids"].tolist()
+        for k in range(16):
+            assert toks[k] == idx[k, 0] or int(idx[k, 0]) in seen_all, "a token other than the raw top-1 needs the repetition penalty"
+            seen_all.append(int(toks[k]))
+    assert len(set(g["t0_tokens"].tolist() + g["t1_tokens"].tolist())) >= 30       # the permutation walk does not loop
