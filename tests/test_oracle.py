@@ -162,3 +162,29 @@ def test_livecc7b_decisive_golden_stream_is_decided_by_margin_and_rebuildable():
             assert toks[k] == idx[k, 0] or int(idx[k, 0]) in seen_all, "a token other than the raw top-1 needs the repetition penalty"
             seen_all.append(int(toks[k]))
     assert len(set(g["t0_tokens"].tolist() + g["t1_tokens"].tolist())) >= 30       # the permutation walk does not loop
+
+
+def test_qwen2vl2b_config0_golden_stream_is_rebuildable_from_its_seeds():
+    """tests/golden/qwen2vl2b_config0_stream.npz (oracle/make_golden_2b.py: HF bf16 at the real Qwen2-VL-2B shapes, BASELINE configs[0],
+    free-running): prompts rebuilt from the seeds, per-step top-64 sorted, the emitted token is the raw top-1 unless the repetition
+    penalty demoted a seen id, sample ids reproducible."""
+    from livecc_amd import protocol
+    from livecc_amd.config import qwen2vl_2b
+    from oracle import make_golden_2b as G
+    g = dict(np.load(G.PATH))
+    cfg = qwen2vl_2b()
+    seed_w, seed_in, n_frames, H, W, max_new = (int(x) for x in g["meta"])
+    assert (seed_w, n_frames, H, W, max_new, int(g["n_turns"])) == (0, 8, 392, 728, 16, 2)
+    assert np.array_equal(g["sample_ids"], G.sample_ids(cfg.vocab_size))
+    b = protocol.TurnBuilder(cfg, seed=seed_in)
+    seen = []
+    for ti in range(2):
+        grid = tuple(int(x) for x in g[f"t{ti}_grid"])
+        assert np.array_equal(g[f"t{ti}_ids"], np.asarray(b.turn_ids(ti, protocol.num_video_tokens(grid, cfg))))
+        vals, idx, toks = g[f"t{ti}_top_vals"], g[f"t{ti}_top_ids"], g[f"t{ti}_tokens"]
+        assert vals.shape == (16, 64) and (np.diff(vals, axis=1) <= 0).all() and g[f"t{ti}_sample_vals"].shape == (16, 2048)
+        assert (np.abs(vals[:, 0]) <= g[f"t{ti}_scale"] + 1e-6).all()
+        seen += g[f"t{ti}_ids"].tolist()
+        for k in range(16):
+            assert toks[k] == idx[k, 0] or int(idx[k, 0]) in seen
+            seen.append(int(toks[k]))
