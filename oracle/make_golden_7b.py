@@ -78,7 +78,7 @@ def compare(native_logits: np.ndarray, fx: dict) -> dict:
     return rep
 
 
-if __name__ == "__main__" and "--decisive" not in sys.argv:
+if __name__ == "__main__" and "--decisive" not in sys.argv and "--turns" not in sys.argv:
     out = generate()
     np.savez_compressed(PATH, **out)
     fx = load()
@@ -128,3 +128,65 @@ if __name__ == "__main__" and "--decisive" in sys.argv:
         m = out[f"t{ti}_top_vals"][:, 0] - out[f"t{ti}_top_vals"][:, 1]
         print(f"turn {ti}: tokens {out[f't{ti}_tokens'].tolist()}  min raw top-1 margin / scale = {float((m / out[f't{ti}_scale']).min()):.3f}")
     print("wrote", PATH_DECISIVE, os.path.getsize(PATH_DECISIVE), "bytes")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the benchmark's two turns on the tiled:0 weights: HF bf16 free-running + HF fp32 teacher-forced along the same tokens
+# ---------------------------------------------------------------------------------------------------------------------
+PATH_TURNS = os.path.join(ROOT, "tests", "golden", "livecc7b_two_turns.npz")
+TOPK_T, NSAMPLE_T = 64, 4096
+
+
+def sample_ids(vocab: int) -> np.ndarray:
+    return np.sort(np.random.default_rng(SEED_IN).choice(vocab, NSAMPLE_T, replace=False)).astype(np.int64)
+
+
+def generate_turns(turns: int = 2, max_new: int = 16, penalty: float = 1.05):
+    """BASELINE configs[1]'s first two turns (6 + 2 frames, 16 greedy tokens each, repetition_penalty 1.05) at LiveCC-7B shapes on the
+    `tiled:0` weights: HF bf16 free-running (its own tokens), then HF fp32 on the same weights teacher-forced along those tokens.  Per
+    step: the bf16 run's top-64 raw logits (ids + values), both runs' values at 4,096 fixed sample ids and at those top-64 ids, the logit
+    scale, and the fp32 top-1 / top-2 -- enough for error-ratio and margin-aware token checks on the GPU box without HF (prepared in
+    round 3; the GPU test against it is next round's)."""
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = get_config("livecc-7b")
+    n_frames = 6 + 2 * (turns - 1)
+    frames = torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=SEED_IN, layout="TCHW"))
+    hf = O.build_hf_model_synthetic(cfg, torch.bfloat16, "tiled:0")
+    t0 = time.time()
+    res = O.replay_stream(hf, cfg, frames, protocol.TurnBuilder(cfg, seed=SEED_IN), max_new, penalty, max_turns=turns)
+    print(f"bf16: {turns} turns in {time.time() - t0:.0f} s", flush=True)
+    t0 = time.time()
+    hf = hf.float()
+    s32 = O.OracleStream(hf, cfg)
+    sid = torch.from_numpy(sample_ids(cfg.vocab_size))
+    out = dict(n_turns=np.int64(len(res)), meta=np.asarray([SEED_IN, n_frames, H, W, max_new, 0], dtype=np.int64), sample_ids=sid.numpy())
+    for ti, (r, (a, b)) in enumerate(zip(res, protocol.split_clip(n_frames))):
+        pv, grid = O.patchify_normalize_ref(frames[a:b], cfg)
+        r32 = s32.turn(r["turn_ids"], pv, grid, max_new_tokens=max_new, repetition_penalty=penalty, teacher_tokens=r["new_tokens"])
+        l16, l32 = torch.stack(r["logits"]).float(), torch.stack(r32["logits"]).float()
+        top = l16.topk(TOPK_T, dim=-1)
+        t32 = l32.topk(2, dim=-1)
+        out[f"t{ti}_ids"] = np.asarray(r["turn_ids"], dtype=np.int64)
+        out[f"t{ti}_grid"] = np.asarray(grid, dtype=np.int64)
+        out[f"t{ti}_tokens"] = np.asarray(r["new_tokens"], dtype=np.int64)
+        out[f"t{ti}_top_ids"] = top.indices.numpy().astype(np.int64)
+        out[f"t{ti}_top_vals_bf16"] = top.values.numpy().astype(np.float32)
+        out[f"t{ti}_top_vals_fp32"] = torch.gather(l32, 1, top.indices).numpy().astype(np.float32)
+        out[f"t{ti}_sample_vals_bf16"] = l16[:, sid].numpy().astype(np.float32)
+        out[f"t{ti}_sample_vals_fp32"] = l32[:, sid].numpy().astype(np.float32)
+        out[f"t{ti}_scale"] = l32.abs().max(dim=-1).values.numpy().astype(np.float32)
+        out[f"t{ti}_fp32_top2_ids"] = t32.indices.numpy().astype(np.int64)
+        out[f"t{ti}_fp32_top2_vals"] = t32.values.numpy().astype(np.float32)
+        out[f"t{ti}_rms_err_bf16_full_vocab"] = (l16 - l32).double().pow(2).mean(dim=-1).sqrt().numpy().astype(np.float32)
+    print(f"fp32: convert + {turns} turns in {time.time() - t0:.0f} s", flush=True)
+    return out
+
+
+if __name__ == "__main__" and "--turns" in sys.argv:
+    out = generate_turns()
+    np.savez_compressed(PATH_TURNS, **out)
+    for ti in range(int(out["n_turns"])):
+        e = np.sqrt(((out[f"t{ti}_sample_vals_bf16"] - out[f"t{ti}_sample_vals_fp32"]).astype(np.float64) ** 2).mean(axis=-1))
+        print(f"turn {ti}: tokens {out[f't{ti}_tokens'].tolist()}")
+        print(f"   rms(bf16 - fp32) over the sample ids / full vocabulary: {e.mean():.4f} / {float(out[f't{ti}_rms_err_bf16_full_vocab'].mean()):.4f}")
+    print("wrote", PATH_TURNS, os.path.getsize(PATH_TURNS), "bytes")

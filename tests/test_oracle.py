@@ -188,3 +188,27 @@ def test_qwen2vl2b_config0_golden_stream_is_rebuildable_from_its_seeds():
         for k in range(16):
             assert toks[k] == idx[k, 0] or int(idx[k, 0]) in seen
             seen.append(int(toks[k]))
+
+
+def test_livecc7b_two_turn_golden_is_consistent_with_the_first_token_fixture():
+    """tests/golden/livecc7b_two_turns.npz (make_golden_7b.py --turns: HF bf16 free-running + HF fp32 teacher-forced, LiveCC-7B shapes,
+    tiled:0 weights, the benchmark's first two turns): its first step agrees with the full-vocabulary first-token fixture, the 4,096
+    sample ids reproduce, and the rms error over the sample ids tracks the stored full-vocabulary rms within 5 % at every step (so a
+    GPU test may use the samples for the error ratio)."""
+    from livecc_amd.config import get_config
+    from oracle import make_golden_7b as G
+    g = dict(np.load(G.PATH_TURNS))
+    fx = G.load()
+    cfg = get_config("livecc-7b")
+    sid = g["sample_ids"]
+    assert np.array_equal(sid, G.sample_ids(cfg.vocab_size)) and int(g["n_turns"]) == 2
+    assert np.array_equal(g["t0_ids"], fx["ids"])
+    # step 0 of turn 0 = the first-token fixture (same weights, same prompt; the bf16 run is deterministic on one host)
+    assert np.array_equal(g["t0_sample_vals_bf16"][0], fx["logits_bf16"][sid])
+    assert np.abs(g["t0_sample_vals_fp32"][0] - fx["logits_fp32"][sid]).max() <= 1e-4
+    assert int(g["t0_tokens"][0]) == int(fx["logits_bf16"].argmax())
+    for ti in range(2):
+        e = np.sqrt(((g[f"t{ti}_sample_vals_bf16"] - g[f"t{ti}_sample_vals_fp32"]).astype(np.float64) ** 2).mean(axis=-1))
+        full = g[f"t{ti}_rms_err_bf16_full_vocab"].astype(np.float64)
+        assert e.shape == (16,) and (np.abs(e / full - 1.0) <= 0.05).all(), (e / full)
+        assert (np.diff(g[f"t{ti}_top_vals_bf16"], axis=1) <= 0).all()
