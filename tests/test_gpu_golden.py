@@ -162,3 +162,109 @@ def test_livecc7b_greedy_tokens_equal_the_committed_hf_tokens_on_decisive_weight
     record("livecc7b_decisive_tokens_vs_committed_golden", dict(tokens_equal=equal, tokens_total=total, worst_rel_dlogit_at_top8=worst))
     assert (equal, total) == (32, 32), f"{equal}/{total} greedy tokens equal HF's committed tokens"
     assert worst <= 6e-2, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two more fixture-based comparisons, WRITTEN at the end of round 3 when no GPU minutes were left to run them once: they are skipped
+# unless LCC_UNVALIDATED_GOLDEN=1 so that an untested test cannot stop the tier; the first GPU call of the next round runs them with
+# the variable set and removes the gate.  (The two tests above were run on the MI355X before they were committed.)
+# ---------------------------------------------------------------------------------------------------------------------
+_UNVALIDATED = pytest.mark.skipif(os.environ.get("LCC_UNVALIDATED_GOLDEN") != "1",
+                                  reason="written without a GPU run (round 3's GPU minutes were spent); LCC_UNVALIDATED_GOLDEN=1 runs it")
+
+
+def _follow_golden_stream(native, cfg, g, frames, n_turns, max_new, top_key, sample_key16=None, sample_key32=None):
+    """The native path along a committed free-running reference stream: per turn the prompt is the golden history + the turn ids; tokens
+    and raw logits are compared step by step while the histories agree, and every turn continues along the GOLDEN tokens."""
+    from livecc_amd import protocol
+    builder = protocol.TurnBuilder(cfg, seed=int(g["meta"][0]))            # callers put the prompt seed in meta[0]
+    for ti in range(n_turns):                                               # the fixture's prompts are rebuilt from the seed
+        assert np.array_equal(g[f"t{ti}_ids"], np.asarray(builder.turn_ids(ti, protocol.num_video_tokens(tuple(int(x) for x in g[f"t{ti}_grid"]), cfg))))
+    state, past = None, None
+    stats = dict(steps=0, tokens_equal=0, decided=0, decided_equal=0, worst_rel_dlogit_top=0.0, ratios=[])
+    sid = g.get("sample_ids")
+    for ti, (a, b) in enumerate(protocol.split_clip(frames.shape[0])[:n_turns]):
+        new = g[f"t{ti}_ids"]
+        ids = new if past is None else np.concatenate([past, new])
+        r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames[a:b], past_key_values=state, repetition_penalty=1.05,
+                            max_new_tokens=max_new, min_new_tokens=max_new, output_logits=True, do_sample=False)
+        state = r.past_key_values
+        toks = r.sequences[0, len(ids):].tolist()
+        gold = g[f"t{ti}_tokens"].tolist()
+        lg = r.logits.float().cpu().numpy()
+        for k in range(max_new):
+            if toks[:k] != gold[:k]:
+                break
+            stats["steps"] += 1
+            stats["tokens_equal"] += int(toks[k] == gold[k])
+            scale = float(g[f"t{ti}_scale"][k])
+            top_ids, top_vals = g[f"t{ti}_top_ids"][k], g[f"t{ti}_{top_key}"][k]
+            d = float(np.abs(lg[k][top_ids] - top_vals).max())
+            stats["worst_rel_dlogit_top"] = max(stats["worst_rel_dlogit_top"], d / scale)
+            # the reference's raw top-1 margin against twice the measured difference: where it decides, the tokens must agree
+            if (top_vals[0] - top_vals[1]) > 2.0 * d and gold[k] == int(top_ids[0]):
+                stats["decided"] += 1
+                stats["decided_equal"] += int(toks[k] == gold[k])
+            if sample_key32 is not None:
+                n, b16, t32 = lg[k][sid].astype(np.float64), g[f"t{ti}_{sample_key16}"][k].astype(np.float64), g[f"t{ti}_{sample_key32}"][k].astype(np.float64)
+                stats["ratios"].append(float(np.sqrt(((n - t32) ** 2).mean()) / np.sqrt(((b16 - t32) ** 2).mean())))
+        past = np.concatenate([ids, np.asarray(gold[:-1], dtype=np.int64)])
+        if toks != gold:                       # the carried cache now holds a different history: later turns are not comparable
+            break
+    if state is not None:
+        state.release()
+    return stats
+
+
+@_UNVALIDATED
+def test_livecc7b_two_turns_against_the_committed_hf_logits(dev):
+    """BASELINE configs[1]'s first two turns at LiveCC-7B shapes (tiled:0 weights) against tests/golden/livecc7b_two_turns.npz: while the
+    native free-running tokens follow HF's, per step |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale, rms over the 4,096 sample
+    ids of (native - fp32) <= 1.25 x rms(HF_bf16 - fp32) (their rms tracks the full vocabulary within 5 %), tokens equal wherever HF's
+    raw top-1 margin exceeds twice the measured difference; at least the first 8 steps are compared."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.weights import WeightArena
+    from oracle import make_golden_7b as G
+    g = dict(np.load(G.PATH_TURNS))
+    seed_in, n_frames, H, W, max_new, seed_w = (int(x) for x in g["meta"])
+    cfg = get_config("livecc-7b")
+    arena = WeightArena(cfg, dev).fill_tiled(seed=seed_w)
+    native = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=1, max_kv_len=4096, max_new_rows=1280, max_patches=4608, max_history=16)
+    frames = torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=seed_in, layout="TCHW"))
+    g2 = dict(g)
+    g2["meta"] = np.asarray([seed_in])          # _follow_golden_stream reads the prompt seed from meta[0]
+    st = _follow_golden_stream(native, cfg, g2, frames, int(g["n_turns"]), max_new, "top_vals_bf16", "sample_vals_bf16", "sample_vals_fp32")
+    record("livecc7b_two_turns_vs_committed_golden", {k: v for k, v in st.items() if k != "ratios"} | dict(worst_rms_ratio=max(st["ratios"]),
+           mean_rms_ratio=float(np.mean(st["ratios"]))))
+    assert st["steps"] >= 8, st
+    assert st["worst_rel_dlogit_top"] <= 6e-2, st
+    assert max(st["ratios"]) <= 1.25, st
+    assert st["decided_equal"] == st["decided"], st
+
+
+@_UNVALIDATED
+def test_qwen2vl2b_config0_against_the_committed_hf_stream(dev):
+    """BASELINE configs[0] (Qwen2-VL-2B real shapes, 8-frame clip = 6 + 2 frames, greedy, 16 tokens per turn) against
+    tests/golden/qwen2vl2b_config0_stream.npz without HF's forward on the GPU box (HF builds the seeded weights only): raw logits at HF's
+    top-64 ids within 6e-2 x scale while the histories agree, tokens equal wherever HF's margin decides."""
+    from livecc_amd import protocol
+    from livecc_amd.config import qwen2vl_2b
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O, make_golden_2b as G
+    g = dict(np.load(G.PATH))
+    seed_w, seed_in, n_frames, H, W, max_new = (int(x) for x in g["meta"])
+    cfg = qwen2vl_2b()
+    hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=seed_w, init_scale=1.0)      # weights only
+    native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=4096, max_new_rows=2048, max_patches=8192,
+                                                          max_history=64)
+    del hf16
+    frames = torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=seed_in, layout="TCHW"))
+    g2 = dict(g)
+    g2["meta"] = np.asarray([seed_in])
+    st = _follow_golden_stream(native, cfg, g2, frames, int(g["n_turns"]), max_new, "top_vals")
+    record("qwen2vl2b_config0_vs_committed_golden", {k: v for k, v in st.items() if k != "ratios"})
+    assert st["steps"] >= 8, st
+    assert st["worst_rel_dlogit_top"] <= 6e-2, st
+    assert st["decided_equal"] == st["decided"], st

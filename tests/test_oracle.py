@@ -212,3 +212,43 @@ def test_livecc7b_two_turn_golden_is_consistent_with_the_first_token_fixture():
         full = g[f"t{ti}_rms_err_bf16_full_vocab"].astype(np.float64)
         assert e.shape == (16,) and (np.abs(e / full - 1.0) <= 0.05).all(), (e / full)
         assert (np.diff(g[f"t{ti}_top_vals_bf16"], axis=1) <= 0).all()
+
+
+def test_the_fixture_following_helper_of_the_gpu_golden_tests_on_a_replaying_fake():
+    """tests/test_gpu_golden.py::_follow_golden_stream (used by the fixture-based 7B / 2B GPU tests) driven by a FAKE native model that
+    replays the committed reference: 32 steps followed, every token equal, rms ratio exactly 1, zero logit difference -- and a fake that
+    flips one undecided token stops the comparison of that turn there without failing the margin rule."""
+    import types
+    from livecc_amd.config import get_config
+    from oracle import make_golden_7b as G
+    from tests import test_gpu_golden as T
+    g = dict(np.load(G.PATH_TURNS))
+    seed_in, n_frames, H, W, max_new, _ = (int(x) for x in g["meta"])
+    cfg = get_config("livecc-7b")
+    V, sid = cfg.vocab_size, g["sample_ids"]
+
+    class Fake:
+        def __init__(self, flip=None):
+            self.turn, self.flip = 0, flip
+
+        def generate(self, input_ids, frames, past_key_values, max_new_tokens, **kw):
+            ti = self.turn
+            self.turn += 1
+            lg = np.full((max_new_tokens, V), -30.0, dtype=np.float32)
+            for k in range(max_new_tokens):
+                lg[k][sid] = g[f"t{ti}_sample_vals_bf16"][k]
+                lg[k][g[f"t{ti}_top_ids"][k]] = g[f"t{ti}_top_vals_bf16"][k]
+            toks = g[f"t{ti}_tokens"].copy()
+            if self.flip is not None and self.flip[0] == ti:
+                toks[self.flip[1]] = int(g[f"t{ti}_top_ids"][self.flip[1]][1])
+            seq = torch.cat([input_ids[0], torch.from_numpy(toks)]).view(1, -1)
+            return types.SimpleNamespace(sequences=seq, logits=torch.from_numpy(lg), past_key_values=types.SimpleNamespace(release=lambda: None))
+
+    frames = torch.zeros(n_frames, 3, 4, 4, dtype=torch.uint8)
+    g2 = dict(g)
+    g2["meta"] = np.asarray([seed_in])
+    st = T._follow_golden_stream(Fake(), cfg, g2, frames, 2, max_new, "top_vals_bf16", "sample_vals_bf16", "sample_vals_fp32")
+    assert (st["steps"], st["tokens_equal"]) == (32, 32) and st["worst_rel_dlogit_top"] == 0.0
+    assert max(st["ratios"]) == 1.0 and min(st["ratios"]) == 1.0 and st["decided_equal"] == st["decided"] > 0
+    st = T._follow_golden_stream(Fake(flip=(0, 5)), cfg, g2, frames, 2, max_new, "top_vals_bf16", "sample_vals_bf16", "sample_vals_fp32")
+    assert st["steps"] == 6 and st["tokens_equal"] == 5          # steps 0..5 compared (histories equal), step 5 differs, turn 1 not entered
