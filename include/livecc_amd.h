@@ -318,6 +318,12 @@ int lcc_engine_profile_read_step_index(lcc_engine* e, int32_t* idx_out, int max_
  * (input of block l; [vit_depth] = input of the PatchMerger). */
 int lcc_debug_set_llm_taps(lcc_engine* e, void* taps, const void* overrides, int max_rows);
 int lcc_debug_set_vit_taps(lcc_engine* e, void* taps, const void* overrides, int max_rows);
+/* Teacher forcing (tests only; what the HF oracle does with a forcing LogitsProcessor): while bound, the token the sampler chose at
+ * generate-step k (k = 0 the prefill's token, k >= 1 the decode steps; k < n_steps) of the b-th stream of the call is REPLACED by
+ * dev_tokens[k * n_streams + b] (int32, device memory) as the current token and in the history -- raw logits and processed scores stay
+ * the model's own, so that a committed reference stream (tests/golden/) can be followed step by step even where the reference's own
+ * top-1 margin is inside bf16 noise.  Applies to calls with exactly n_streams streams.  NULL, 0, 0 unbinds. */
+int lcc_debug_set_forced_tokens(lcc_engine* e, const int32_t* dev_tokens, int n_steps, int n_streams);
 
 /* stream (slot) state */
 int lcc_slot_reset(lcc_engine* e, int slot, void* stream);                 /* new video stream: empty KV, empty history */

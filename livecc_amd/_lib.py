@@ -147,6 +147,7 @@ def load():
         "lcc_engine_profile_read_step_index": (i32, [vp, vp, i32, C.POINTER(i32)]),
         "lcc_debug_set_llm_taps": (i32, [vp, vp, vp, i32]),
         "lcc_debug_set_vit_taps": (i32, [vp, vp, vp, i32]),
+        "lcc_debug_set_forced_tokens": (i32, [vp, vp, i32, i32]),      # engine, int32 device tokens [steps][streams], steps, streams
         "lcc_slot_reset": (i32, [vp, i32, vp]),
         "lcc_slot_set_length": (i32, [vp, i32, i32, i32, vp]),
         "lcc_slot_get_length": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),

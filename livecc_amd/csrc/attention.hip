@@ -911,8 +911,8 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
   if (n_tiles <= 0) return 0;
   if (g_attn_variant >= 2 && n_groups > 0) {
     constexpr size_t lds = (size_t)4 * (6 + 5) * 1024;
-    static bool once = false;
-    if (!once) { set_lds_attr(attn_shared_kernel<80, 2, 0, 4>, lds); set_lds_attr(attn_shared_kernel<80, 1, 0, 8>, lds); once = true; }
+    static DeviceOnce once;
+    if (once.first()) { set_lds_attr(attn_shared_kernel<80, 2, 0, 4>, lds); set_lds_attr(attn_shared_kernel<80, 1, 0, 8>, lds); }
     // a group = 128 query rows of one head: 4 waves x 32 rows, or 8 waves x 16 rows.  The per-wave chain QK^T -> softmax -> PV is
     // latency-bound; with few blocks on the chip (one stream's 2-frame chunk: 12 groups x 16 heads = 192 blocks, one wave per SIMD)
     // two shorter chains per SIMD overlap where one long one cannot: 254.4 -> 258.3 tok/s single stream without the ViT prefetch
@@ -962,8 +962,8 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
     const dim3 grid(n_tiles, lay.n_kv_heads, S);
 #define LCC_ATTN_SH(GW)                                                                                                          \
   case GW: {                                                                                                                     \
-    static bool once = false;                                                                                                    \
-    if (!once) { set_lds_attr(attn_shared_kernel<128, 1, 1, GW>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1, GW>, lds); once = true; } \
+    static DeviceOnce once;                                                                                                    \
+    if (once.first()) { set_lds_attr(attn_shared_kernel<128, 1, 1, GW>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1, GW>, lds); } \
     if (tile_rows == 32)                                                                                                         \
       attn_shared_kernel<128, 2, 1, GW><<<grid, dim3(GW * 64), lds, st>>>(q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, \
                                                                           nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml); \
@@ -1026,8 +1026,8 @@ int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias
       attn_decode_fused_kernel<NS, 0><<<grid, blk, lds, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,     \
                                                               n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128));    \
     else if (nw == 8) {                                                                                                          \
-      static bool attr = false;                                                                                                  \
-      if (!attr) { set_lds_attr(attn_decode_fused_kernel<NS, 1, 8>, lds); attr = true; }                                         \
+      static DeviceOnce attr;                                                                                                  \
+      if (attr.first()) { set_lds_attr(attn_decode_fused_kernel<NS, 1, 8>, lds); }                                         \
       attn_decode_fused_kernel<NS, 1, 8><<<grid, blk, lds, st>>>(qkv_part, bias, cs, sn, slots, kv_len, kv_base, lay, layer, B,  \
                                                                  n_q_heads, nsplit, ws_o, ws_ml, counters, out, scale_l2e(128)); \
     } else                                                                                                                       \

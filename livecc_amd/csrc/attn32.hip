@@ -357,11 +357,10 @@ int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const in
   if (n_groups <= 0) return 0;
   if (group_rows != 256 && group_rows != 128) return LCC_ERR_ARG;
   constexpr size_t lds = (size_t)10 * 11 * 1024;
-  static bool once = false;
-  if (!once) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
   }
   // group_rows 256: 8 waves x 32 rows per block; 128: 4 waves (one per SIMD) -- twice the blocks for a grid that does not fill the chip
   if (group_rows == 256)
@@ -381,11 +380,10 @@ int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stre
   const int G = n_q_heads / lay.n_kv_heads;
   if (G < 1 || G > 8 || lay.head_dim != 128) return LCC_ERR_SHAPE;
   constexpr size_t lds = (size_t)10 * 16 * 1024;
-  static bool once = false;
-  if (!once) {
+  static DeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
   }
   const dim3 grid(n_tiles, lay.n_kv_heads, nsplit > 1 ? nsplit : 1);
   if (G <= 4)

@@ -112,6 +112,7 @@ struct lcc_engine {
   lcc_model_config c;
   lcc_engine_limits lim;
   int qd, kvd, qkvd, words, E, vit_hd;
+  int cu_count = 256;          // compute units of the device current at lcc_engine_create
   KvLayout lay;
 
   // weights
@@ -157,6 +158,7 @@ struct lcc_engine {
   // parity instrumentation (lcc_debug_set_llm_taps / lcc_debug_set_vit_taps): residual-stream taps and per-layer input overrides
   bf16_t* llm_taps = nullptr; const bf16_t* llm_over = nullptr; int llm_tap_rows = 0;
   bf16_t* vit_taps = nullptr; const bf16_t* vit_over = nullptr; int vit_tap_rows = 0;
+  const int32_t* forced = nullptr; int forced_steps = 0, forced_B = 0;   // teacher forcing (lcc_debug_set_forced_tokens)
   // host mirrors
   std::vector<int> h_kv_len, h_pos;
   std::vector<void*> h_kv_base;
@@ -213,6 +215,8 @@ extern "C" lcc_engine* lcc_engine_create(const lcc_model_config* cfg, const lcc_
   e->lay = KvLayout{cfg->n_layers, cfg->n_kv_heads, lim->max_kv_len, 128};
   e->vit.resize(cfg->vit_depth); e->llm.resize(cfg->n_layers);
   e->chain_epoch.assign(128, 0u);
+  { int dev = 0; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&e->cu_count, hipDeviceAttributeMultiprocessorCount, dev); }
+  if (e->cu_count <= 0) e->cu_count = 256;
   e->h_kv_len.assign(lim->max_slots, 0); e->h_pos.assign(lim->max_slots, 0); e->h_kv_base.assign(lim->max_slots, nullptr);
   return e;
 }
@@ -301,6 +305,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
   e->d_history = cv.take<int32_t>(B * (size_t)e->lim.max_history);
   e->d_seen = cv.take<uint32_t>(B * (size_t)e->words);
   HIP_TRY(hipMemset(e->state, 0, state_bytes));
+  std::fill(e->chain_epoch.begin(), e->chain_epoch.end(), 0u);   // the device hand-off counters were just zeroed: host mirror follows
   for (int i = 0; i < META_RING; ++i) if (!e->meta_ev[i]) HIP_TRY(hipEventCreateWithFlags(&e->meta_ev[i], hipEventDisableTiming));
   return 0;
 }
@@ -857,12 +862,16 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
     LCC_TRY(sample_topk_topp(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr, sp->eos_token,
                              eos2, sp->suppress_eos, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col,
                              sp->scores_out, sp->temperature, sp->top_k, sp->top_p, sp->seed, e->d_rng_ctr, st));
+    if (e->forced != nullptr && B == e->forced_B && step_index < e->forced_steps)
+      LCC_TRY(force_tokens(d_slots, e->forced + (size_t)step_index * B, B, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col, st));
     return 0;
   }
   // top_k == 1 (the released generation_config): the top-k warper leaves one finite score -> the draw IS the argmax
   LCC_TRY(sample_greedy(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr,
                         sp ? sp->eos_token : -1, eos2, sp ? sp->suppress_eos : 0, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
                         e->d_hist_col, sp ? sp->scores_out : nullptr, b.ws_ml, st));
+  if (e->forced != nullptr && B == e->forced_B && step_index < e->forced_steps)
+    LCC_TRY(force_tokens(d_slots, e->forced + (size_t)step_index * B, B, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col, st));
   return 0;
 }
 }  // namespace
@@ -944,7 +953,7 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
       // a split costs its fp32 partials twice (write + combine launch: 3,088 rows x 28 heads x 3 splits = 137 MB, 415 vs 373 us at 8
       // streams), so keys are split only while the unsplit grid cannot fill ONE round of the chip (one stream's chunk: 52 blocks ->
       // 4 splits, 68 vs 177 us); then the split count that fills whole rounds best, slightly preferring fewer splits.
-      int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+      const int cus = e->cu_count;     // of the engine's device, queried once at create time
       const long base = (long)n_tiles * e->c.n_kv_heads;
       const int ks_max = (S <= 1024 && base < cus) ? std::max(1, std::min(8, (max_kv / 32) / 8)) : 1;   // >= 8 key tiles per split
       float best = -1.f; int best_ks = 1;
@@ -954,7 +963,8 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
         if (u > best) { best = u; best_ks = k; }
       }
       static const int forced = [] { const char* v = getenv("LCC_ATTN32_SPLIT"); return v ? atoi(v) : 0; }();
-      cx.kv_split = forced > 0 ? std::min(forced, std::max(1, std::min(8, (max_kv / 32) / 8))) : best_ks;
+      // a forced split obeys the same bound as the automatic one: the partial buffers hold min(S, 1024) x heads x 8 slots (carve_llm)
+      cx.kv_split = (forced > 0 && S <= 1024) ? std::min(forced, std::max(1, std::min(8, (max_kv / 32) / 8))) : (forced > 0 ? 1 : best_ks);
     }
   }
   cx.slots = d_slots; cx.B = n_streams; cx.nsplit_attn = 1;
@@ -1075,6 +1085,11 @@ extern "C" int lcc_debug_set_vit_taps(lcc_engine* e, void* taps, const void* ove
   if (!e || max_rows < 0 || ((taps || overrides) && max_rows == 0)) return fail(LCC_ERR_ARG, "bad argument");
   if (((uintptr_t)taps | (uintptr_t)overrides) & 15) return fail(LCC_ERR_ALIGN, "tap buffers must be 16-byte aligned");
   e->vit_taps = (bf16_t*)taps; e->vit_over = (const bf16_t*)overrides; e->vit_tap_rows = max_rows;
+  return 0;
+}
+extern "C" int lcc_debug_set_forced_tokens(lcc_engine* e, const int32_t* dev_tokens, int n_steps, int n_streams) {
+  if (!e || n_steps < 0 || n_streams < 0 || (dev_tokens && (n_steps == 0 || n_streams == 0))) return fail(LCC_ERR_ARG, "bad argument");
+  e->forced = dev_tokens; e->forced_steps = dev_tokens ? n_steps : 0; e->forced_B = dev_tokens ? n_streams : 0;
   return 0;
 }
 namespace lcc { long long g_launch_counts[LC_COUNT] = {}; }

@@ -817,10 +817,9 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
   const int nkt = (a.K + 63) / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
   if (g_gemm_variant == 1 || ((g_gemm_variant == 2 || g_gemm_variant == 7) && BM == 64)) {   // 7: auto without the 8-wave kernel
     constexpr size_t lds = (size_t)3 * ((BM / 16) * 2 + 16) * 1024;   // 96 KB (BM 128) / 72 KB (BM 64)
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
+    static DeviceOnce attr_set;   // per instantiation
+    if (attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
     }
     gemm_glds_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), lds, st>>>(
         a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
@@ -838,10 +837,9 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
   // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages
   constexpr size_t lds = (size_t)((BM == 256 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
+  static DeviceOnce attr_set;   // per instantiation
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale);
@@ -920,12 +918,11 @@ static void launch_tall(const GemmArgs& a, hipStream_t st) {
     return;
   }
   constexpr size_t lds = (size_t)2 * (448 * 8 + 20 * 64) * 16;   // 155,648 B
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
+  static DeviceOnce attr_set;   // per instantiation
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   static const int sched = [] { const char* v = getenv("LCC_TALL_SCHED"); return v ? atoi(v) : 0; }();   // 0 compiler order, 1 pinned, 2 pinned + spread DMA
   if (sched == 2)

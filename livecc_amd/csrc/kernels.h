@@ -142,7 +142,23 @@ int sample_topk_topp(const bf16_t* logits, int ld, int B, int V, uint32_t* seen,
                      float repetition_penalty, int thr_token, int use_thr, float thr_value, int eos_token, int eos_token2,
                      int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld, int32_t* hist_col,
                      float* scores_out, float temperature, int top_k, float top_p, uint64_t seed, uint32_t* rng_ctr, hipStream_t st);
+// "first use on this device" latch for per-kernel attributes (160-KB dynamic LDS): hipFuncSetAttribute applies to the CURRENT device, so a
+// process that drives a second GPU must set it there too (the shipped deployment is one process per GPU).  Host only.
+struct DeviceOnce {
+  unsigned long long seen = 0;
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (seen & bit) return false;
+    seen |= bit;
+    return true;
+  }
+};
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st);
+// teacher forcing (tests): the token just sampled for stream b becomes forced[b] (current token + last history column)
+int force_tokens(const int32_t* slots, const int32_t* forced, int B, int32_t* cur_tok, int32_t* history, int hist_ld, const int32_t* hist_col,
+                 hipStream_t st);
 
 // ---- decode layer pipeline v2 (decode_v2.hip): elementwise stages fused into the weight-streaming GEMVs ----
 struct DgArgs {

@@ -536,6 +536,20 @@ __global__ void advance_kernel(const int32_t* slots, int32_t* kv_len, int32_t* p
   const int s = slots[i];
   if (done == nullptr || !done[s]) { kv_len[s] += 1; pos[s] += 1; }
 }
+__global__ void force_tokens_kernel(const int32_t* __restrict__ slots, const int32_t* __restrict__ forced, int B, int32_t* __restrict__ cur_tok,
+                                    int32_t* __restrict__ history, int hist_ld, const int32_t* __restrict__ hist_col) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int slot = slots[b], tok = forced[b];
+  cur_tok[slot] = tok;
+  const int col = hist_col[slot] - 1;          // the sampler has just written column hist_col - 1
+  if (col >= 0 && col < hist_ld) history[(size_t)slot * hist_ld + col] = tok;
+}
+int force_tokens(const int32_t* slots, const int32_t* forced, int B, int32_t* cur_tok, int32_t* history, int hist_ld, const int32_t* hist_col,
+                 hipStream_t st) {
+  force_tokens_kernel<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(slots, forced, B, cur_tok, history, hist_ld, hist_col);
+  return 0;
+}
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st) {
   if (B <= 0) return 0;
   advance_kernel<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(slots, kv_len, pos, B, done);

@@ -67,8 +67,20 @@ def pin_to_gpu_numa_node(local_rank: int) -> dict:
         allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
         if not allowed:
             return dict(pinned=False, reason="no overlap with the allowed CPU set")
-        os.sched_setaffinity(0, allowed)
-        return dict(pinned=True, cpus=len(allowed), first_cpu=allowed[0])
+        # every thread that already exists (HIP runtime, torch intra-op pool), not only the caller: sched_setaffinity(0) pins one thread
+        tids = [0]
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")] or [0]
+        except OSError:
+            pass
+        n = 0
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, allowed)
+                n += 1
+            except OSError:
+                pass                      # a thread that just exited
+        return dict(pinned=n > 0, cpus=len(allowed), first_cpu=allowed[0], threads=n)
     except Exception as e:                   # never fatal
         return dict(pinned=False, reason=repr(e))
 

@@ -275,6 +275,18 @@ class Engine:
                                                    max_rows), "lcc_debug_set_vit_taps")
         return taps
 
+    def set_forced_tokens(self, tokens: Optional[np.ndarray]) -> None:
+        """Teacher forcing (tests): tokens int [n_steps, n_streams] replace what the sampler chooses at generate-step k of the following
+        calls with n_streams streams (lcc_debug_set_forced_tokens); None unbinds."""
+        if tokens is None:
+            _lib.check(self.lib.lcc_debug_set_forced_tokens(self.h, None, 0, 0), "lcc_debug_set_forced_tokens")
+            self._forced = None
+            return
+        t = torch.as_tensor(np.ascontiguousarray(tokens, dtype=np.int32)).to(self.device)
+        assert t.dim() == 2
+        self._forced = t                      # keeps the device buffer alive while bound
+        _lib.check(self.lib.lcc_debug_set_forced_tokens(self.h, t.data_ptr(), int(t.shape[0]), int(t.shape[1])), "lcc_debug_set_forced_tokens")
+
     def profile(self, enable: bool, max_samples: int = 4096) -> None:
         _lib.check(self.lib.lcc_engine_profile(self.h, 1 if enable else 0, max_samples), "lcc_engine_profile")
 

@@ -131,7 +131,7 @@ class LiveCCForConditionalGeneration:
         self._side: Optional[torch.cuda.Stream] = None
         self._vit_cache: dict = {}
         self._vit_last_event: Optional[torch.cuda.Event] = None
-        self._sample_calls = 0                      # generate calls that drew their Philox seed from torch.initial_seed()
+        self._sample_calls = 0                      # generate calls that drew their Philox seed from torch's default generator
 
     # ---- constructors ----
     @classmethod
@@ -225,7 +225,9 @@ class LiveCCForConditionalGeneration:
                  do_sample: Optional[bool] = None, repetition_penalty: float = 1.0, logits_processor=None,
                  max_new_tokens: int = 16, min_new_tokens: Optional[int] = None, pad_token_id: Optional[int] = None,
                  eos_token_id: Optional[int] = None, frames: Optional[torch.Tensor] = None, frames_layout: str = "TCHW",
-                 output_logits: bool = False, output_scores: bool = False, attention_mask=None, **unused):
+                 output_logits: bool = False, output_scores: bool = False, attention_mask=None, teacher_tokens=None, **unused):
+        """`teacher_tokens` (tests): the generated tokens are forced to this sequence (what the HF oracle does with a forcing
+        LogitsProcessor) while `output_logits` keeps the model's own raw logits of every step."""
         sampling_kw = self._resolve_sampling(do_sample, unused)
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).all()):
             raise NotImplementedError("padding masks are not supported (the reference passes none, infer.py:156)")
@@ -238,14 +240,15 @@ class LiveCCForConditionalGeneration:
             video_grid_thw=video_grid_thw, frames=frames, frames_layout=frames_layout, state=past_key_values)],
             repetition_penalty=repetition_penalty, logits_processor=logits_processor, max_new_tokens=max_new_tokens,
             force_length=bool(min_new_tokens), eos_token_id=eos_token_id, output_logits=output_logits,
-            output_scores=output_scores, **sampling_kw)[0]
+            output_scores=output_scores, teacher_tokens=None if teacher_tokens is None else [list(teacher_tokens)], **sampling_kw)[0]
         return r if return_dict_in_generate else r.sequences
 
     @torch.inference_mode()
     def generate_batch(self, requests: Sequence[dict], repetition_penalty: float = 1.0, logits_processor=None,
                        max_new_tokens: int = 16, force_length: bool = False, eos_token_id=None,
                        output_logits: bool = False, output_scores: bool = False, do_sample: bool = False, temperature: float = 1.0,
-                       top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None, prefetch: Optional[Sequence[dict]] = None) -> List[GenerateOutput]:
+                       top_k: int = 0, top_p: float = 1.0, seed: Optional[int] = None, prefetch: Optional[Sequence[dict]] = None,
+                       teacher_tokens: Optional[Sequence[Sequence[int]]] = None) -> List[GenerateOutput]:
         """Many streams, one call: the ViTs of all clips run as one batch, all prefills as one packed batch, and the
         decode steps advance every stream together (weights are streamed from HBM once per step for the whole batch).
         Each request: input_ids (1-D, full history like the reference's cat(past_ids, new_ids)), optional
@@ -267,11 +270,15 @@ class LiveCCForConditionalGeneration:
                              f"with max_history >= the largest max_new_tokens you generate (video_qa uses 512)")
         thr = self._threshold_params(logits_processor)
         if seed is None:
-            # HF draws from torch's global generator, so two generate calls never repeat their draws; the kernel's Philox stream is
-            # keyed by (seed, slot, per-slot draw counter) and the counter restarts with every fresh stream -- without a per-call
-            # seed every new stream on a slot would replay the same "samples".  Explicit `seed=` keeps a call reproducible.
-            seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * self._sample_calls) & 0xFFFFFFFFFFFFFFFF
-            self._sample_calls += 1
+            # HF draws from torch's global generator: `torch.manual_seed(s)` before a call reproduces its draws, two calls never repeat
+            # them, and ranks seeded differently diverge.  The kernel's Philox stream is keyed by (seed, slot, per-slot draw counter); the
+            # per-call seed is therefore DRAWN from torch's default generator -- only when the call really samples, so that
+            # greedy calls leave the generator untouched like HF's.  Explicit `seed=` keeps a call reproducible by itself.
+            if do_sample and top_k != 1:
+                seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+                self._sample_calls += 1
+            else:
+                seed = 0
         n = len(requests)
         states, ids_new, pos3, clips, slots = [], [], [], [], []
         full_ids = []
@@ -319,6 +326,21 @@ class LiveCCForConditionalGeneration:
         sp = Sampling(repetition_penalty=repetition_penalty, eos_token=eos, suppress_eos=force_length,
                       thr_token=thr[0] if thr else -1, thr_base=thr[1] if thr else None, thr_step=thr[2] if thr else 0.0,
                       eos_token2=eos2, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
+        if teacher_tokens is not None:          # tests: [n streams][max_new_tokens] -> device table [step][stream]
+            tt = np.asarray(teacher_tokens, dtype=np.int32)
+            if tt.shape != (n, max_new_tokens) or (n > 1 and sum(len(x) for x in ids_new) > eng.max_new_rows) or n > self.DECODE_GROUP:
+                raise ValueError("teacher_tokens must be [n_streams][max_new_tokens]; several streams must fit one prefill / one decode group")
+            eng.set_forced_tokens(np.ascontiguousarray(tt.T))
+        try:
+            return self._generate_tail(n, states, slots, ids_new, pos3, vit, sp, scores_buf, logits_buf, prefetch, max_new_tokens, force_length,
+                                       thr, logits_processor, full_ids)
+        finally:
+            if teacher_tokens is not None:
+                eng.set_forced_tokens(None)
+
+    def _generate_tail(self, n, states, slots, ids_new, pos3, vit, sp, scores_buf, logits_buf, prefetch, max_new_tokens, force_length, thr,
+                       logits_processor, full_ids) -> List[GenerateOutput]:
+        eng = self.engine
         self._prefill(slots, ids_new, pos3, vit, sp, scores_buf, logits_buf)
         if prefetch:
             self._prefetch_vit(prefetch)

@@ -13,50 +13,79 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# The GPU tier runs SERIALLY under a 20-minute limit on the driver's box.  The tests that pay for a 7B HF forward on the host take minutes
-# each, so (1) they run FIRST, the most informative first, and (2) each of them asks `slow_budget(seconds it needs)` before starting: a
-# slow test that could not finish before LCC_SLOW_DEADLINE_S (default 780 s into the session; measured serially on one MI355X box: the
-# five slow tests ~500 s, the 1,037 quick tests behind them 197 s) skips with that reason instead of running the tier into its limit (bench.py's default line carries the same 7B
-# parity numbers: bf16 + fp32 oracle + decisive-weight tokens).  LCC_SLOW_DEADLINE_S=0 disables the guard.
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The GPU tier runs SERIALLY under a 20-minute limit on the driver's box.  Policy since round 4:
+#   * every parity comparison against the executed HF reference at the REAL shapes runs from a committed fixture (tests/golden/*.npz +
+#     the generator under oracle/): seconds per test, no HF forward on the box, never skipped;
+#   * the live twins of those fixtures -- the same comparison with HF's forward run on the box's host cores, minutes each -- are OPT-IN
+#     (LCC_LIVE_ORACLE=1 collects them); without the variable they are DESELECTED, not skipped, so the tier's skip count only holds tests
+#     that did not run for a reason worth reading.  bench.py's default line runs HF bf16 + fp32 at LiveCC-7B shapes live on every box;
+#   * the one live slow test that has no fixture twin (per-layer teacher forcing at LiveCC-7B shapes) runs FIRST;
+#   * a test that asks `slow_budget(seconds)` past the deadline, or any GPU test past LCC_TIER_LIMIT_S, still skips instead of running
+#     the tier into the driver's kill -- but the skip is RECORDED and the tier's last test fails unless LCC_ALLOW_BUDGET_SKIPS=1: a green
+#     tier means every parity test ran.
+# ---------------------------------------------------------------------------------------------------------------------------------
 _SESSION_T0 = time.time()
 _SLOW_ORDER = ("test_every_layer_at_livecc_7b_shapes_matches_hf_on_the_oracles_input",
+               "test_qwen2vl_72b_shaped_layer_with_fp8_weights_matches_hf_on_the_dequantised_weights",
                "test_greedy_tokens_are_exact_on_decisive_weights",
                "test_livecc_7b_turns_match_hf_cpu_path_on_identical_weights",
                "test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference")
+# live test -> the fixture-based test that always runs in its place
+LIVE_TWINS = {
+    "test_livecc_7b_turns_match_hf_cpu_path_on_identical_weights": "test_livecc7b_two_turns_against_the_committed_hf_logits",
+    "test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference": "test_qwen2vl2b_config0_against_the_committed_hf_stream",
+    "test_greedy_tokens_are_exact_on_decisive_weights": "test_livecc7b_greedy_tokens_equal_the_committed_hf_tokens_on_decisive_weights",
+}
+SENTINEL = "test_zz_no_parity_test_was_skipped_by_the_time_budget"
+BUDGET_SKIPPED = []          # node ids skipped by a time budget in this session (read by the sentinel)
 
 
 def _slow_rank(item):
+    if SENTINEL in item.nodeid:
+        return len(_SLOW_ORDER) + 1
     for i, name in enumerate(_SLOW_ORDER):
         if name in item.nodeid:
             return i
     return len(_SLOW_ORDER)
 
 
+def _is_live_twin(nodeid):
+    return any(name in nodeid for name in LIVE_TWINS)
+
+
 @pytest.fixture
-def slow_budget():
-    """Call with the seconds the test needs; skips when the session would run past the deadline."""
+def slow_budget(request):
+    """Call with the seconds the test needs; skips (and records the skip) when the session would run past the deadline."""
     def check(needs_s: float):
         deadline = float(os.environ.get("LCC_SLOW_DEADLINE_S", "780"))
         elapsed = time.time() - _SESSION_T0
         if deadline > 0 and elapsed + needs_s > deadline:
+            BUDGET_SKIPPED.append(getattr(getattr(request, "node", None), "nodeid", "?"))
             pytest.skip(f"slow-test time budget: {elapsed:.0f} s into the session + {needs_s:.0f} s needed > {deadline:.0f} s "
-                        "(the GPU tier has a 20-minute limit; bench.py's default line carries the 7B parity)")
+                        "(the GPU tier has a 20-minute limit); the tier's last test reports this as a failure")
         return elapsed
     return check
 
 
 def pytest_runtest_setup(item):
     """Safety net of the same limit: past LCC_TIER_LIMIT_S (default 1,080 s) the remaining GPU tests skip instead of being killed."""
-    if "gpu" not in item.keywords:
+    if "gpu" not in item.keywords or SENTINEL in item.nodeid:
         return
     limit = float(os.environ.get("LCC_TIER_LIMIT_S", "1080"))
     if limit > 0 and time.time() - _SESSION_T0 > limit:
+        BUDGET_SKIPPED.append(item.nodeid)
         pytest.skip(f"GPU tier time limit: {time.time() - _SESSION_T0:.0f} s into the session (> {limit:.0f} s)")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
-    items.sort(key=_slow_rank)            # stable: everything else keeps its order behind the slow tests
+    if os.environ.get("LCC_LIVE_ORACLE") != "1":
+        live = [it for it in items if _is_live_twin(it.nodeid)]
+        if live:
+            items[:] = [it for it in items if not _is_live_twin(it.nodeid)]
+            config.hook.pytest_deselected(items=live)
+    items.sort(key=_slow_rank)            # stable: everything else keeps its order between the slow tests and the sentinel
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

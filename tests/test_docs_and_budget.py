@@ -44,26 +44,43 @@ def test_header_symbol_count_matches_what_build_reports():
         assert not missing, f"{doc} names C-ABI symbols the header does not declare: {sorted(missing)}"
 
 
-def test_slow_tests_run_first_and_respect_the_time_budget(monkeypatch):
+def test_slow_tests_run_first_budget_skips_are_recorded_and_the_sentinel_fails_on_them(monkeypatch):
     from tests import conftest as C
+    from tests import test_gpu_zz_tier as Z
 
     class Item:
         def __init__(self, nodeid):
             self.nodeid = nodeid
             self.keywords = {}
-    items = [Item("tests/test_gpu_ops.py::test_a"), Item("tests/test_gpu_e2e.py::test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference"),
+    items = [Item("tests/test_gpu_ops.py::test_a"), Item("tests/test_gpu_zz_tier.py::" + C.SENTINEL),
+             Item("tests/test_gpu_e2e.py::test_baseline_config0_qwen2vl_2b_8frame_clip_vs_cpu_reference"),
              Item("tests/test_gpu_baseline_configs.py::test_greedy_tokens_are_exact_on_decisive_weights[livecc-7b]"), Item("tests/test_abi.py::test_b"),
              Item("tests/test_gpu_layer_parity.py::test_every_layer_at_livecc_7b_shapes_matches_hf_on_the_oracles_input")]
     order = [it.nodeid.split("::")[1][:20] for it in sorted(items, key=C._slow_rank)]
-    assert order == ["test_every_layer_at_", "test_greedy_tokens_a", "test_baseline_config", "test_a", "test_b"]
-    # budget: a test that needs 300 s does not start 600 s into a session whose slow block must end by 780 s
-    check = C.slow_budget.__wrapped__() if hasattr(C.slow_budget, "__wrapped__") else None
+    assert order == ["test_every_layer_at_", "test_greedy_tokens_a", "test_baseline_config", "test_a", "test_b", C.SENTINEL[:20]]
+    # the live twins of the committed fixtures are opt-in; each names a fixture test that exists
+    src = _read("tests", "test_gpu_golden.py")
+    for live, twin in C.LIVE_TWINS.items():
+        assert C._is_live_twin("x::" + live) and f"def {twin}(" in src, (live, twin)
+    assert not C._is_live_twin("tests/test_gpu_layer_parity.py::test_every_layer_at_livecc_7b_shapes_matches_hf_on_the_oracles_input")
+    # budget: a test that needs 300 s does not start 600 s into a session whose slow block must end by 780 s -- and the skip is recorded
+    class Req:
+        node = Item("tests/x.py::test_needs_300")
+    check = C.slow_budget.__wrapped__(Req()) if hasattr(C.slow_budget, "__wrapped__") else None
     if check is None:
         pytest.skip("fixture internals not reachable in this pytest version")
     monkeypatch.setattr(C, "_SESSION_T0", time.time() - 600.0)
+    monkeypatch.setattr(C, "BUDGET_SKIPPED", [])
     monkeypatch.delenv("LCC_SLOW_DEADLINE_S", raising=False)
+    monkeypatch.delenv("LCC_ALLOW_BUDGET_SKIPS", raising=False)
+    Z.test_zz_no_parity_test_was_skipped_by_the_time_budget()           # nothing skipped yet: green
     with pytest.raises(pytest.skip.Exception):
         check(300)
+    assert C.BUDGET_SKIPPED == ["tests/x.py::test_needs_300"]
+    with pytest.raises(AssertionError):
+        Z.test_zz_no_parity_test_was_skipped_by_the_time_budget()       # a budget skip fails the tier
+    monkeypatch.setenv("LCC_ALLOW_BUDGET_SKIPS", "1")
+    Z.test_zz_no_parity_test_was_skipped_by_the_time_budget()
     assert check(100) >= 600.0
     monkeypatch.setenv("LCC_SLOW_DEADLINE_S", "0")
     assert check(10_000) >= 600.0

@@ -19,12 +19,15 @@ def _rmsnorm_ref(h, w, eps):
     return rb(w.float() * rb(x * r))
 
 
-@pytest.mark.parametrize("M", [1, 2, 4])
-@pytest.mark.parametrize("N,K", [(37888, 3584), (17920, 1536), (1024, 256), (4864, 896)])
+def _staged(Ms, NKs):
+    """(M, N, K) triples the decode pipeline v2 serves: its GEMVs stage M normalised rows of K bf16 in LDS (M * K <= 16384).  A filtered
+    parameter list instead of skip-by-construction."""
+    return [(m, n, k) for (n, k) in NKs for m in Ms if m * k <= 16384]
+
+
+@pytest.mark.parametrize("M,N,K", _staged([1, 2, 4], [(37888, 3584), (17920, 1536), (1024, 256), (4864, 896)]))
 def test_norm_swiglu_gemv(dev, M, N, K):
     from livecc_amd import ops
-    if M * K > 16384:
-        pytest.skip("M * K beyond the LDS-staged rows")
     h, w, nw = _rand((M, K), dev, 2.0, 1), _rand((N, K), dev, 0.03, 2), (1.0 + 0.1 * _rand((K,), dev, 1.0, 3).float()).to(torch.bfloat16)
     got = ops.dgemv_norm_linear(ops.pack_weight(w), h, ops.tile_stats(h), nw, 1e-6, (N, K), swiglu=True)
     ref, atol = _ref_linear(_rmsnorm_ref(h, nw, 1e-6).to(torch.bfloat16), w, None, 4, with_atol=True)
@@ -209,12 +212,9 @@ def _w8(dev, N, K, seed):
     return w8, sc.contiguous(), wd
 
 
-@pytest.mark.parametrize("M", [1, 2, 4])
-@pytest.mark.parametrize("N,K", [(37888, 3584), (59136, 8192), (1024, 256)])
+@pytest.mark.parametrize("M,N,K", _staged([1, 2, 4], [(37888, 3584), (59136, 8192), (1024, 256)]))
 def test_fp8_norm_swiglu_gemv(dev, M, N, K):
     from livecc_amd import ops
-    if M * K > 16384:
-        pytest.skip("M * K beyond the LDS-staged rows")
     h, nw = _rand((M, K), dev, 2.0, 1), (1.0 + 0.1 * _rand((K,), dev, 1.0, 3).float()).to(torch.bfloat16)
     w8, sc, wd = _w8(dev, N, K, 2)
     got = ops.dgemv_norm_linear(w8, h, ops.tile_stats(h), nw, 1e-6, (N, K), swiglu=True, wscale=sc)
@@ -234,11 +234,9 @@ def test_fp8_norm_linear_gemv_lm_head(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M", [1, 2])
-@pytest.mark.parametrize("N,K", [(3584, 18944), (3584, 3584), (8192, 29568), (256, 512)])
+@pytest.mark.parametrize("N,K", [(3584, 18944), (3584, 3584), (8192, 29568), (256, 512)])      # fp8 fragments are 64 k wide: K % 64 == 0
 def test_fp8_residual_gemv_and_tile_statistics(dev, M, N, K, resid_waves):
     from livecc_amd import ops
-    if K % 64:
-        pytest.skip("fp8 fragments are 64 k wide")
     x, h0 = _rand((M, K), dev, 1.0, 7), _rand((M, N), dev, 2.0, 9)
     w8, sc, wd = _w8(dev, N, K, 8)
     h = h0.clone()
@@ -248,8 +246,8 @@ def test_fp8_residual_gemv_and_tile_statistics(dev, M, N, K, resid_waves):
     assert torch.allclose(stats, ops.tile_stats(h), rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("Hq,Hkv,K", [(28, 4, 3584), (64, 8, 8192), (2, 1, 256)])
-@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("Hq,Hkv,K,M", [(hq, hkv, k, m) for (hq, hkv, k) in [(28, 4, 3584), (64, 8, 8192), (2, 1, 256)] for m in (1, 2)
+                                         if m * k <= 16384])
 def test_fp8_qkv_gemv_with_rope_and_kv_append(dev, Hq, Hkv, K, M):
     """fp8 decode copy (rows AND scales permuted) in one launch against the round-1 fp8 chain on the un-permuted weight: RMSNorm ->
     fp8 split-K GEMV slabs (lcc_gemm_w8_bf16) -> rope_kv_append.  Same e4m3 values and scales on both sides; they differ only by the
@@ -257,8 +255,6 @@ def test_fp8_qkv_gemv_with_rope_and_kv_append(dev, Hq, Hkv, K, M):
     from livecc_amd import ops
     from livecc_amd.config import LiveCCConfig
     from livecc_amd.weights import pack_weight_fp8, quantize_fp8_rows, qkv_decode_row_permutation
-    if M * K > 16384:
-        pytest.skip("M * K beyond the LDS-staged rows")
     D = 128
     N = (Hq + 2 * Hkv) * D
     cfg = LiveCCConfig(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=K)

@@ -165,63 +165,78 @@ def test_livecc7b_greedy_tokens_equal_the_committed_hf_tokens_on_decisive_weight
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Two more fixture-based comparisons, WRITTEN at the end of round 3 when no GPU minutes were left to run them once: they are skipped
-# unless LCC_UNVALIDATED_GOLDEN=1 so that an untested test cannot stop the tier; the first GPU call of the next round runs them with
-# the variable set and removes the gate.  (The two tests above were run on the MI355X before they were committed.)
+# Fixture-based comparisons at the real shapes, TEACHER-FORCED along the committed reference stream (round 4): the first GPU run of the
+# round-3 free-running versions showed what free running costs on random weights -- the native tokens left HF's at the first step whose
+# top-1 margin lies inside bf16 noise (step 3 of 32) and nothing after it was comparable.  The engine now forces the committed tokens
+# (lcc_debug_set_forced_tokens = what the HF oracle does with a forcing LogitsProcessor), so EVERY step is compared, and the token the
+# native path would have chosen is recomputed on the host from its raw logits (repetition penalty over the ids seen so far, argmax).
 # ---------------------------------------------------------------------------------------------------------------------
-_UNVALIDATED = pytest.mark.skipif(os.environ.get("LCC_UNVALIDATED_GOLDEN") != "1",
-                                  reason="written without a GPU run (round 3's GPU minutes were spent); LCC_UNVALIDATED_GOLDEN=1 runs it")
+def own_choice(raw_logits: np.ndarray, seen_ids, penalty: float) -> int:
+    """HF RepetitionPenaltyLogitsProcessor + argmax on one step's raw logits: score < 0 -> * penalty, else / penalty, for every id of
+    the history (prompt + generated so far: ref demo/infer.py:160,169)."""
+    sc = raw_logits.astype(np.float32).copy()
+    idx = np.unique(np.asarray(list(seen_ids), dtype=np.int64))
+    v = sc[idx]
+    sc[idx] = np.where(v < 0, v * np.float32(penalty), v / np.float32(penalty))
+    return int(sc.argmax())
 
 
-def _follow_golden_stream(native, cfg, g, frames, n_turns, max_new, top_key, sample_key16=None, sample_key32=None):
-    """The native path along a committed free-running reference stream: per turn the prompt is the golden history + the turn ids; tokens
-    and raw logits are compared step by step while the histories agree, and every turn continues along the GOLDEN tokens."""
-    from livecc_amd import protocol
-    builder = protocol.TurnBuilder(cfg, seed=int(g["meta"][0]))            # callers put the prompt seed in meta[0]
-    for ti in range(n_turns):                                               # the fixture's prompts are rebuilt from the seed
-        assert np.array_equal(g[f"t{ti}_ids"], np.asarray(builder.turn_ids(ti, protocol.num_video_tokens(tuple(int(x) for x in g[f"t{ti}_grid"]), cfg))))
+def follow_golden_stream(native, turns, frames_of_turn, max_new, top_key, noise_of_step, penalty=1.05, sample=None, past_rule=True):
+    """The native path along a committed reference stream.  `turns`: per turn a dict(ids=new prompt ids, tokens=the reference's greedy
+    tokens, top_ids / top_vals (its top-K raw logits per step), scale).  Every turn is teacher-forced along the reference's tokens; per
+    step: |native - reference| at the reference's top-K ids relative to the scale, whether the native path's OWN choice (host-side
+    penalty + argmax over its raw logits) equals the reference's token, and whether the reference's raw top-1 margin exceeds twice the
+    COMMITTED reference noise `noise_of_step(turn, k)` (not the native error) -- there the tokens must agree.
+    `sample` = (ids, key16, key32): rms error ratio against the fp32 truth over fixed sample ids."""
     state, past = None, None
-    stats = dict(steps=0, tokens_equal=0, decided=0, decided_equal=0, worst_rel_dlogit_top=0.0, ratios=[])
-    sid = g.get("sample_ids")
-    for ti, (a, b) in enumerate(protocol.split_clip(frames.shape[0])[:n_turns]):
-        new = g[f"t{ti}_ids"]
+    st = dict(steps=0, tokens_equal=0, decided=0, decided_equal=0, worst_rel_dlogit_top=0.0, ratios=[], undecided_mismatch_steps=[])
+    for ti, t in enumerate(turns):
+        new = np.asarray(t["ids"], dtype=np.int64)
         ids = new if past is None else np.concatenate([past, new])
-        r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames[a:b], past_key_values=state, repetition_penalty=1.05,
-                            max_new_tokens=max_new, min_new_tokens=max_new, output_logits=True, do_sample=False)
+        gold = [int(x) for x in t["tokens"]]
+        r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames_of_turn(ti), past_key_values=state,
+                            repetition_penalty=penalty, max_new_tokens=max_new, min_new_tokens=max_new, output_logits=True, do_sample=False,
+                            teacher_tokens=gold)
         state = r.past_key_values
-        toks = r.sequences[0, len(ids):].tolist()
-        gold = g[f"t{ti}_tokens"].tolist()
+        assert r.sequences[0, len(ids):].tolist() == gold, "teacher forcing: the history holds the committed tokens"
         lg = r.logits.float().cpu().numpy()
+        seen = set(int(x) for x in ids)
         for k in range(max_new):
-            if toks[:k] != gold[:k]:
-                break
-            stats["steps"] += 1
-            stats["tokens_equal"] += int(toks[k] == gold[k])
-            scale = float(g[f"t{ti}_scale"][k])
-            top_ids, top_vals = g[f"t{ti}_top_ids"][k], g[f"t{ti}_{top_key}"][k]
+            st["steps"] += 1
+            scale = float(t["scale"][k])
+            top_ids, top_vals = np.asarray(t["top_ids"][k]), np.asarray(t[top_key][k], dtype=np.float64)
             d = float(np.abs(lg[k][top_ids] - top_vals).max())
-            stats["worst_rel_dlogit_top"] = max(stats["worst_rel_dlogit_top"], d / scale)
-            # the reference's raw top-1 margin against twice the measured difference: where it decides, the tokens must agree
-            if (top_vals[0] - top_vals[1]) > 2.0 * d and gold[k] == int(top_ids[0]):
-                stats["decided"] += 1
-                stats["decided_equal"] += int(toks[k] == gold[k])
-            if sample_key32 is not None:
-                n, b16, t32 = lg[k][sid].astype(np.float64), g[f"t{ti}_{sample_key16}"][k].astype(np.float64), g[f"t{ti}_{sample_key32}"][k].astype(np.float64)
-                stats["ratios"].append(float(np.sqrt(((n - t32) ** 2).mean()) / np.sqrt(((b16 - t32) ** 2).mean())))
-        past = np.concatenate([ids, np.asarray(gold[:-1], dtype=np.int64)])
-        if toks != gold:                       # the carried cache now holds a different history: later turns are not comparable
-            break
+            st["worst_rel_dlogit_top"] = max(st["worst_rel_dlogit_top"], d / scale)
+            own = own_choice(lg[k], seen, penalty)
+            st["tokens_equal"] += int(own == gold[k])
+            decided = (top_vals[0] - top_vals[1]) > 2.0 * noise_of_step(ti, k) and gold[k] == int(top_ids[0])
+            if decided:
+                st["decided"] += 1
+                st["decided_equal"] += int(own == gold[k])
+            elif own != gold[k]:
+                st["undecided_mismatch_steps"].append((ti, k))
+            if sample is not None:
+                sid, k16, k32 = sample
+                n, b16, t32 = lg[k][sid].astype(np.float64), t[k16][k].astype(np.float64), t[k32][k].astype(np.float64)
+                st["ratios"].append(float(np.sqrt(((n - t32) ** 2).mean()) / np.sqrt(((b16 - t32) ** 2).mean())))
+            seen.add(gold[k])
+        past = np.concatenate([ids, np.asarray(gold[:-1], dtype=np.int64)]) if past_rule else None
     if state is not None:
         state.release()
-    return stats
+    return st
 
 
-@_UNVALIDATED
+def _turns_of(g, n_turns, top_key):
+    return [dict(ids=g[f"t{ti}_ids"], tokens=g[f"t{ti}_tokens"], top_ids=g[f"t{ti}_top_ids"], scale=g[f"t{ti}_scale"],
+                 **{k[len(f"t{ti}_"):]: g[k] for k in g if k.startswith(f"t{ti}_") and ("vals" in k)}) for ti in range(n_turns)]
+
+
 def test_livecc7b_two_turns_against_the_committed_hf_logits(dev):
-    """BASELINE configs[1]'s first two turns at LiveCC-7B shapes (tiled:0 weights) against tests/golden/livecc7b_two_turns.npz: while the
-    native free-running tokens follow HF's, per step |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale, rms over the 4,096 sample
-    ids of (native - fp32) <= 1.25 x rms(HF_bf16 - fp32) (their rms tracks the full vocabulary within 5 %), tokens equal wherever HF's
-    raw top-1 margin exceeds twice the measured difference; at least the first 8 steps are compared."""
+    """BASELINE configs[1]'s first two turns at LiveCC-7B shapes (tiled:0 weights) against tests/golden/livecc7b_two_turns.npz (HF bf16
+    free-running + HF fp32 teacher-forced, oracle/make_golden_7b.py --turns), teacher-forced along HF's tokens, all 32 steps: per step
+    |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale; rms over the 4,096 sample ids of (native - fp32) <= 1.25 x rms(HF_bf16 - fp32)
+    per step and <= 1.08 over all steps (their rms tracks the full vocabulary within 5 %); the native path's own choice equals HF's token
+    wherever HF's raw top-1 margin exceeds twice HF-bf16's OWN committed error against fp32 at its top-64 ids."""
     from livecc_amd import protocol
     from livecc_amd.config import get_config
     from livecc_amd.modeling import LiveCCForConditionalGeneration
@@ -230,25 +245,36 @@ def test_livecc7b_two_turns_against_the_committed_hf_logits(dev):
     g = dict(np.load(G.PATH_TURNS))
     seed_in, n_frames, H, W, max_new, seed_w = (int(x) for x in g["meta"])
     cfg = get_config("livecc-7b")
+    n_turns = int(g["n_turns"])
+    builder = protocol.TurnBuilder(cfg, seed=seed_in)                                   # the fixture's prompts are rebuilt from the seed
+    for ti in range(n_turns):
+        assert np.array_equal(g[f"t{ti}_ids"], builder.turn_ids(ti, protocol.num_video_tokens(tuple(int(x) for x in g[f"t{ti}_grid"]), cfg)))
     arena = WeightArena(cfg, dev).fill_tiled(seed=seed_w)
     native = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=1, max_kv_len=4096, max_new_rows=1280, max_patches=4608, max_history=16)
     frames = torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=seed_in, layout="TCHW"))
-    g2 = dict(g)
-    g2["meta"] = np.asarray([seed_in])          # _follow_golden_stream reads the prompt seed from meta[0]
-    st = _follow_golden_stream(native, cfg, g2, frames, int(g["n_turns"]), max_new, "top_vals_bf16", "sample_vals_bf16", "sample_vals_fp32")
-    record("livecc7b_two_turns_vs_committed_golden", {k: v for k, v in st.items() if k != "ratios"} | dict(worst_rms_ratio=max(st["ratios"]),
-           mean_rms_ratio=float(np.mean(st["ratios"]))))
-    assert st["steps"] >= 8, st
+    chunks = protocol.split_clip(n_frames)
+    turns = _turns_of(g, n_turns, "top_vals_bf16")
+
+    def noise(ti, k):          # HF-bf16's own error against the fp32 truth at its top-64 ids of this step (committed)
+        return float(np.abs(g[f"t{ti}_top_vals_bf16"][k].astype(np.float64) - g[f"t{ti}_top_vals_fp32"][k]).max())
+    st = follow_golden_stream(native, turns, lambda ti: frames[chunks[ti][0]:chunks[ti][1]], max_new, "top_vals_bf16", noise,
+                              sample=(g["sample_ids"], "sample_vals_bf16", "sample_vals_fp32"))
+    ratios = np.asarray(st.pop("ratios"))
+    record("livecc7b_two_turns_vs_committed_golden", st | dict(worst_rms_ratio=float(ratios.max()), mean_rms_ratio=float(ratios.mean()),
+                                                                rms_ratio_all_steps=float(np.sqrt((ratios ** 2).mean()))))
+    assert st["steps"] == n_turns * max_new
     assert st["worst_rel_dlogit_top"] <= 6e-2, st
-    assert max(st["ratios"]) <= 1.25, st
+    assert ratios.max() <= 1.25 and np.sqrt((ratios ** 2).mean()) <= 1.08, (ratios.max(), ratios.mean())
     assert st["decided_equal"] == st["decided"], st
+    assert st["tokens_equal"] >= (2 * st["steps"]) // 3, st          # loose majority on random weights (measured 27-30 of 32 live)
 
 
-@_UNVALIDATED
 def test_qwen2vl2b_config0_against_the_committed_hf_stream(dev):
     """BASELINE configs[0] (Qwen2-VL-2B real shapes, 8-frame clip = 6 + 2 frames, greedy, 16 tokens per turn) against
-    tests/golden/qwen2vl2b_config0_stream.npz without HF's forward on the GPU box (HF builds the seeded weights only): raw logits at HF's
-    top-64 ids within 6e-2 x scale while the histories agree, tokens equal wherever HF's margin decides."""
+    tests/golden/qwen2vl2b_config0_stream.npz (HF bf16 free-running, oracle/make_golden_2b.py) without HF's forward on the GPU box (HF
+    builds the seeded weights only), teacher-forced along HF's tokens: raw logits at HF's top-64 ids within 6e-2 x scale on all 32 steps;
+    the native path's own choice equals HF's wherever HF's raw margin exceeds twice 3 % of the logit scale (the bf16 noise of these shapes:
+    2.9 % measured live against HF)."""
     from livecc_amd import protocol
     from livecc_amd.config import qwen2vl_2b
     from livecc_amd.modeling import LiveCCForConditionalGeneration
@@ -256,15 +282,126 @@ def test_qwen2vl2b_config0_against_the_committed_hf_stream(dev):
     g = dict(np.load(G.PATH))
     seed_w, seed_in, n_frames, H, W, max_new = (int(x) for x in g["meta"])
     cfg = qwen2vl_2b()
+    n_turns = int(g["n_turns"])
+    builder = protocol.TurnBuilder(cfg, seed=seed_in)
+    for ti in range(n_turns):
+        assert np.array_equal(g[f"t{ti}_ids"], builder.turn_ids(ti, protocol.num_video_tokens(tuple(int(x) for x in g[f"t{ti}_grid"]), cfg)))
     hf16 = O.build_hf_model(cfg, dtype=torch.bfloat16, seed=seed_w, init_scale=1.0)      # weights only
     native = LiveCCForConditionalGeneration.from_hf_model(hf16, cfg, dev, max_streams=1, max_kv_len=4096, max_new_rows=2048, max_patches=8192,
                                                           max_history=64)
     del hf16
     frames = torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=seed_in, layout="TCHW"))
-    g2 = dict(g)
-    g2["meta"] = np.asarray([seed_in])
-    st = _follow_golden_stream(native, cfg, g2, frames, int(g["n_turns"]), max_new, "top_vals")
-    record("qwen2vl2b_config0_vs_committed_golden", {k: v for k, v in st.items() if k != "ratios"})
-    assert st["steps"] >= 8, st
+    chunks = protocol.split_clip(n_frames)
+    turns = _turns_of(g, n_turns, "top_vals")
+    st = follow_golden_stream(native, turns, lambda ti: frames[chunks[ti][0]:chunks[ti][1]], max_new, "top_vals",
+                              lambda ti, k: 0.03 * float(g[f"t{ti}_scale"][k]))
+    st.pop("ratios")
+    record("qwen2vl2b_config0_vs_committed_golden", st)
+    assert st["steps"] == n_turns * max_new
     assert st["worst_rel_dlogit_top"] <= 6e-2, st
     assert st["decided_equal"] == st["decided"], st
+    assert st["tokens_equal"] >= (2 * st["steps"]) // 3, st
+
+
+def test_livecc7b_oneshot480_against_the_committed_hf_logits(dev):
+    """BASELINE configs[3] at the REAL shapes (VERDICT r3 missing #4): the reference's video_qa / MCQ first turn -- 480 frames 280x280 =
+    96,000 patches in 240 temporal slices -> 24,000 visual tokens + a 24-id query in ONE generate call (a 24,058-row prefill served in
+    4,096-row pieces over the carried KV), then 8 greedy tokens over the ~24k-key cache -- against tests/golden/livecc7b_oneshot480.npz
+    (HF bf16 free-running + HF fp32 teacher-forced on the tiled:0 weights, oracle/make_golden_7b_long.py; HF 5.15 text-offset rule on both
+    sides), teacher-forced along HF's tokens: |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale on every step (step 0 = the 24k-row
+    prefill's token, steps 1-7 = decode steps at L ~ 24k), rms(native - fp32) <= 1.25 x rms(HF_bf16 - fp32) over the 4,096 sample ids, the
+    native path's own choice equal to HF's wherever HF's margin exceeds twice its committed error."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.weights import WeightArena
+    from oracle import make_golden_7b_long as L
+    g = dict(np.load(L.PATH))
+    seed_in, T, H, W, n_new, seed_w, qlen = (int(x) for x in g["meta"])
+    assert (seed_in, T, H, W, n_new, qlen) == (L.SEED_IN, L.T, L.H, L.W, L.N_NEW, L.QUERY_LEN)
+    cfg = get_config("livecc-7b")
+    ids, grid = L.prompt_ids(cfg)
+    assert len(ids) == int(g["ids_len"]) and np.array_equal(ids[:64], g["ids_head"]) and np.array_equal(ids[-64:], g["ids_tail"])
+    arena = WeightArena(cfg, dev).fill_tiled(seed=seed_w)
+    native = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=1, max_kv_len=32 * ((len(ids) + n_new + 31) // 32) + 64, max_new_rows=4096,
+                                            max_patches=40 * 400, max_history=16, text_offset_rule="hf5")
+    frames = torch.from_numpy(protocol.synth_frames(T, H, W, seed=seed_in, layout="TCHW"))
+    has32 = "t0_sample_vals_fp32" in g
+    scale = g["t0_scale"] if has32 else g["t0_scale_bf16"]
+    turn = dict(ids=ids, tokens=g["tokens"], top_ids=g["t0_top_ids"], scale=scale, top_vals_bf16=g["t0_top_vals_bf16"],
+                sample_vals_bf16=g["t0_sample_vals_bf16"])
+    if has32:
+        turn["sample_vals_fp32"] = g["t0_sample_vals_fp32"]
+
+    def noise(ti, k):
+        if has32:
+            return float(np.abs(g["t0_top_vals_bf16"][k].astype(np.float64) - g["t0_top_vals_fp32"][k]).max())
+        return 0.04 * float(scale[k])
+    st = follow_golden_stream(native, [turn], lambda ti: frames, n_new, "top_vals_bf16", noise,
+                              sample=(g["sample_ids"], "sample_vals_bf16", "sample_vals_fp32") if has32 else None, past_rule=False)
+    ratios = np.asarray(st.pop("ratios")) if has32 else None
+    rec = dict(st, prompt_rows=len(ids), patches=int(np.prod(grid)), fp32_truth=has32)
+    if has32:
+        rec.update(worst_rms_ratio=float(ratios.max()), mean_rms_ratio=float(ratios.mean()))
+    record("livecc7b_oneshot480_vs_committed_golden", rec)
+    assert st["steps"] == n_new
+    assert st["worst_rel_dlogit_top"] <= 6e-2, st
+    if has32:
+        assert ratios.max() <= 1.25, ratios
+    assert st["decided_equal"] == st["decided"], st
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own orchestrator, executed (oracle/ref_infer_harness.py): its committed call trace through the native engine
+# ---------------------------------------------------------------------------------------------------------------------
+def test_reference_orchestrator_trace_through_the_native_engine(dev):
+    """tests/golden/ref_infer_trace.json holds what `ref demo/infer.py` ITSELF (loaded from /root/reference in the build container, HF's
+    Qwen2VLForConditionalGeneration behind it at tiny shapes, its own ThresholdLogitsProcessor inside HF's generate) did for
+    `live_cc_once_for_evaluation` (ref :244-310) and for the demo/cli.py loop over `live_cc` (ref :61-180) on a seeded synthetic video:
+    every generate call's ids and generated tokens, and the responses.  Here `livecc_amd.infer.LiveCCDemoInfer` drives the NATIVE engine
+    (same seeded weights, same tokenizer, same video, GPU resize + patchify + fused sampler) through the same two flows: every call must
+    carry identical ids, generate identical tokens (HF's top-1 margin is >= 8 % of the logit scale on every step) and return identical
+    strings -- the drop-in claim, demonstrated end to end."""
+    import json
+    from livecc_amd import video as V
+    from livecc_amd.infer import LiveCCDemoInfer
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.text import TextFrontEnd
+    from oracle import ref_infer_harness as H
+    with open(H.TRACE_PATH) as f:
+        want = json.load(f)
+    tk = H.load_tokenizer()
+    cfg = H.model_config(tk)
+    hf = H.hf_weights(cfg).to(torch.bfloat16)                     # weights only: HF computes nothing here
+    native = LiveCCForConditionalGeneration.from_hf_model(hf, cfg, dev, max_streams=1, max_kv_len=4096, max_new_rows=1024, max_patches=4096,
+                                                          max_history=32)
+    del hf
+    calls, inner = [], native.generate
+
+    def recording_generate(**kw):
+        out = inner(**kw)
+        ids = kw["input_ids"][0].tolist()
+        calls.append(dict(input_ids=ids, tokens=out.sequences[0, len(ids):].tolist()))
+        return out
+    native.generate = recording_generate
+    infer = LiveCCDemoInfer(model=native, text=TextFrontEnd(tk, cfg))
+    assert infer.streaming_eos_token_id == want["streaming_eos_token_id"] and infer.system_prompt_offset == want["system_prompt_offset"]
+    V.register_video(H.VIDEO_NAME, H.make_video())
+    try:
+        got = {}
+        responses = H.scenario_once(infer)
+        got["once"] = dict(responses=[[float(a), float(b), t] for a, b, t in responses], calls=list(calls))
+        calls.clear()
+        live, _ = H.scenario_live(infer)
+        got["live"] = dict(responses=live, calls=list(calls))
+    finally:
+        V.unregister_video(H.VIDEO_NAME)
+    stats = {}
+    for sc in ("once", "live"):
+        w, g = want[sc], got[sc]
+        assert len(g["calls"]) == len(w["calls"]), (sc, len(g["calls"]), len(w["calls"]))
+        for i, (a, b) in enumerate(zip(w["calls"], g["calls"])):
+            assert a["input_ids"] == b["input_ids"], f"{sc} call {i}: the prompt ids differ from the executed reference's"
+            assert a["tokens"] == b["tokens"], f"{sc} call {i}: tokens {b['tokens']} vs the reference's {a['tokens']}"
+        assert g["responses"] == w["responses"], sc
+        stats[sc] = dict(calls=len(w["calls"]), tokens=sum(len(c["tokens"]) for c in w["calls"]))
+    record("reference_orchestrator_trace_vs_native", stats)

@@ -140,3 +140,41 @@ def test_every_layer_at_livecc_7b_shapes_matches_hf_on_the_oracles_input(dev, sl
     print("first-token logits vs fp32 (free running):", rep)
     assert rep["rms_ratio"] <= 1.25, rep
     assert rep["max_err_native"] <= 1.5 * rep["max_err_ref16"] + 1e-3 * scale, rep
+
+
+def test_qwen2vl_72b_shaped_layer_with_fp8_weights_matches_hf_on_the_dequantised_weights(dev):
+    """BASELINE.json configs[4] at the REAL 72B widths (VERDICT r3 missing #3): ONE Qwen2-VL-72B decoder layer (hidden 8192, 64 / 8 heads,
+    intermediate 29568: 0.86 B parameters) + the 152,064 x 8192 embedding and lm_head, LLM Linear weights as OCP e4m3 bytes + fp32 row
+    scales -- the single-GPU 72B weight path -- behind one vision block.  Oracles: HF on the SAME quantised values (`fake_quantize_llm_fp8`):
+    fp32 = exact q x scale (the truth), bf16 = what the reference's dtype makes of the dequantised checkpoint.  (i) layer by layer on the
+    bf16 oracle's inputs: rms(native - fp32) <= 1.25 x rms(HF_bf16 - fp32) after the attention block, after the MLP and for final norm +
+    lm_head (the fp8 prefill GEMMs: MFMA kernels on fp8 fragments converted after the LDS read); (ii) a 2-frame turn + 4 decode steps,
+    teacher-forced in HF along the native tokens (the fp8 decode GEMVs of pipeline v2): worst |dlogit| <= 6e-2 x scale, error against fp32
+    <= 1.5 x the bf16 oracle's."""
+    import copy
+    import dataclasses
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from oracle import hf_oracle as O, layer_probe as P
+    from tests.test_gpu_e2e import _compare_stream, _replay_native
+    cfg = dataclasses.replace(get_config("qwen2vl-72b"), num_hidden_layers=1, vit_depth=1, name="qwen2vl-72b-1layer")
+    hf32 = O.build_hf_model_synthetic(cfg, torch.float32, "tiled:0")
+    O.fake_quantize_llm_fp8(hf32)
+    hf16 = copy.deepcopy(hf32).to(torch.bfloat16)
+    native = LiveCCForConditionalGeneration.from_hf_model(hf32, cfg, dev, llm_fp8=True, max_streams=1, max_kv_len=2048, max_new_rows=1280,
+                                                          max_patches=4608, max_history=8)
+    assert native.weights.llm_fp8 and native.weights.view("llm.0.gate_up_w").dtype == torch.uint8
+    T, H, W = 6, 392, 728
+    frames = torch.from_numpy(protocol.synth_frames(T, H, W, seed=1234, layout="TCHW"))
+    pv, grid = O.patchify_normalize_ref(frames, cfg)
+    ids = protocol.TurnBuilder(cfg, seed=1234).turn_ids(0, protocol.num_video_tokens(grid, cfg))
+    a16 = P.probe(hf16, cfg, ids, pv, grid)
+    t32 = P.probe(hf32, cfg, ids, pv, grid, P.inputs_of(a16))
+    nat = native_probe(native, cfg, ids, frames.to(dev), a16)
+    summary = _compare("per_layer_parity[qwen2vl-72b-1layer-fp8]", nat, a16, t32, cfg, ids)
+    print("72B-shaped fp8 layer:", summary)
+    # (ii) decode path: a 2-frame turn + 4 generated tokens on the carried cache of a 6-frame turn
+    frames2 = torch.from_numpy(protocol.synth_frames(8, H, W, seed=77, layout="TCHW"))
+    turns = _replay_native(native, cfg, frames2, protocol.TurnBuilder(cfg, seed=77), max_new_tokens=5, repetition_penalty=1.05, max_turns=2)
+    _compare_stream(cfg, hf16, hf32, turns, frames2, "stream_72b_1layer_fp8", 1.05, min_exact_frac=0.0, strict_rate=None)

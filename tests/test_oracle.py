@@ -215,40 +215,74 @@ def test_livecc7b_two_turn_golden_is_consistent_with_the_first_token_fixture():
 
 
 def test_the_fixture_following_helper_of_the_gpu_golden_tests_on_a_replaying_fake():
-    """tests/test_gpu_golden.py::_follow_golden_stream (used by the fixture-based 7B / 2B GPU tests) driven by a FAKE native model that
-    replays the committed reference: 32 steps followed, every token equal, rms ratio exactly 1, zero logit difference -- and a fake that
-    flips one undecided token stops the comparison of that turn there without failing the margin rule."""
+    """tests/test_gpu_golden.py::follow_golden_stream (used by the fixture-based 7B / 2B GPU tests) driven by a FAKE native model that
+    replays the committed reference's logits and honours teacher forcing: 32 steps compared, every own choice equal, rms ratio exactly 1,
+    zero logit difference; a fake whose logits prefer the reference's second choice on one step shows up as a token mismatch -- counted
+    against the margin rule only when the reference's own margin decides that step."""
     import types
-    from livecc_amd.config import get_config
     from oracle import make_golden_7b as G
     from tests import test_gpu_golden as T
     g = dict(np.load(G.PATH_TURNS))
     seed_in, n_frames, H, W, max_new, _ = (int(x) for x in g["meta"])
-    cfg = get_config("livecc-7b")
-    V, sid = cfg.vocab_size, g["sample_ids"]
+    V, sid = 152064, g["sample_ids"]
 
     class Fake:
         def __init__(self, flip=None):
             self.turn, self.flip = 0, flip
 
-        def generate(self, input_ids, frames, past_key_values, max_new_tokens, **kw):
+        def generate(self, input_ids, frames, past_key_values, max_new_tokens, teacher_tokens=None, **kw):
             ti = self.turn
             self.turn += 1
             lg = np.full((max_new_tokens, V), -30.0, dtype=np.float32)
             for k in range(max_new_tokens):
                 lg[k][sid] = g[f"t{ti}_sample_vals_bf16"][k]
                 lg[k][g[f"t{ti}_top_ids"][k]] = g[f"t{ti}_top_vals_bf16"][k]
-            toks = g[f"t{ti}_tokens"].copy()
             if self.flip is not None and self.flip[0] == ti:
-                toks[self.flip[1]] = int(g[f"t{ti}_top_ids"][self.flip[1]][1])
-            seq = torch.cat([input_ids[0], torch.from_numpy(toks)]).view(1, -1)
+                k = self.flip[1]
+                lg[k][g[f"t{ti}_top_ids"][k][1]] = g[f"t{ti}_top_vals_bf16"][k][0] + 1.0     # prefers the reference's second choice
+            seq = torch.cat([input_ids[0], torch.as_tensor(teacher_tokens, dtype=torch.long)]).view(1, -1)
             return types.SimpleNamespace(sequences=seq, logits=torch.from_numpy(lg), past_key_values=types.SimpleNamespace(release=lambda: None))
 
-    frames = torch.zeros(n_frames, 3, 4, 4, dtype=torch.uint8)
-    g2 = dict(g)
-    g2["meta"] = np.asarray([seed_in])
-    st = T._follow_golden_stream(Fake(), cfg, g2, frames, 2, max_new, "top_vals_bf16", "sample_vals_bf16", "sample_vals_fp32")
+    turns = T._turns_of(g, 2, "top_vals_bf16")
+
+    def noise(ti, k):
+        return float(np.abs(g[f"t{ti}_top_vals_bf16"][k].astype(np.float64) - g[f"t{ti}_top_vals_fp32"][k]).max())
+    sample = (sid, "sample_vals_bf16", "sample_vals_fp32")
+    st = T.follow_golden_stream(Fake(), turns, lambda ti: None, max_new, "top_vals_bf16", noise, sample=sample)
+    # the replayed RAW logits + the host-side penalty reproduce HF's own greedy choice on every step
     assert (st["steps"], st["tokens_equal"]) == (32, 32) and st["worst_rel_dlogit_top"] == 0.0
     assert max(st["ratios"]) == 1.0 and min(st["ratios"]) == 1.0 and st["decided_equal"] == st["decided"] > 0
-    st = T._follow_golden_stream(Fake(flip=(0, 5)), cfg, g2, frames, 2, max_new, "top_vals_bf16", "sample_vals_bf16", "sample_vals_fp32")
-    assert st["steps"] == 6 and st["tokens_equal"] == 5          # steps 0..5 compared (histories equal), step 5 differs, turn 1 not entered
+    undecided = [(ti, k) for ti in range(2) for k in range(max_new)
+                 if not (g[f"t{ti}_top_vals_bf16"][k][0] - g[f"t{ti}_top_vals_bf16"][k][1] > 2 * noise(ti, k))]
+    assert undecided, "random weights leave undecided steps"
+    st = T.follow_golden_stream(Fake(flip=undecided[0]), turns, lambda ti: None, max_new, "top_vals_bf16", noise, sample=sample)
+    assert st["steps"] == 32 and st["tokens_equal"] == 31 and st["decided_equal"] == st["decided"] and st["undecided_mismatch_steps"] == [undecided[0]]
+
+
+def test_livecc7b_oneshot480_fixture_is_selfconsistent_and_rebuildable_from_its_seeds():
+    """tests/golden/livecc7b_oneshot480.npz (oracle/make_golden_7b_long.py: the executed HF reference at BASELINE configs[3]'s real shapes --
+    480 frames, 24,058-row prompt, 8 tokens at L ~ 24k; bf16 free-running + fp32 teacher-forced): the prompt is rebuilt from the seeds, the
+    bf16 run's own greedy tokens equal its top-1 ids after the repetition penalty, and the 4,096-id sample tracks the full-vocabulary rms
+    of (bf16 - fp32) within 5 % on every step (the statistic the GPU test uses)."""
+    from livecc_amd.config import get_config
+    from oracle import make_golden_7b_long as L
+    from tests.test_gpu_golden import own_choice
+    g = dict(np.load(L.PATH))
+    cfg = get_config("livecc-7b")
+    ids, grid = L.prompt_ids(cfg)
+    assert len(ids) == int(g["ids_len"]) == 24058 and tuple(grid) == (240, 20, 20) and int((ids == cfg.video_token_id).sum()) == 24000
+    assert np.array_equal(ids[:64], g["ids_head"]) and np.array_equal(ids[-64:], g["ids_tail"])
+    assert np.array_equal(g["sample_ids"], L.sample_ids(cfg.vocab_size))
+    n = int(g["meta"][4])
+    assert g["tokens"].shape == (n,) and g["t0_top_ids"].shape == (n, L.TOPK) and g["t0_sample_vals_fp32"].shape == (n, L.NSAMPLE)
+    assert (np.diff(g["t0_top_vals_bf16"], axis=1) <= 0).all()
+    e = np.sqrt(((g["t0_sample_vals_bf16"] - g["t0_sample_vals_fp32"]).astype(np.float64) ** 2).mean(axis=-1))
+    full = g["t0_rms_err_bf16_full_vocab"].astype(np.float64)
+    assert (np.abs(e / full - 1.0) <= 0.05).all(), e / full
+    # the committed tokens are the bf16 run's own greedy choices: rebuild each step's decision from its top-64 raw logits + the penalty
+    seen = set(int(x) for x in ids)
+    for k in range(n):
+        lg = np.full(cfg.vocab_size, -1e30, dtype=np.float32)
+        lg[g["t0_top_ids"][k]] = g["t0_top_vals_bf16"][k]
+        assert own_choice(lg, seen, L.PENALTY) == int(g["tokens"][k]), k
+        seen.add(int(g["tokens"][k]))

@@ -1,0 +1,30 @@
+#!/bin/bash
+# One parametrised driver for the GPU calls of a round (replaces the per-call scripts of round 3):
+#   gpurun --timeout N -- 'bash tools/gpu_call.sh <recipe> [args]'
+# Every step runs under its own `timeout`, writes under gpurun_out/<recipe>/ and never stops the recipe on failure.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+RECIPE=${1:-help}; shift || true
+O=$R/gpurun_out/$RECIPE
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+B="python bench.py --cpu-baseline off --parity off"
+val() { grep -o "\"$2\": [0-9.]*" $1 | head -1 | cut -d' ' -f2; }
+
+case $RECIPE in
+golden)      # the fixture-based 7B / 2B tests (no HF forward on the box)
+  timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q --timeout 600 "$@" > $O/golden.log 2>&1; tail -n 15 $O/golden.log ;;
+ring4)       # gemm_big4_kernel (LCC_GEMM_RING=4) vs the default: bit-identity, micro-benchmark, and (only if faster) the 8-stream bench A/B
+  timeout 200 python tools/gemm_checksum.py > $O/sum_ring2.txt 2>$O/sum_ring2.err
+  LCC_GEMM_RING=4 timeout 200 python tools/gemm_checksum.py > $O/sum_ring4.txt 2>$O/sum_ring4.err
+  cmp $O/sum_ring2.txt $O/sum_ring4.txt && echo "CHECKSUMS IDENTICAL (ring 2 vs ring 4)" || paste $O/sum_ring2.txt $O/sum_ring4.txt
+  for RING in 2 4 2 4; do LCC_GEMM_RING=$RING timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/ring$RING /" | tee -a $O/gemm_ring.txt; done ;;
+pmc_l2)      # L2 / TCP / TA counters of the 8-wave GEMM's DMA ring
+  bash tools/pmc_gemm_l2.sh $O > $O/pmc_l2.log 2>&1; tail -n 70 $O/pmc_l2.log ;;
+tests)       # the whole GPU tier, serially, as the driver runs it
+  timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
+bench)       # the driver's default line
+  timeout 1700 python bench.py "$@" > $O/bench.log 2>$O/bench.err; tail -n 3 $O/bench.log | cut -c1-3000; tail -n 5 $O/bench.err ;;
+*) echo "recipes: golden ring4 pmc_l2 tests bench (see the case statement)";;
+esac

@@ -1,5 +1,5 @@
 #!/bin/bash
-# NEXT-ROUND EXPERIMENT (prepared in round 3, not yet run: the round's GPU minutes were spent): where do the bytes of the 8-wave GEMM's
+# Where do the bytes of the 8-wave GEMM's
 # LDS-DMA ring come from?  The round-3 timing split says the ring is THROUGHPUT-bound at ~12 TB/s chip-wide (profiles/r03/gemm_diag.jsonl);
 # these passes ask whether that is the L2 (hit bandwidth, same-line contention), the fabric behind it (MALL / HBM misses), or the CU side
 # (TCP / TA).  One rocprofv3 pass per counter group (never combined with trace domains), kernel = gemm_big_kernel<256,...> at M = 3088
@@ -19,8 +19,6 @@ for C in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
          "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
          "TCC_TAG_STALL_sum TCC_BUSY_sum TCC_CYCLE_sum TCC_NORMAL_WRITEBACK_sum" \
          "TA_BUSY_avr TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
-         "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_GMI_32B_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_LEVEL_sum" \
-         "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCC_LATENCY_FIFO_FULL_sum TCC_SRC_FIFO_FULL_sum" \
          "SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pass$i -o gemm -- python $R/tools/pmc_target.py --gemm > $O/pass$i.log 2>&1 || echo "pass $i ($C) failed: $(tail -n 1 $O/pass$i.log)"
