@@ -77,6 +77,9 @@ def parse(argv=None):
                     help="compare the native path with the CPU reference leg on the same seeded weights (when the CPU leg runs at the "
                          "benchmarked shapes); full (= auto at --gpus 1, +~5 min of host time) also runs the fp32 truth for the error-ratio "
                          "test and the greedy token-identity check on the decisive synthetic weights; auto with --gpus > 1 = bf16")
+    ap.add_argument("--share8", choices=["auto", "on", "off"], default="auto",
+                    help="also time ONE GPU's share of BASELINE.json configs[2] (8 co-scheduled streams) in the same run and emit it as "
+                         "`configs2_share` (auto: on for the default line -- LiveCC-7B, stream60, bf16, one stream per GPU, --gpus 1)")
     ap.add_argument("--standin", action="store_true",
                     help="launcher self-test: a stand-in model on CPU ranks over gloo (no GPU work, numbers meaningless)")
     a = ap.parse_args(argv)
@@ -203,6 +206,117 @@ def oneshot_flops(cfg, nframes, height, width, n_text):
     return dict(vit_flops=float(vit), llm_prefill_flops=float(llm), prefill_rows=int(S), patches=int(slices * n))
 
 
+def stream_phase_flops(cfg, nframes, height, width, kept_per_turn, protocol):
+    """Algorithmic flops of the MFMA-bound phases of ONE stream's replay (SURVEY 8d formulas), turn by turn: the vision tower over the
+    turn's temporal slices (patch embed + blocks + per-slice attention + merger) and the LLM prefill of the turn's S new rows against the
+    L keys already cached (Linear layers + causal attention, lm_head once per turn).  `kept_per_turn`: generated tokens that stay in the
+    cache after a turn (max_new_tokens - 1: `past_ids = sequences[:, :-1]`)."""
+    n = (height // 14) * (width // 14)
+    E, M, H = cfg.vit_embed_dim, cfg.vit_mlp_dim, cfg.hidden_size
+    blk = E * 3 * E + E * E + 2 * E * M
+    lin = cfg.hidden_size * cfg.qkv_dim + cfg.q_dim * cfg.hidden_size + 3 * cfg.hidden_size * cfg.intermediate_size
+    b = protocol.TurnBuilder(cfg, seed=0)
+    vit = llm = 0.0
+    kv = rows = 0
+    for ti, (a, e) in enumerate(protocol.split_clip(nframes)):
+        slices = (e - a + 1) // 2
+        vit += slices * (2 * n * (cfg.patch_dim * E + cfg.vit_depth * blk) + cfg.vit_depth * 4 * n * n * E + 2 * (n // 4) * (4 * E * 4 * E + 4 * E * H))
+        S = len(b.turn_ids(ti, protocol.num_video_tokens(protocol.grid_of(e - a, height, width, cfg), cfg)))
+        llm += cfg.num_hidden_layers * (2 * lin * S + 4 * S * (kv + S / 2) * cfg.q_dim) + 2 * cfg.vocab_size * H
+        kv += S + kept_per_turn
+        rows += S
+    return dict(vit_flops=float(vit), llm_prefill_flops=float(llm), prefill_rows=int(rows), final_kv=int(kv))
+
+
+def decode_step_roofline(cfg, engine, spg, kv_list, fp8):
+    """Whole decode steps sampled by the engine (every 4th step, hipEvents on the launch stream): every Linear weight of the layers + lm_head
+    once for the batch, plus each stream's KV read and its new KV row written, plus the logits (SURVEY 8d "decode step" formula), over the
+    measured step time against 8 TB/s."""
+    st_ms = engine.profile_read_steps(16384)
+    if not len(st_ms):
+        return None
+    wbytes = (cfg.decode_weight_bytes() // 2) if fp8 else cfg.decode_weight_bytes()
+    kv_avg = float(np.mean(kv_list)) if len(kv_list) else 0.0
+    step_bytes = wbytes + spg * (kv_avg * cfg.kv_bytes_per_token + cfg.kv_bytes_per_token + cfg.vocab_size * 4)
+    s_ms = float(np.mean(st_ms))
+    ach = step_bytes / (s_ms * 1e-3) / 1e9
+    out = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(ach, 1), frac=round(ach / 8000.0, 4), avg_step_us=round(s_ms * 1e3, 1),
+               steps_timed=int(len(st_ms)), algorithmic_bytes_per_step=int(step_bytes), weight_bytes=int(wbytes), mean_kv_len=round(kv_avg, 1),
+               us_per_layer=round((s_ms * 1e3) / cfg.num_hidden_layers, 2))
+    # the vision tower of the NEXT turn runs on a side stream under the first decode steps of a turn (prefetch): steps late in the call
+    # (index >= 8) see the GPU alone -- the kernel-efficiency number; the object itself is every sampled step
+    try:
+        rel = engine.profile_read_step_index(16384)[:len(st_ms)]
+        late = np.asarray(st_ms)[rel >= 8]
+        if len(late):
+            l_ms = float(np.mean(late))
+            out["late_steps_without_vision_tower_overlap"] = dict(avg_step_us=round(l_ms * 1e3, 1), steps_timed=int(len(late)),
+                                                                  frac=round(step_bytes / (l_ms * 1e-3) / 1e9 / 8000.0, 4))
+    except Exception:
+        pass
+    return out
+
+
+def configs2_share(cfg, arena, dev, args, protocol, streams=8, steps=2):
+    """ONE GPU's share of BASELINE.json configs[2] (64 streams data-parallel over 8 GPUs = 8 co-scheduled streams per GPU) in the driver's
+    own --gpus 1 run: the same 60-frame replay with 8 streams batched turn by turn (batched vision tower, packed
+    prefill, one weight pass per decode step for the 8 streams) -> tokens/s, tokens/s/stream, frames/s; and its MFMA-bound roofline: a
+    second replay that stops after each turn's first token (vision tower + LLM prefill of every turn, no decode steps, no prefetch
+    overlap), algorithmic flops over its wall time against the 2.5 PFLOP/s dense bf16 peak.  The 8-GPU job itself (x 8
+    replicas, one RCCL weight broadcast, no collective in the data path) is NOT measured here: no multi-GPU box is reachable."""
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    n_tok_turn = (args.height // 28) * (args.width // 28)
+    kv_need = 32 * ((args.frames // 2 + 2) * (n_tok_turn + 64) // 32 + 4)
+    model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=streams, max_kv_len=min(32768, max(4096, kv_need)),
+                                           max_new_rows=streams * (3 * n_tok_turn + 128), max_patches=streams * 12 * n_tok_turn + 64,
+                                           max_history=max(16, args.max_new_tokens))
+    frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + i)).to(dev) for i in range(streams)]
+    seeds = [1234 + i for i in range(streams)]
+    sync = lambda: torch.cuda.synchronize(dev)      # noqa: E731
+    replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, True)          # warm-up
+    model.engine.profile(True, 16384)
+    sync()
+    t0 = time.perf_counter()
+    toks = nfr = 0
+    for _ in range(steps):
+        a, b = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, True)
+        toks += a
+        nfr += b
+    sync()
+    dt = time.perf_counter() - t0
+    model.engine.profile(False)
+    kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
+    step_roof = decode_step_roofline(cfg, model.engine, streams, kv_list, False)
+    # MFMA-bound phases alone: every turn's vision tower + prefill, one token per turn (no decode steps), no prefetch overlap
+    replay(model, cfg, frames, seeds, 1, protocol, torch, False)
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        replay(model, cfg, frames, seeds, 1, protocol, torch, False)
+    sync()
+    dt1 = (time.perf_counter() - t1) / steps
+    fl = stream_phase_flops(cfg, args.frames, args.height, args.width, 0, protocol)
+    flops = streams * (fl["vit_flops"] + fl["llm_prefill_flops"])
+    tf = flops / dt1 / 1e12
+    per_stream = toks / dt / streams
+    del model, frames
+    torch.cuda.empty_cache()
+    return dict(
+        workload=f"{cfg.name}, {streams} co-scheduled streams on ONE GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, {args.max_new_tokens} "
+                 f"tokens/turn, greedy = one GPU's share of BASELINE.json configs[2] (64 streams over 8 GPUs)",
+        streams_per_gpu=streams, steps=steps, value=round(toks / dt, 2), unit="tokens/s", tokens_per_s_per_stream=round(per_stream, 2),
+        frames_per_s=round(nfr / dt, 2), ms_per_replay=round(dt / steps * 1e3, 1),
+        north_star_target_tokens_per_s_per_stream=30.0, meets_target_on_this_gpu=bool(per_stream >= 30.0),
+        eight_gpu_job="unmeasured (no multi-GPU box reachable): x 8 independent replicas of this share, weights broadcast once over RCCL, no "
+                      "collective in prefill / decode",
+        roofline=dict(bound="mfma", kernel="vision tower + LLM prefill of every turn (every GEMM / attention launch), 8 streams batched; replay "
+                                           "stopped after each turn's first token, no prefetch overlap",
+                      achieved=round(tf, 1), peak=2500.0, unit="TFLOP/s", frac=round(tf / 2500.0, 4), traffic=None,
+                      algorithmic_flops_per_replay=flops, vit_flops_per_stream=fl["vit_flops"], llm_prefill_flops_per_stream=fl["llm_prefill_flops"],
+                      prefill_rows_per_stream=fl["prefill_rows"], seconds_per_replay=round(dt1, 4)),
+        decode_step=step_roof)
+
+
 def kv_lengths_of_decode_steps(cfg, nframes, height, width, max_new, protocol):
     """KV length seen by every decode step of one stream replay (for the decode_step roofline's KV bytes)."""
     b = protocol.TurnBuilder(cfg, seed=0)
@@ -219,11 +333,11 @@ def kv_lengths_of_decode_steps(cfg, nframes, height, width, max_new, protocol):
 # ------------------------------------------------------------------------------------------------------------------------
 # CPU reference leg (oracle/cpu_baseline.py in a subprocess under a wall-clock budget) + parity against it
 # ------------------------------------------------------------------------------------------------------------------------
-def run_cpu_leg(cfg_name, args, budget_s, turns, teacher=None, logits_out=None, dtype="bfloat16", weights="tiled:0"):
+def run_cpu_leg(cfg_name, args, budget_s, turns, teacher=None, logits_out=None, dtype="bfloat16", weights="tiled:0", attn="sdpa", threads=0):
     import selectors
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", cfg_name, "--height", str(args.height),
            "--width", str(args.width), "--max-new-tokens", str(args.max_new_tokens), "--turns", str(turns), "--dtype", dtype,
-           "--weights", weights, "--seed", "1234"]
+           "--weights", weights, "--seed", "1234", "--attn", attn, "--threads", str(threads)]
     if teacher is not None:
         cmd += ["--teacher", teacher]
     if logits_out is not None:
@@ -377,6 +491,23 @@ def parity_report(native_tokens, native_logits, ref, ref32=None):
     return out
 
 
+def hf_vs_hf_report(ref_a, ref_b, native_tokens, how):
+    """The reference's OWN bf16 noise floor: the same two turns, same weights, same teacher tokens through HF bf16
+    twice under different evaluation orders (`ref_a`: sdpa on all cores -- the `cpu_baseline` leg; `ref_b`: eager attention on fewer
+    threads = another GEMM blocking and another softmax / accumulation order).  Same statistics as native-vs-HF next to it: what two runs
+    of the REFERENCE differ by is the resolution at which any bf16 implementation can be compared with it."""
+    la, lb = ref_a["logits"], ref_b["logits"]
+    t = min(la.shape[0], lb.shape[0])
+    la, lb = la[:t], lb[:t]
+    scale = np.abs(la).max(axis=-1)
+    d = np.abs(la - lb).max(axis=-1)
+    oa, ob, nt = ref_a["own_argmax"][:t], ref_b["own_argmax"][:t], native_tokens[:t]
+    return dict(how=how, turns_compared=int(t), steps=int(d.size), rel_dlogit_hf_vs_hf=round(float((d / scale).max()), 5),
+                mean_rel_dlogit_hf_vs_hf=round(float((d / scale).mean()), 5), tokens_equal_hf_vs_hf=int((oa == ob).sum()), tokens_total=int(oa.size),
+                rms_dlogit_hf_vs_hf=round(float(np.sqrt(((la - lb).astype(np.float64) ** 2).mean())), 5),
+                native_tokens_equal_run_a=int((nt == oa).sum()), native_tokens_equal_run_b=int((nt == ob).sum()))
+
+
 def decisive_report(native_tokens, native_logits, ref):
     """Greedy token identity on the `decisive` synthetic weights (livecc_amd/weights.py): the HF CPU path, teacher-forced along the
     native tokens, must prefer exactly the native token at every step; margin_over_noise = HF's own top-1/top-2 logit margin over
@@ -526,37 +657,14 @@ def main():
             roof = dict(bound="hbm", kernel=("fp8 " if fp8 else "") + "decode gate/up weight-streaming GEMV + SwiGLU", achieved=round(ach, 1),
                         peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=traffic, avg_launch_us=round(avg_ms * 1e3, 2),
                         launches_timed=int(len(ms)), algorithmic_bytes_per_launch=alg_bytes)
-        st_ms = model.engine.profile_read_steps(16384)
-        if len(st_ms):
-            # whole decode step: every Linear weight of the 28 layers + lm_head once for the batch, plus each stream's KV read and
-            # its new KV row written, plus the logits (SURVEY 8d "decode step" formula)
-            wbytes = (cfg.decode_weight_bytes() // 2) if fp8 else cfg.decode_weight_bytes()
-            if oneshot:
-                S0 = oneshot_flops(cfg, args.frames, args.height, args.width, ONESHOT_TEXT_IDS)["prefill_rows"]
-                kv_list = [S0 + k for k in range(1, args.max_new_tokens)]
-            else:
-                kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
-            kv_avg = float(np.mean(kv_list)) if kv_list else 0.0
-            step_bytes = wbytes + spg * (kv_avg * cfg.kv_bytes_per_token + cfg.kv_bytes_per_token + cfg.vocab_size * 4)
-            s_ms = float(np.mean(st_ms))
-            ach = step_bytes / (s_ms * 1e-3) / 1e9
-            step_roof = dict(bound="hbm", unit="GB/s", peak=8000.0, achieved=round(ach, 1), frac=round(ach / 8000.0, 4),
-                             avg_step_us=round(s_ms * 1e3, 1), steps_timed=int(len(st_ms)), algorithmic_bytes_per_step=int(step_bytes),
-                             weight_bytes=int(wbytes), mean_kv_len=round(kv_avg, 1),
-                             us_per_layer=round((s_ms * 1e3) / cfg.num_hidden_layers, 2))
-            # the vision tower of the NEXT turn runs on a side stream under the first decode steps of a turn (prefetch): steps late in
-            # the call (index >= 8) see the GPU alone -- the kernel-efficiency number; `decode_step` above is every sampled step
-            try:
-                rel = model.engine.profile_read_step_index(16384)[:len(st_ms)]
-                late = np.asarray(st_ms)[rel >= 8]
-                if len(late):
-                    l_ms = float(np.mean(late))
-                    step_roof["late_steps_without_vision_tower_overlap"] = dict(avg_step_us=round(l_ms * 1e3, 1), steps_timed=int(len(late)),
-                                                                                frac=round(step_bytes / (l_ms * 1e-3) / 1e9 / 8000.0, 4))
-            except Exception:
-                pass
-            if roof is not None:
-                roof["decode_step"] = step_roof
+        if oneshot:
+            S0 = oneshot_flops(cfg, args.frames, args.height, args.width, ONESHOT_TEXT_IDS)["prefill_rows"]
+            kv_list = [S0 + k for k in range(1, args.max_new_tokens)]
+        else:
+            kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
+        step_roof = decode_step_roofline(cfg, model.engine, spg, kv_list, fp8)
+        if step_roof is not None and roof is not None:
+            roof["decode_step"] = step_roof
         if oneshot:
             # the one-shot call is MFMA-bound up to its first token: the vision tower over every slice + the long prefill.  Timed live
             # with events around prefill-only calls (max_new_tokens = 1) on the launch stream; flops = SURVEY 8d formulas.
@@ -577,6 +685,14 @@ def main():
                         vit_flops=fl["vit_flops"], llm_prefill_flops=fl["llm_prefill_flops"], prefill_rows=fl["prefill_rows"], patches=fl["patches"],
                         prefill_rows_per_launch_sequence=args.prefill_rows, frames_per_s_to_first_token=round(spg * args.frames / (ms1 * 1e-3), 1),
                         decode_gate_up=roof)
+    share = None
+    want_share = args.share8 == "on" or (args.share8 == "auto" and world == 1 and spg == 1 and cfg.name == "livecc-7b" and args.workload == "stream60"
+                                         and args.frames == 60 and not fp8)
+    if want_share and not args.standin:
+        try:
+            share = configs2_share(cfg, arena, dev, args, protocol)
+        except Exception as e:       # never takes the main line down
+            share = dict(error=repr(e))
     cpu = par = None
     want_cpu = (args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)) and not args.standin
     if want_cpu:
@@ -598,6 +714,16 @@ def main():
                     run_cpu_leg(cpu_cfg, args, 4 * args.cpu_budget, 2, teacher, out32, dtype="float32")
                     ref32 = np.load(out32) if os.path.exists(out32) else None
                 par = parity_report(ntok, nlog, np.load(out16), ref32)
+                if args.parity == "full":
+                    # the reference against ITSELF: a second bf16 leg under another evaluation order (eager attention, a quarter of the threads)
+                    out16b = os.path.join(tmp, "ref16b.npz")
+                    thr_b = max(8, (os.cpu_count() or 32) // 4)
+                    run_cpu_leg(cpu_cfg, args, 2 * args.cpu_budget, 2, teacher, out16b, attn="eager", threads=thr_b)
+                    if os.path.exists(out16b):
+                        par["reference_noise_floor"] = hf_vs_hf_report(np.load(out16), np.load(out16b), ntok,
+                                                                        f"HF bf16 sdpa / all cores vs HF bf16 eager / {thr_b} threads, same weights, same teacher tokens")
+                        nf = par["reference_noise_floor"]
+                        par["rel_dlogit_vs_bf16_over_reference_noise_floor"] = round(par["rel_dlogit_vs_bf16"] / max(nf["rel_dlogit_hf_vs_hf"], 1e-9), 3)
                 if args.parity == "full":
                     # "token-id exact under greedy" (north_star) on weights where the argmax is decided by the model, not by rounding:
                     # the SAME arena refilled in place with the decisive variant, the same two turns, HF CPU teacher-forced
@@ -645,7 +771,10 @@ def main():
         "weight_broadcast_s_per_rank": [round(x, 3) for x in bcast_per_rank],
         "weight_broadcast_xgmi_bound_s": round(arena.nbytes() / 153e9, 3) if (arena is not None and world > 1) else 0.0,
         "ranks_pinned_to_gpu_numa_node": int(numa_pinned),
-        "roofline": roof, "cpu_baseline": cpu, "parity": par,
+        "roofline": roof, "cpu_baseline": cpu, "parity": par, "configs2_share": share,
+        "timed_region": "frames resident in HBM as uint8 (resize / H2D outside the timed region); back-to-back replay: the NEXT turn's vision tower "
+                        "is prefetched on a side stream under this turn's decode steps" + (" (disabled: --no-prefetch)" if args.no_prefetch else "") +
+                        " -- available to a replay / a server that fetches ahead, NOT to a live 2-fps stream whose next frames do not exist yet",
     }
     print(json.dumps(out), flush=True)
 

@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--teacher", default=None)
     ap.add_argument("--logits-out", default=None)
+    ap.add_argument("--attn", default="sdpa", choices=["sdpa", "eager"], help="HF attention implementation (the bench's second bf16 leg runs "
+                    "`eager` on fewer threads: the reference's own bf16 arithmetic under another evaluation order = its noise floor)")
+    ap.add_argument("--threads", type=int, default=0, help="torch intra-op threads (0 = torch's default: all cores)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -54,6 +57,8 @@ def main():
     from livecc_amd.config import get_config
     from oracle import hf_oracle as O
     cfg = get_config(a.config)
+    if a.threads > 0:
+        torch.set_num_threads(a.threads)
     dtype = getattr(torch, a.dtype)
     cores = os.cpu_count() or 1
     emit(event="imported", seconds=round(time.perf_counter() - T_IMPORT, 2))
@@ -66,9 +71,9 @@ def main():
                     break
     except OSError:
         pass
-    emit(event="start", cores=cores, threads=torch.get_num_threads(), cpu=cpu_model, config=cfg.name, dtype=a.dtype)
+    emit(event="start", cores=cores, threads=torch.get_num_threads(), cpu=cpu_model, config=cfg.name, dtype=a.dtype, attn=a.attn)
     t0 = time.perf_counter()
-    m = O.build_hf_model_synthetic(cfg, dtype, a.weights)
+    m = O.build_hf_model_synthetic(cfg, dtype, a.weights, attn_implementation=a.attn)
     emit(event="built", seconds=round(time.perf_counter() - t0, 2))
 
     n_frames = 6 + 2 * (a.turns - 1)

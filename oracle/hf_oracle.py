@@ -127,7 +127,7 @@ def parse_weight_spec(spec: str):
     return variant, int(seed or 0)
 
 
-def build_hf_model_synthetic(cfg: LiveCCConfig, dtype=torch.bfloat16, spec: str = "tiled:0"):
+def build_hf_model_synthetic(cfg: LiveCCConfig, dtype=torch.bfloat16, spec: str = "tiled:0", attn_implementation: str = "sdpa"):
     """HF model at `cfg`'s shapes filled with the seeded synthetic weights of `WeightArena.fill_tiled(seed, variant)` -- bit-identical
     to the MI355X arena, so this model's outputs ARE the oracle for the native path at full shapes.  Built on the meta device (no
     random init of 8 B parameters) and filled window by window."""
@@ -135,7 +135,7 @@ def build_hf_model_synthetic(cfg: LiveCCConfig, dtype=torch.bfloat16, spec: str 
     from livecc_amd.weights import fill_hf_model_tiled
     variant, seed = parse_weight_spec(spec)
     with torch.device("meta"):
-        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(), dtype=dtype)
+        m = Qwen2VLForConditionalGeneration._from_config(cfg.to_hf(attn_implementation=attn_implementation), dtype=dtype)
     m = m.to_empty(device="cpu")
     fill_hf_model_tiled(m, cfg, seed, variant)
     if cfg.tie_word_embeddings:
