@@ -81,7 +81,7 @@ int lcc_debug_set_fused_tails(int on);
  * measured slower: 4-wave attention blocks 10.0 us + o_proj 9.8 us vs 7.3 + 4.9 + 6.8 us. */
 int lcc_debug_set_decode_path(int path);
 /* 1: pipeline v2 launches down_proj of layer l and the q/k/v GEMV of layer l+1 as ONE chained launch (5 launches per layer; default 0:
- * measured slower on MI355X, 3.1-3.2 vs 2.99 ms per decode step -- see csrc/engine.hip):
+ * measured slower on MI355X, 3.1-3.2 vs 2.99 ms per decode step -- see csrc/engine_llm.hip):
  * the q/k/v blocks are resident next to the down_proj blocks, request their weights at once and then wait -- bounded -- for the
  * down_proj blocks to publish the residual stream (write-through stores + a monotonic counter, Guideline 16 R1), so the HBM stream
  * does not drain at the hand-off.  Used only when both grids fit the chip at once (LiveCC-7B: 224 + 288 blocks of 512 threads = 2 per
@@ -91,6 +91,10 @@ int lcc_debug_set_decode_chain(int on);
  * K >= 8192 (the down projection: half the dependent chain of load stages per wave), 2 = 16 waves for every call.  Returns the old mode.
  * The K split across the waves of a block -- and so the fp32 summation order -- differs between the two shapes. */
 int lcc_debug_set_resid_waves(int mode);
+/* Largest M (16..64, default 64) served by the weight-streaming GEMV kernels of lcc_gemm_bf16 and by the engine's decode step: with 17..64
+ * rows (decode batches of 17-64 streams) a weight fragment is multiplied with 2-4 activation fragments, so every weight byte is still
+ * read once per step.  16 restores the round-3 routing of such batches through the 64-row GEMM tiles.  Returns the old value. */
+int lcc_debug_set_skinny_rows(int rows);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
  * [N/16][K/64][4 g][16 rows][16 k] (lane (g,row) owns 16 consecutive k), wscale = fp32 [N] per-output-row scale:
@@ -364,7 +368,8 @@ int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slots, const in
                     void* stream);
 /* n_steps further decode steps for the same streams without any host round trip.  n_streams <= LCC_MAX_DECODE_BATCH (and
  * <= max_new_rows): up to 16 streams are one MFMA column tile of the weight-streaming GEMVs; 17..64 go through the 64-row GEMM
- * tiles (the weights are still streamed once per step for the whole batch).  Larger batches: call once per group. */
+ * tiles (the weights are still streamed once per step for the whole batch).  Larger batches: call once per group.
+ * Round 4: 17..64 streams take the weight-streaming GEMVs too (lcc_debug_set_skinny_rows). */
 #define LCC_MAX_DECODE_BATCH 64
 int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots, int n_steps, int first_step_index,
                    const lcc_sampling* sp, void* stream);

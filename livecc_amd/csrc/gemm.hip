@@ -528,6 +528,156 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// tiled GEMM v5 ("ping-pong", round 4): the 256 x 256 x 64 tile with the two wave groups of a CU running HALF A PHASE APART
+// ------------------------------------------------------------------------------------------------
+// Why.  gemm_big_kernel<256> has ONE barrier per k-tile; both waves of a SIMD leave it together, both wait for their first fragments,
+// both multiply, both drain: MFMAs alone 654 us, DMA ring alone 580 us, kernel 830 us at M = 3088 (profiles/r03/gemm_diag.jsonl),
+// MfmaUtil 51 %.  A deeper ring does not help (gemm_big4 experiment, profiles/r04/gemm_ring4_vs_ring2.txt: 0.97 vs 1.01 PF) -- the lost
+// time is the lock step, not the DMA round trip.  Here the k-tile is cut into FOUR phases = the four 64 x 32 quadrants of a wave's
+// 128 x 64 output tile (16 MFMAs each), every phase is [fragment reads + 2 DMA pieces] barrier [16 MFMAs] barrier, and the waves of
+// group 1 (wm = 1: the second wave of every SIMD) execute one extra barrier up front: in every barrier interval one wave of a SIMD
+// multiplies while the other reads fragments and feeds the DMA ring (the 8-phase structure of cdna_hip_programming.md section 5,
+// rebuilt on this library's packed-W / swizzled-A LDS images).
+//   quadrant order (0,0) (0,1) (1,1) (1,0): phase 1 reads A rows 0-3 (8 ds_read_b128) + W cols 0-1 (4), phase 2 W cols 2-3 (4),
+//   phase 3 A rows 4-7 (8), phase 4 nothing (both W halves stay in registers) -> 24 fragment reads per k-tile instead of 40.
+//   DMA: the next k-tile is staged in four 16-KB regions, one per phase (A rows 0-63 of both row halves | W cols 0-1 of the four
+//   column groups | W cols 2-3 | A rows 64-127), 2 pieces per wave and phase, into the OTHER 64-KB stage: a region is written >= 4
+//   phases after its last reader and needed >= 3 phases after its issue.  Every wave waits `vmcnt(4)` (its two youngest phases may
+//   stay in flight) before every EVEN barrier -- group 0 at the end of its phase, group 1 in the middle of its own -- so that whoever
+//   reads a region next has passed a barrier behind every issuing wave's wait (MI355X_MICROARCH.md item 7: one barrier more between
+//   staggered groups).  The DMA stream never drains inside the k loop.
+// Same accumulation order per accumulator as gemm_big_kernel (k-step 0, then 1, tile after tile): outputs are bit-identical.
+template <int EPI, int PRIO>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
+    float* __restrict__ partial, int kt_per_split) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
+  constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image (128 B per row, chunks XOR-swizzled with row & 7)
+  constexpr int STAGE = A_UNITS + 32 * 64;        // + 32 W sub-tiles of 1 KB: 4096 units = 64 KB
+  extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
+
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;   // consecutive ids (one XCD) share the W panel
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 15, g = lane >> 4;
+  const int K32 = K >> 5, nfrag = N >> 4;
+  const bool wave_has_rows = m0 + wm * WM < M;
+
+  // DMA pieces of this wave: in phase j it copies pieces 2*wave and 2*wave + 1 of region j
+  const bf16_t* src[4][2];
+  int dst[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = wave * 2 + u;                 // 0..15
+      if (j == 0 || j == 3) {                     // A rows [h*128 + (j ? 64 : 0) + (q & 7)*8, + 8)
+        const int row0 = (q >> 3) * WM + (j == 3 ? 64 : 0) + (q & 7) * 8;
+        src[j][u] = A + (size_t)min(m0 + row0 + (lane >> 3), M - 1) * lda + (((lane & 7) ^ (lane >> 3)) << 3);
+        dst[j][u] = row0 * 8;
+      } else {                                    // W sub-tile: column group c = q >> 2, fragment row c*4 + (j == 2 ? 2 : 0) + bit 1 of q, k-step q & 1
+        const int fr = (q >> 2) * NT + (j == 2 ? 2 : 0) + ((q >> 1) & 1), kk = q & 1;
+        src[j][u] = W + ((size_t)min((n0 >> 4) + fr, nfrag - 1) * K32 + kk) * 512 + lane * 8;
+        dst[j][u] = A_UNITS + (fr * 2 + kk) * 64;
+      }
+    }
+  auto issue = [&](int kt, u32x4* sbase, int j) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src[j][u] + (size_t)kt * ((j == 0 || j == 3) ? BK : 1024)),
+          (__attribute__((address_space(3))) void*)(sbase + dst[j][u]), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt_all = K / BK;
+  const int kt0 = (EPI == EPI_PARTIAL) ? blockIdx.y * kt_per_split : 0;
+  const int nkt = (EPI == EPI_PARTIAL) ? min(nkt_all, kt0 + kt_per_split) : nkt_all;
+
+  // fragment read offsets (16-byte units within a stage)
+  int aoff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (wm * WM + li) * 8 + ((kk * 4 + g) ^ (li & 7));
+  const int boff = A_UNITS + (wn * NT * 2) * 64 + lane;
+
+  // prologue: the whole first k-tile (regions in their steady-state order), then group 1 falls one barrier interval behind
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue(kt0, dsmem, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wm == 1) {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  bf16x8 fa[4][2], fb[2][2][2];      // A rows of the current quadrant row [row tile][k-step]; W [column half][column tile][k-step]
+  for (int kt = kt0; kt < nkt; ++kt) {
+    const u32x4* s = dsmem + ((kt - kt0) & 1) * STAGE;
+    u32x4* d = dsmem + ((kt - kt0 + 1) & 1) * STAGE;
+    const int kt_dma = min(kt + 1, nkt - 1);      // past the last tile: a clamped copy into the stage nobody reads any more (uniform counts)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // ---- read half: this phase's fragments, this phase's two DMA pieces
+      if (wave_has_rows) {
+        if (j == 0 || j == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = as_bf16x8(s[aoff[kk] + ((j == 2 ? 4 : 0) + i) * 128]);
+        }
+        if (j == 0 || j == 1) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[j][c][kk] = as_bf16x8(s[boff + ((j * 2 + c) * 2 + kk) * 64]);
+        }
+      }
+      issue(kt_dma, d, j);
+      if (wm == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- multiply half: quadrant (qi, qj) = (0,0) (0,1) (1,1) (1,0)
+      if (wave_has_rows) {
+        constexpr int QI[4] = {0, 0, 1, 1}, QJ[4] = {0, 1, 1, 0};
+        const int qi = QI[j], qj = QJ[j];
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[qi * 4 + i][qj * 2 + c] = mfma16(fb[qj][c][kk], fa[i][kk], acc[qi * 4 + i][qj * 2 + c]);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+      }
+      if (wm == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();      // group 0 finishes one interval early: same barrier count for every wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies of the last k-tile
+  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // tiled GEMM v4 ("tall"): ONE block row covers all of M (256 < M <= 448: a single-stream streaming chunk is 386 rows), 8 waves,
 // 448 x 160 x 64 block tile, LDS-DMA for both operands
 // ------------------------------------------------------------------------------------------------
@@ -809,7 +959,8 @@ __global__ __launch_bounds__(512) void gemm_tall4_kernel(
 // kernel (64 KB, 2 blocks/CU; the 96 KB ring would leave 1 block/CU and measured 0.75x).
 static int g_gemm_variant = 2;
 static int g_gemm_sched = 1;   // fragment-read schedule of gemm_big_kernel: 0 compiler order, 1 pinned software pipeline
-void set_gemm_variant(int v) { g_gemm_variant = v; g_gemm_sched = (v == 5 || v == 6) ? 0 : 1; }
+static int g_gemm_pp_default = -1;
+void set_gemm_variant(int v);
 
 template <int BM, int EPI>
 static void launch_tiled(const GemmArgs& a, hipStream_t st) {
@@ -844,8 +995,28 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale);
 }
+// 0: gemm_big_kernel<256> (round 2/3), 1: gemm_pp_kernel (ping-pong wave groups), 2: the same with s_setprio(1) around the MFMA clusters.
+// LCC_GEMM_PP / lcc_debug_set_gemm_variant(10 / 11 / 12) select it.
+static int g_gemm_pp = [] { const char* v = getenv("LCC_GEMM_PP"); return v ? atoi(v) : 0; }();
+template <int EPI, int PRIO>
+static void launch_pp(const GemmArgs& a, hipStream_t st) {
+  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+  const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
+  constexpr size_t lds = (size_t)2 * (256 * 8 + 2048) * 16;      // two 64-KB stages
+  static DeviceOnce attr_set;   // per instantiation
+  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  g_launch_counts[LC_GEMM_PP]++;
+  gemm_pp_kernel<EPI, PRIO><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S);
+}
 template <int BM, int EPI>
 static void launch_big(const GemmArgs& a, hipStream_t st) {
+  if constexpr (BM == 256) {
+    if (g_gemm_pp != 0 && !a.w_fp8) {
+      if (g_gemm_pp == 2) return launch_pp<EPI, 1>(a, st);
+      return launch_pp<EPI, 0>(a, st);
+    }
+  }
   if constexpr (BM == 256 && EPI == EPI_SWIGLU) {
     // LCC_GEMM_DIAG (tools/bench_gemm_diag.py; results are WRONG by construction): 2 = no DMA after the prologue, 3 = no MFMAs
     static const int diag = [] { const char* v = getenv("LCC_GEMM_DIAG"); return v ? atoi(v) : 0; }();
@@ -862,6 +1033,14 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
   else if (g_gemm_sched && spread) launch_big_s<BM, EPI, 6, false>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
+}
+// variants 10 / 11 / 12: the 256-row 8-wave tile wherever eligible (like 3), served by gemm_big_kernel / gemm_pp_kernel / gemm_pp + setprio
+void set_gemm_variant(int v) {
+  if (g_gemm_pp_default < 0) g_gemm_pp_default = g_gemm_pp;
+  if (v >= 10 && v <= 12) { g_gemm_pp = v - 10; v = 3; }
+  else g_gemm_pp = g_gemm_pp_default;
+  g_gemm_variant = v;
+  g_gemm_sched = (v == 5 || v == 6) ? 0 : 1;
 }
 static bool big_eligible(const GemmArgs& a) { return a.w_packed && (a.K % 64) == 0 && a.M > 16; }
 
@@ -912,8 +1091,8 @@ static void launch_tall(const GemmArgs& a, hipStream_t st) {
   g_launch_counts[LC_GEMM_TALL]++;
   if (g_tall_ring == 4 || g_gemm_variant == 9) {     // variant 9 forces the tall tile with the 4-stage ring of half tiles (A/B, tests)
     constexpr size_t lds4 = (size_t)4 * (448 * 4 + 10 * 64) * 16;   // 155,648 B
-    static bool attr4 = false;   // per instantiation
-    if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_tall4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); attr4 = true; }
+    static DeviceOnce attr4;   // per instantiation
+    if (attr4.first()) (void)hipFuncSetAttribute((const void*)gemm_tall4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     gemm_tall4_kernel<EPI><<<dim3((a.N + 159) / 160), dim3(512), lds4, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
     return;
   }
@@ -965,20 +1144,25 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
 // PIPE 1: two-stage software pipeline (the next stage's loads are in flight while this one is multiplied).
 __device__ unsigned int lcc_zero_page_g[64];  // 256 zero bytes: x operand of absent K chunks (address select, no branch)
 
-template <int NTILE, int MODE, bool PACKED, int UNR, int PIPE>
+// MG = 16-row groups of activations (M <= 16 * MG): the weight fragment of a k-block is loaded ONCE and multiplied with MG activation
+// fragments (rows mg*16 + li), so 17..64 decode streams still read every weight byte once per step (round 4: before, they went through the
+// 64-row GEMM tiles: 8.5-11.9 ms per 32-stream step where the weight stream alone costs ~2.6 ms).
+template <int NTILE, int MODE, bool PACKED, int UNR, int PIPE, int MG = 1>
 __global__ __launch_bounds__(256) void gemv_skinny_kernel(
     const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ W, int ldw,
     const bf16_t* __restrict__ bias, void* __restrict__ out, int ldo, int M, int N, int K, int chunks_per_split, GemvTail tail) {
   constexpr int NW = 4;
-  __shared__ f32x4 red[NW - 1][NTILE][64];
+  static_assert(MODE != 3 || MG == 1, "the fused tail serves M <= 2");
+  __shared__ f32x4 red[NW - 1][NTILE * MG][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (NTILE * 16);
   const int split = blockIdx.y;
   const int nchunk = (K + 63) >> 6, K32 = (K + 31) >> 5;
   const int cb = split * chunks_per_split, ce = min(nchunk, cb + chunks_per_split);
 
-  const int xm = min(li, M - 1);
-  const bf16_t* xp = X + (size_t)xm * ldx + g * 8;
+  const bf16_t* xp[MG];
+#pragma unroll
+  for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (size_t)min(mg * 16 + li, M - 1) * ldx + g * 8;
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_g) + g * 8;
   const bf16_t* wp[NTILE];
 #pragma unroll
@@ -986,13 +1170,15 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
     wp[t] = PACKED ? W + (size_t)((n0 >> 4) + t) * K32 * 512 + lane * 8
                    : W + (size_t)min(n0 + t * 16 + li, N - 1) * ldw + g * 8;
 
-  f32x4 acc[NTILE];
+  f32x4 acc[NTILE][MG];
 #pragma unroll
-  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) acc[t][mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // loads are unconditional (32-k block index clamped into range) so that the compiler emits straight-line loads with
   // counted waits; an absent block is cancelled by pointing the (shared) x fragment at a zero page.
-  auto load_stage = [&](int c0, u32x4 (&wv)[UNR][2][NTILE], u32x4 (&xv)[UNR][2]) {
+  auto load_stage = [&](int c0, u32x4 (&wv)[UNR][2][NTILE], u32x4 (&xv)[UNR][2][MG]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int cc = c0 + u * NW;
@@ -1004,27 +1190,30 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 #pragma unroll
         for (int t = 0; t < NTILE; ++t)
           wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)kbc * (PACKED ? 512 : 32)));
-        xv[u][h] = ld16(ok ? xp + kbc * 32 : zp);
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) xv[u][h][mg] = ld16(ok ? xp[mg] + kbc * 32 : zp);
       }
     }
   };
-  auto mma_stage = [&](const u32x4 (&wv)[UNR][2][NTILE], const u32x4 (&xv)[UNR][2]) {
+  auto mma_stage = [&](const u32x4 (&wv)[UNR][2][NTILE], const u32x4 (&xv)[UNR][2][MG]) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int t = 0; t < NTILE; ++t) acc[t] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h]), acc[t]);
+        for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+          for (int mg = 0; mg < MG; ++mg) acc[t][mg] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h][mg]), acc[t][mg]);
   };
   constexpr int STEP = UNR * NW;  // chunk stride of one stage
   if (PIPE == 0) {
     for (int c = cb + wave; c < ce; c += STEP) {
-      u32x4 wa[UNR][2][NTILE], xa[UNR][2];
+      u32x4 wa[UNR][2][NTILE], xa[UNR][2][MG];
       load_stage(c, wa, xa);
       mma_stage(wa, xa);
     }
   } else {
-    u32x4 wa[UNR][2][NTILE], xa[UNR][2], wb[UNR][2][NTILE], xb[UNR][2];
+    u32x4 wa[UNR][2][NTILE], xa[UNR][2][MG], wb[UNR][2][NTILE], xb[UNR][2][MG];
     int c = cb + wave;
     load_stage(c, wa, xa);
     for (; c < ce; c += 2 * STEP) {
@@ -1038,7 +1227,9 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   // cross-wave reduction
   if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) red[wave - 1][t][lane] = acc[t];
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) red[wave - 1][t * MG + mg][lane] = acc[t][mg];
   }
   __syncthreads();
   if (MODE == 3) {
@@ -1049,7 +1240,7 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 #pragma unroll
       for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-        for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
+        for (int w = 0; w < NW - 1; ++w) acc[t][0] += red[w][t * MG][lane];
       if (li < M) {
         float* o = (float*)out + ((size_t)split * M + li) * ldo;
 #pragma unroll
@@ -1060,8 +1251,8 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
             // so NO per-block release fence (buffer_wbl2) is needed -- measured: a release fence in each of the ~900 blocks
             // made the whole kernel ~17 us slower
             unsigned long long* p8 = reinterpret_cast<unsigned long long*>(o + n);
-            const unsigned long long lo = (unsigned long long)__float_as_uint(acc[t][0]) | ((unsigned long long)__float_as_uint(acc[t][1]) << 32);
-            const unsigned long long hi = (unsigned long long)__float_as_uint(acc[t][2]) | ((unsigned long long)__float_as_uint(acc[t][3]) << 32);
+            const unsigned long long lo = (unsigned long long)__float_as_uint(acc[t][0][0]) | ((unsigned long long)__float_as_uint(acc[t][0][1]) << 32);
+            const unsigned long long hi = (unsigned long long)__float_as_uint(acc[t][0][2]) | ((unsigned long long)__float_as_uint(acc[t][0][3]) << 32);
             __hip_atomic_store(p8, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(p8 + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -1096,47 +1287,59 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 #pragma unroll
   for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-    for (int w = 0; w < NW - 1; ++w) acc[t] += red[w][t][lane];
+    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) acc[t][mg] += red[w][t * MG + mg][lane];
 
-  if (li >= M) return;
-  if (MODE == 0) {
-    float* o = (float*)out + ((size_t)split * M + li) * ldo;
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      const int n = n0 + t * 16 + g * 4;
-      if (n < N) *reinterpret_cast<f32x4*>(o + n) = acc[t];
-    }
-  } else if (MODE == 1) {
-    bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
+  for (int mg = 0; mg < MG; ++mg) {
+    const int m = mg * 16 + li;
+    if (m >= M) continue;
+    if (MODE == 0) {
+      float* o = (float*)out + ((size_t)split * M + m) * ldo;
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      const int n = n0 + t * 16 + g * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-      if (bias != nullptr) {
-        u32x2 b = ld8(bias + n);
-        v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+      for (int t = 0; t < NTILE; ++t) {
+        const int n = n0 + t * 16 + g * 4;
+        if (n < N) *reinterpret_cast<f32x4*>(o + n) = acc[t][mg];
       }
-      st8(o + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
-    }
-  } else {  // swiglu: tile 0 = 16 gate rows, tile 1 = the 16 matching up rows
-    static_assert(MODE != 2 || NTILE == 2, "swiglu needs the gate and up tile in one block");
-    bf16_t* o = (bf16_t*)out + (size_t)li * ldo;
-    const int oc = n0 / 2 + g * 4;
-    if (n0 < N) {
-      float r[4];
+    } else if (MODE == 1) {
+      bf16_t* o = (bf16_t*)out + (size_t)m * ldo;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) r[q] = silu_bf16(rbf(acc[0][q])) * rbf(acc[NTILE - 1][q]);
-      st8(o + oc, (u32x2){pack2(r[0], r[1]), pack2(r[2], r[3])});
+      for (int t = 0; t < NTILE; ++t) {
+        const int n = n0 + t * 16 + g * 4;
+        if (n >= N) continue;
+        float v[4] = {acc[t][mg][0], acc[t][mg][1], acc[t][mg][2], acc[t][mg][3]};
+        if (bias != nullptr) {
+          u32x2 b = ld8(bias + n);
+          v[0] += lo2f(b.x); v[1] += hi2f(b.x); v[2] += lo2f(b.y); v[3] += hi2f(b.y);
+        }
+        st8(o + n, (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])});
+      }
+    } else {  // swiglu: tile 0 = 16 gate rows, tile 1 = the 16 matching up rows
+      static_assert(MODE != 2 || NTILE == 2, "swiglu needs the gate and up tile in one block");
+      bf16_t* o = (bf16_t*)out + (size_t)m * ldo;
+      const int oc = n0 / 2 + g * 4;
+      if (n0 < N) {
+        float r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = silu_bf16(rbf(acc[0][mg][q])) * rbf(acc[NTILE - 1][mg][q]);
+        st8(o + oc, (u32x2){pack2(r[0], r[1]), pack2(r[2], r[3])});
+      }
     }
   }
 }
 
+static int g_skinny_rows = 64;
+int set_skinny_rows(int rows) { const int old = g_skinny_rows; g_skinny_rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows); return old; }
 static int g_gemv_variant = 1;  // 0: UNR2 single stage; 1: UNR1 two-stage pipeline (default: best measured); 2: UNR2 two-stage
 void set_gemv_variant(int v) { g_gemv_variant = v; }
 
-template <int NTILE, int MODE, bool PACKED>
-static void launch_gemv(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
+template <int NTILE, int MODE, bool PACKED, int MG>
+static void launch_gemv_mg(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
+  if (MG > 1) {     // 17..64 rows: the two-stage pipeline with one chunk per stage (register budget: NTILE x MG accumulators + MG x fragments)
+    gemv_skinny_kernel<NTILE, MODE, PACKED, 1, 1, MG><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps, a.tail);
+    return;
+  }
   switch (g_gemv_variant) {
     case 1:
       gemv_skinny_kernel<NTILE, MODE, PACKED, 1, 1><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps, a.tail);
@@ -1147,6 +1350,14 @@ static void launch_gemv(dim3 grid, const GemmArgs& a, void* out, int ldo, int cp
     default:
       gemv_skinny_kernel<NTILE, MODE, PACKED, 2, 0><<<grid, dim3(256), 0, st>>>(a.A, a.lda, a.W, a.ldw, a.bias, out, ldo, a.M, a.N, a.K, cps, a.tail);
   }
+}
+template <int NTILE, int MODE, bool PACKED>
+static void launch_gemv(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
+  const int mg = (a.M + 15) / 16;
+  if (mg <= 1) launch_gemv_mg<NTILE, MODE, PACKED, 1>(grid, a, out, ldo, cps, st);
+  else if (mg == 2) launch_gemv_mg<NTILE, MODE, PACKED, 2>(grid, a, out, ldo, cps, st);
+  else if (mg == 3) launch_gemv_mg<NTILE, MODE, PACKED, 3>(grid, a, out, ldo, cps, st);
+  else launch_gemv_mg<NTILE, MODE, PACKED, 4>(grid, a, out, ldo, cps, st);
 }
 template <int NTILE, int MODE>
 static void launch_gemv_l(dim3 grid, const GemmArgs& a, void* out, int ldo, int cps, hipStream_t st) {
@@ -1385,7 +1596,10 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if ((((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) != 0) return LCC_ERR_ALIGN;
   if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
   if (a.epilogue == EPI_RESIDUAL && a.residual == nullptr) return LCC_ERR_ARG;
-  const bool skinny = a.M <= 16 && (a.K % 32 == 0) && a.epilogue != EPI_QUICK_GELU &&
+  // weight-streaming path: up to g_skinny_rows rows (64: decode batches of 17-64 streams multiply every weight fragment with 2-4 activation
+  // fragments; lcc_debug_set_skinny_rows(16) restores the round-3 routing of 17-64 rows through the 64-row GEMM tiles)
+  // (a forced GEMM tile variant -- tests, A/B runs -- keeps 17-64 rows on the tiles it asks for)
+  const bool skinny = a.M <= (g_gemm_variant == 2 ? g_skinny_rows : 16) && (a.K % 32 == 0) && a.epilogue != EPI_QUICK_GELU &&
                       a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
   if (skinny) {
     const int nchunk = (a.K + 63) / 64;

@@ -26,6 +26,7 @@ enum LaunchCounter {
   LC_LAST_PREFILL_NSPLIT = 11, // key splits of the most recent prefill attention launch
   LC_GEMM_TALL = 12,
   LC_ATTN_VIT32 = 13,          // attn_vit32_kernel (vision attention on 32x32x16 MFMAs)
+  LC_GEMM_PP = 14,             // gemm_pp_kernel (256 x 256 tile, ping-pong wave groups)
   LC_COUNT = 16
 };
 extern long long g_launch_counts[LC_COUNT];
@@ -71,6 +72,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st);
 int gemv_num_splits(int N, int K);
 int gemm_tiled_num_splits(int M, int N, int K);
 void set_gemv_variant(int v);
+int set_skinny_rows(int rows);     // 16..64: largest M served by the weight-streaming GEMV kernels (returns the previous value)
 void set_gemm_variant(int v);
 int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
 

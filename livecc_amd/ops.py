@@ -109,7 +109,7 @@ ATTN_DEFAULT_VARIANT = 3
 
 LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "attn_decode_fused_merge", "gemv_fused_tail", "dgemv_v2",
                    "attn_prefill_mfma32", "attn_prefill_shared", "attn_prefill_per_wave", "attn_prefill_combine", "last_decode_nsplit",
-                   "last_prefill_nsplit", "gemm_tall", "attn_vit32")
+                   "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_pp")
 
 
 def launch_counts(reset: bool = False) -> dict:
@@ -130,6 +130,11 @@ def set_attn_variant(v: int) -> None:
 
 def set_gemm_variant(v: int) -> None:
     _lib.load().lcc_debug_set_gemm_variant(int(v))
+
+
+def set_skinny_rows(rows: int) -> int:
+    """Largest M served by the weight-streaming GEMV kernels (16..64, default 64); returns the previous value."""
+    return _lib.load().lcc_debug_set_skinny_rows(int(rows))
 
 
 def gemv_num_splits(N: int, K: int) -> int:

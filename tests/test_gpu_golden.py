@@ -181,12 +181,23 @@ def own_choice(raw_logits: np.ndarray, seen_ids, penalty: float) -> int:
     return int(sc.argmax())
 
 
+def processed_top2(top_ids, top_vals, seen_ids, penalty):
+    """The reference's own decision on one step, rebuilt from its top-K RAW logits: repetition penalty on the ids of the history, then the
+    winner and its margin over the runner-up (both are among the raw top-K: the penalty moves a logit by < 5 % of its value)."""
+    v = np.asarray(top_vals, dtype=np.float64).copy()
+    hit = np.isin(np.asarray(top_ids), np.asarray(list(seen_ids), dtype=np.int64))
+    v[hit] = np.where(v[hit] < 0, v[hit] * penalty, v[hit] / penalty)
+    order = np.argsort(-v, kind="stable")
+    return int(np.asarray(top_ids)[order[0]]), float(v[order[0]] - v[order[1]])
+
+
 def follow_golden_stream(native, turns, frames_of_turn, max_new, top_key, noise_of_step, penalty=1.05, sample=None, past_rule=True):
     """The native path along a committed reference stream.  `turns`: per turn a dict(ids=new prompt ids, tokens=the reference's greedy
     tokens, top_ids / top_vals (its top-K raw logits per step), scale).  Every turn is teacher-forced along the reference's tokens; per
     step: |native - reference| at the reference's top-K ids relative to the scale, whether the native path's OWN choice (host-side
-    penalty + argmax over its raw logits) equals the reference's token, and whether the reference's raw top-1 margin exceeds twice the
-    COMMITTED reference noise `noise_of_step(turn, k)` (not the native error) -- there the tokens must agree.
+    penalty + argmax over its raw logits) equals the reference's token, and whether the reference's margin ON ITS PROCESSED SCORES (the
+    penalty can cost the raw winner 5 % of its logit) exceeds the COMMITTED decision threshold `noise_of_step(turn, k)` (derived
+    from the reference's own bf16-vs-fp32 noise, not from the native error) -- there the tokens must agree.
     `sample` = (ids, key16, key32): rms error ratio against the fp32 truth over fixed sample ids."""
     state, past = None, None
     st = dict(steps=0, tokens_equal=0, decided=0, decided_equal=0, worst_rel_dlogit_top=0.0, ratios=[], undecided_mismatch_steps=[])
@@ -209,7 +220,8 @@ def follow_golden_stream(native, turns, frames_of_turn, max_new, top_key, noise_
             st["worst_rel_dlogit_top"] = max(st["worst_rel_dlogit_top"], d / scale)
             own = own_choice(lg[k], seen, penalty)
             st["tokens_equal"] += int(own == gold[k])
-            decided = (top_vals[0] - top_vals[1]) > 2.0 * noise_of_step(ti, k) and gold[k] == int(top_ids[0])
+            winner, margin = processed_top2(top_ids, top_vals, seen, penalty)
+            decided = margin > noise_of_step(ti, k) and winner == gold[k]
             if decided:
                 st["decided"] += 1
                 st["decided_equal"] += int(own == gold[k])
@@ -236,7 +248,8 @@ def test_livecc7b_two_turns_against_the_committed_hf_logits(dev):
     free-running + HF fp32 teacher-forced, oracle/make_golden_7b.py --turns), teacher-forced along HF's tokens, all 32 steps: per step
     |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale; rms over the 4,096 sample ids of (native - fp32) <= 1.25 x rms(HF_bf16 - fp32)
     per step and <= 1.08 over all steps (their rms tracks the full vocabulary within 5 %); the native path's own choice equals HF's token
-    wherever HF's raw top-1 margin exceeds twice HF-bf16's OWN committed error against fp32 at its top-64 ids."""
+    wherever HF's margin on its processed scores exceeds 8 x the committed rms of (HF_bf16 - HF_fp32) of that step (4 sigma of the difference
+    two equally accurate bf16 implementations show on a pair of logits; 11-12 of the 32 steps)."""
     from livecc_amd import protocol
     from livecc_amd.config import get_config
     from livecc_amd.modeling import LiveCCForConditionalGeneration
@@ -255,8 +268,10 @@ def test_livecc7b_two_turns_against_the_committed_hf_logits(dev):
     chunks = protocol.split_clip(n_frames)
     turns = _turns_of(g, n_turns, "top_vals_bf16")
 
-    def noise(ti, k):          # HF-bf16's own error against the fp32 truth at its top-64 ids of this step (committed)
-        return float(np.abs(g[f"t{ti}_top_vals_bf16"][k].astype(np.float64) - g[f"t{ti}_top_vals_fp32"][k]).max())
+    def noise(ti, k):
+        # decision threshold from the COMMITTED noise of the reference itself: rms over the vocabulary of (HF_bf16 - HF_fp32) on this step.  Two
+        # equally accurate bf16 implementations differ per logit by ~sqrt(2) rms, the difference of two logits by ~2 rms: 8 rms = 4 sigma
+        return 8.0 * float(g[f"t{ti}_rms_err_bf16_full_vocab"][k])
     st = follow_golden_stream(native, turns, lambda ti: frames[chunks[ti][0]:chunks[ti][1]], max_new, "top_vals_bf16", noise,
                               sample=(g["sample_ids"], "sample_vals_bf16", "sample_vals_fp32"))
     ratios = np.asarray(st.pop("ratios"))
@@ -273,8 +288,8 @@ def test_qwen2vl2b_config0_against_the_committed_hf_stream(dev):
     """BASELINE configs[0] (Qwen2-VL-2B real shapes, 8-frame clip = 6 + 2 frames, greedy, 16 tokens per turn) against
     tests/golden/qwen2vl2b_config0_stream.npz (HF bf16 free-running, oracle/make_golden_2b.py) without HF's forward on the GPU box (HF
     builds the seeded weights only), teacher-forced along HF's tokens: raw logits at HF's top-64 ids within 6e-2 x scale on all 32 steps;
-    the native path's own choice equals HF's wherever HF's raw margin exceeds twice 3 % of the logit scale (the bf16 noise of these shapes:
-    2.9 % measured live against HF)."""
+    the native path's own choice equals HF's wherever HF's margin on its processed scores exceeds 6 % of the logit scale (twice the bf16
+    noise of these shapes: 2.9 % measured live against HF)."""
     from livecc_amd import protocol
     from livecc_amd.config import qwen2vl_2b
     from livecc_amd.modeling import LiveCCForConditionalGeneration
@@ -294,7 +309,7 @@ def test_qwen2vl2b_config0_against_the_committed_hf_stream(dev):
     chunks = protocol.split_clip(n_frames)
     turns = _turns_of(g, n_turns, "top_vals")
     st = follow_golden_stream(native, turns, lambda ti: frames[chunks[ti][0]:chunks[ti][1]], max_new, "top_vals",
-                              lambda ti, k: 0.03 * float(g[f"t{ti}_scale"][k]))
+                              lambda ti, k: 0.06 * float(g[f"t{ti}_scale"][k]))
     st.pop("ratios")
     record("qwen2vl2b_config0_vs_committed_golden", st)
     assert st["steps"] == n_turns * max_new
@@ -310,7 +325,7 @@ def test_livecc7b_oneshot480_against_the_committed_hf_logits(dev):
     (HF bf16 free-running + HF fp32 teacher-forced on the tiled:0 weights, oracle/make_golden_7b_long.py; HF 5.15 text-offset rule on both
     sides), teacher-forced along HF's tokens: |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale on every step (step 0 = the 24k-row
     prefill's token, steps 1-7 = decode steps at L ~ 24k), rms(native - fp32) <= 1.25 x rms(HF_bf16 - fp32) over the 4,096 sample ids, the
-    native path's own choice equal to HF's wherever HF's margin exceeds twice its committed error."""
+    native path's own choice equal to HF's wherever HF's processed-score margin exceeds 8 x its committed rms error."""
     from livecc_amd import protocol
     from livecc_amd.config import get_config
     from livecc_amd.modeling import LiveCCForConditionalGeneration
@@ -333,10 +348,10 @@ def test_livecc7b_oneshot480_against_the_committed_hf_logits(dev):
     if has32:
         turn["sample_vals_fp32"] = g["t0_sample_vals_fp32"]
 
-    def noise(ti, k):
+    def noise(ti, k):          # decision threshold: 8 x the committed rms(HF_bf16 - HF_fp32) of the step (see the two-turn test)
         if has32:
-            return float(np.abs(g["t0_top_vals_bf16"][k].astype(np.float64) - g["t0_top_vals_fp32"][k]).max())
-        return 0.04 * float(scale[k])
+            return 8.0 * float(g["t0_rms_err_bf16_full_vocab"][k])
+        return 0.08 * float(scale[k])
     st = follow_golden_stream(native, [turn], lambda ti: frames, n_new, "top_vals_bf16", noise,
                               sample=(g["sample_ids"], "sample_vals_bf16", "sample_vals_fp32") if has32 else None, past_rule=False)
     ratios = np.asarray(st.pop("ratios")) if has32 else None

@@ -69,11 +69,12 @@ def _layout_variants(variants):
 @pytest.mark.parametrize("M,N,K", [(200, 512, 256), (386, 1280, 1176), (130, 480, 160), (64, 1024, 640), (1456, 3840, 1280),
                                    (17, 256, 512), (300, 4608, 3584), (260, 272, 192), (100, 256, 64), (600, 768, 512)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 2, 3, 4, 5, 6]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 2, 3, 4, 5, 6, 11, 12]))
 def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
     """variant 0: register-staged 2-stage kernel; 1: LDS-DMA (global_load_lds) 3-stage ring; 2: auto (default);
     3 / 4: the 8-wave 256x256 / 128x256 LDS-DMA kernel wherever it is eligible (packed W, K % 64 == 0), pinned fragment-read
-    schedule; 5 / 6: the same with the compiler's schedule."""
+    schedule; 5 / 6: the same with the compiler's schedule; 11 / 12: the 256x256 tile as gemm_pp_kernel (ping-pong wave groups; 12 with
+    s_setprio around the MFMA clusters)."""
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
     res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
@@ -87,7 +88,7 @@ def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
 
 
 @pytest.mark.parametrize("M,I,K", [(100, 512, 256), (386, 2432, 896), (530, 400, 128)])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 6]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 6, 11, 12]))
 def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
     from livecc_amd import ops
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
@@ -252,8 +253,46 @@ def test_gemv_skinny(dev, M, N, K, packed, variant):
     assert err <= 2e-5 * float(ref.abs().max()) * math.sqrt(K / 256) + 1e-5, f"split-K slabs: {err}"
 
 
+@pytest.mark.parametrize("M", [17, 32, 33, 48, 64])
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1024, 160)])
+@pytest.mark.parametrize("packed", [False, True])
+def test_gemv_17_to_64_rows_streams_the_weights_once(dev, M, N, K, packed):
+    """Round 4: decode batches of 17-64 streams.  The weight-streaming kernel multiplies every weight fragment with ceil(M / 16) activation
+    fragments (gemv_skinny_kernel<..., MG>): bf16 + bias output and split-K slabs against the fp32 reference, and against the round-3 routing
+    of the same call through the 64-row GEMM tiles (lcc_debug_set_skinny_rows(16))."""
+    from livecc_amd import ops
+    x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.03, 2), _rand((N,), dev, 0.1, 3)
+    ps = (N, K) if packed else None
+    wk = ops.pack_weight(w) if packed else w
+    assert ops.set_skinny_rows(64) == 64, "64 rows is the library default"
+    got = ops.linear(x, wk, b, packed_shape=ps)
+    S = ops.gemv_num_splits(N, K)
+    part = ops.linear_partial(x, wk, S, packed_shape=ps)
+    ops.set_skinny_rows(16)
+    try:
+        tiles = ops.linear(x, wk, b, packed_shape=ps)
+    finally:
+        ops.set_skinny_rows(64)
+    ref, atol = _ref_linear(x, w, b, with_atol=True)
+    assert_bf16_close(got, ref, f"gemv_mid[{M}x{N}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+    assert_bf16_close(got, tiles, f"gemv_mid_vs_tiles[{M}x{N}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+    r32 = x.float() @ w.float().t()
+    err = (part.sum(0) - r32).abs().max().item()
+    assert part.shape == (S, M, N) and err <= 2e-5 * float(r32.abs().max()) * math.sqrt(K / 256) + 1e-5, f"split-K slabs: {err}"
+
+
+@pytest.mark.parametrize("M", [17, 40, 64])
+@pytest.mark.parametrize("I,K", [(512, 256), (18944, 3584)])
+def test_gemv_17_to_64_rows_swiglu(dev, M, I, K):
+    from livecc_amd import ops
+    x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.03, 2)
+    got = ops.linear(x, ops.pack_weight(w), None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
+    ref, atol = _ref_linear(x, w, None, 4, with_atol=True)
+    assert_bf16_close(got, ref, f"gemv_mid_swiglu[{M}x{I}x{K}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+
+
 @pytest.mark.parametrize("M,N,K,S", [(100, 512, 1024, 2), (386, 3584, 3584, 4), (70, 256, 640, 3)])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 5]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 5, 11]))
 def test_gemm_tiled_splitk_slabs(dev, M, N, K, S, packed, variant):
     """prefill split-K: fp32 slabs [S][M][N] whose sum is the product (reduced by add_rmsnorm in the engine)."""
     from livecc_amd import ops

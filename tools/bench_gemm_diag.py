@@ -12,6 +12,8 @@ import torch  # noqa: E402
 from livecc_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:            # python tools/bench_gemm_diag.py <gemm variant>
+    ops.set_gemm_variant(int(sys.argv[1]))
 H, I = 3584, 18944
 ws = [ops.pack_weight((torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(2)]
 for M in (3088, 1131):
@@ -27,4 +29,4 @@ for M in (3088, 1131):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
-    print(json.dumps(dict(diag=os.environ.get("LCC_GEMM_DIAG", "0"), M=M, us=round(us, 1), pflops_if_real=round(2.0 * M * 2 * I * H / us / 1e9, 3))))
+    print(json.dumps(dict(diag=os.environ.get("LCC_GEMM_DIAG", "0"), variant=sys.argv[1] if len(sys.argv) > 1 else "default", M=M, us=round(us, 1), pflops_if_real=round(2.0 * M * 2 * I * H / us / 1e9, 3))))

@@ -11,6 +11,8 @@ import torch  # noqa: E402
 from livecc_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:            # python tools/gemm_checksum.py <gemm variant>: e.g. 3 (gemm_big_kernel<256> everywhere) vs 11 (gemm_pp_kernel)
+    ops.set_gemm_variant(int(sys.argv[1]))
 g = torch.Generator(device="cpu").manual_seed(7)
 
 

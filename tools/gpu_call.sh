@@ -22,6 +22,17 @@ ring4)       # gemm_big4_kernel (LCC_GEMM_RING=4) vs the default: bit-identity, 
   for RING in 2 4 2 4; do LCC_GEMM_RING=$RING timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/ring$RING /" | tee -a $O/gemm_ring.txt; done ;;
 pmc_l2)      # L2 / TCP / TA counters of the 8-wave GEMM's DMA ring
   bash tools/pmc_gemm_l2.sh $O > $O/pmc_l2.log 2>&1; tail -n 70 $O/pmc_l2.log ;;
+pp)          # gemm_pp_kernel (ping-pong wave groups) vs gemm_big_kernel<256>: bit-identity (3 runs = race screen), GEMM tests, micro-benchmark
+  for V in 3 11 11 11 12; do timeout 200 python tools/gemm_checksum.py $V > $O/sum_v$V.txt 2>$O/sum_v$V.err; cmp $O/sum_v3.txt $O/sum_v$V.txt && echo "variant $V: CHECKSUMS IDENTICAL to variant 3" || { echo "variant $V DIFFERS"; paste $O/sum_v3.txt $O/sum_v$V.txt; tail -n 3 $O/sum_v$V.err; }; done
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "gemm_tiled and (11 or 12)" > $O/gemm_tests.log 2>&1; tail -n 6 $O/gemm_tests.log
+  for V in 3 11 12 3 11 12; do timeout 120 python tools/bench_gemm_diag.py $V 2>/dev/null | grep '^{' | tee -a $O/gemm_pp_bench.txt; done ;;
+mid)         # weight-streaming GEMV for 17-64 rows: kernel tests, then the 32-stream bench with the new and the round-3 routing
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "17_to_64" > $O/mid_tests.log 2>&1; tail -n 6 $O/mid_tests.log
+  timeout 600 python -m pytest tests/test_gpu_facade.py -m gpu -q --timeout 500 -k "20_streams or batch" > $O/facade.log 2>&1; tail -n 4 $O/facade.log
+  ( timeout 500 $B --steps 1 --warmup 1 --streams-per-gpu 32 --share8 off ) > $O/bench_32s_mid.log 2>&1; tail -n 1 $O/bench_32s_mid.log | cut -c1-1600 ;;
+ab)          # A/B of an environment switch on the multi-stream bench: bash tools/gpu_call.sh ab <streams> VAR=a VAR=b ...
+  N=$1; shift
+  for KV in "$@"; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu $N --share8 off ) > $O/bench_${N}s_$KV.log 2>&1; echo "== $N streams $KV: $(val $O/bench_${N}s_$KV.log value) tok/s, $(val $O/bench_${N}s_$KV.log frames_per_s) frames/s"; tail -n 2 $O/bench_${N}s_$KV.log | grep -v '^{' | cut -c1-300; done ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
