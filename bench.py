@@ -759,11 +759,14 @@ def main():
         "metric": f"commentary tokens/s (all streams) + frames/s ingested, {'LiveCC-7B' if cfg.name == 'livecc-7b' else cfg.name} streaming", "value": round(total_tokens / dt, 3),
         "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (fp8 e4m3 LLM weights, bf16 MFMA)" if fp8 else "bf16",
+        "dtype": "bf16 (LLM Linear weights stored as fp8 e4m3 + fp32 row scales and expanded to bf16 in registers: every MFMA instruction is a bf16 one, "
+                 "activations are never quantised)" if fp8 else "bf16",
         "data": "standin (launcher self-test, no GPU work)" if args.standin else "synthetic frames + synthetic prompt ids, seeded synthetic weights of the real architecture",
         "config": {"workload": f"{cfg.name} {spg} stream(s) per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
                                f"{args.max_new_tokens} tokens/{'call' if oneshot else 'turn'}, greedy, repetition_penalty 1.05" + tag,
-                   "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)"},
+                   "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)",
+                   "mfma": "bf16 x bf16 -> fp32" + (" (fp8 weights expanded in registers; no fp8 MFMA instruction is issued: on gfx950 only the MX block-scaled "
+                                                    "forms run faster than bf16 and they need activation scales the reference arithmetic does not have)" if fp8 else "")},
         "tokens_per_s_per_stream": round(total_tokens / dt / n_streams, 3), "frames_per_s": round(total_frames / dt, 3),
         "weight_broadcast_s": round(bcast_max, 3), "rccl_ranks": world, "launcher": "self" if os.environ.get("LCC_BENCH_SELF_LAUNCHED") else ("torchrun" if world > 1 else "single"),
         "tokens_per_s_per_rank": [round(x, 2) for x in per_rank],

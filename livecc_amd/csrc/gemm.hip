@@ -1154,16 +1154,28 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
   constexpr int NW = 4;
   static_assert(MODE != 3 || MG == 1, "the fused tail serves M <= 2");
   __shared__ f32x4 red[NW - 1][NTILE * MG][64];
+  // MG > 1: the activation rows of a 64-k chunk are fetched in FULL 128-byte lines (one load instruction = 8 rows x 128 B; the
+  // fragment-shaped load -- 16 rows x 64 B per instruction -- was 2.3x slower at M = 32: 99 vs 43 us for the gate/up GEMV,
+  // profiles/r04/bench_32streams_mg_gemv_first_version.json) and turned into MFMA fragments through a wave-private LDS scratch with the
+  // (chunk ^ row & 7) swizzle of gemm_big_kernel's activation image: ds_write_b128 of the raw lines, ds_read_b128 of the fragments.
+  __shared__ u32x4 xs_all[MG > 1 ? NW * MG * 128 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (NTILE * 16);
   const int split = blockIdx.y;
   const int nchunk = (K + 63) >> 6, K32 = (K + 31) >> 5;
   const int cb = split * chunks_per_split, ce = min(nchunk, cb + chunks_per_split);
 
-  const bf16_t* xp[MG];
+  // MG == 1: xp[0] = this lane's fragment slice (row li, 8 k of lane group g).  MG > 1: xp[i], i < 2 MG = line piece of instruction i:
+  // row i*8 + (lane >> 3), 16-byte piece lane & 7 of the row's 128-byte chunk line (slots [h][mg] of the stage arrays hold i = h*MG + mg)
+  const bf16_t* xp[MG > 1 ? 2 * MG : 1];
+  if (MG == 1) {
+    xp[0] = X + (size_t)min(li, M - 1) * ldx + g * 8;
+  } else {
 #pragma unroll
-  for (int mg = 0; mg < MG; ++mg) xp[mg] = X + (size_t)min(mg * 16 + li, M - 1) * ldx + g * 8;
-  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_g) + g * 8;
+    for (int i = 0; i < 2 * MG; ++i) xp[i] = X + (size_t)min(i * 8 + (lane >> 3), M - 1) * ldx + (lane & 7) * 8;
+  }
+  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_zero_page_g) + (MG == 1 ? g * 8 : (lane & 7) * 8);
+  u32x4* xs = xs_all + (MG > 1 ? wave * MG * 128 : 0);
   const bf16_t* wp[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t)
@@ -1190,20 +1202,43 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 #pragma unroll
         for (int t = 0; t < NTILE; ++t)
           wv[u][h][t] = __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)kbc * (PACKED ? 512 : 32)));
+        if (MG == 1) {
+          xv[u][h][0] = ld16(ok ? xp[0] + kbc * 32 : zp);
+        } else {       // full lines of the 64-k chunk (both k-blocks): instruction i = h*MG + mg; a chunk whose second k-block is past K reads the
+                       // zero page for the whole chunk only when the chunk itself is absent (K % 64 == 32 never occurs with MG > 1: checked by the launcher)
 #pragma unroll
-        for (int mg = 0; mg < MG; ++mg) xv[u][h][mg] = ld16(ok ? xp[mg] + kbc * 32 : zp);
+          for (int mg = 0; mg < MG; ++mg) xv[u][h][mg] = ld16((cc < ce) ? xp[h * MG + mg] + min(cc, nchunk - 1) * 64 : zp);
+        }
       }
     }
   };
   auto mma_stage = [&](const u32x4 (&wv)[UNR][2][NTILE], const u32x4 (&xv)[UNR][2][MG]) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u)
+    for (int u = 0; u < UNR; ++u) {
+      u32x4 xf[2][MG];
+      if (MG == 1) {
+        xf[0][0] = xv[u][0][0];
+        xf[1][0] = xv[u][1][0];
+      } else {
+        // raw lines -> wave-private LDS image [row][8 x 16 B], chunk c of row r at r*8 + (c ^ (r & 7)) -> fragments (row mg*16 + li,
+        // k-block h, lane group g).  One wave, in-order LDS: no barrier.
+#pragma unroll
+        for (int i = 0; i < 2 * MG; ++i) {
+          const int row = i * 8 + (lane >> 3);
+          xs[row * 8 + ((lane & 7) ^ (row & 7))] = xv[u][i / MG][i % MG];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int mg = 0; mg < MG; ++mg) xf[h][mg] = xs[(mg * 16 + li) * 8 + ((h * 4 + g) ^ (li & 7))];
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int t = 0; t < NTILE; ++t)
 #pragma unroll
-          for (int mg = 0; mg < MG; ++mg) acc[t][mg] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xv[u][h][mg]), acc[t][mg]);
+          for (int mg = 0; mg < MG; ++mg) acc[t][mg] = mfma16(as_bf16x8(wv[u][h][t]), as_bf16x8(xf[h][mg]), acc[t][mg]);
+    }
   };
   constexpr int STEP = UNR * NW;  // chunk stride of one stage
   if (PIPE == 0) {
@@ -1599,7 +1634,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   // weight-streaming path: up to g_skinny_rows rows (64: decode batches of 17-64 streams multiply every weight fragment with 2-4 activation
   // fragments; lcc_debug_set_skinny_rows(16) restores the round-3 routing of 17-64 rows through the 64-row GEMM tiles)
   // (a forced GEMM tile variant -- tests, A/B runs -- keeps 17-64 rows on the tiles it asks for)
-  const bool skinny = a.M <= (g_gemm_variant == 2 ? g_skinny_rows : 16) && (a.K % 32 == 0) && a.epilogue != EPI_QUICK_GELU &&
+  const bool skinny = a.M <= (g_gemm_variant == 2 ? g_skinny_rows : 16) && (a.K % 32 == 0) && (a.M <= 16 || a.K % 64 == 0) && a.epilogue != EPI_QUICK_GELU &&
                       a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
   if (skinny) {
     const int nchunk = (a.K + 63) / 64;

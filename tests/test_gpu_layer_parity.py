@@ -148,16 +148,15 @@ def test_qwen2vl_72b_shaped_layer_with_fp8_weights_matches_hf_on_the_dequantised
     scales -- the single-GPU 72B weight path -- behind one vision block.  Oracles: HF on the SAME quantised values (`fake_quantize_llm_fp8`):
     fp32 = exact q x scale (the truth), bf16 = what the reference's dtype makes of the dequantised checkpoint.  (i) layer by layer on the
     bf16 oracle's inputs: rms(native - fp32) <= 1.25 x rms(HF_bf16 - fp32) after the attention block, after the MLP and for final norm +
-    lm_head (the fp8 prefill GEMMs: MFMA kernels on fp8 fragments converted after the LDS read); (ii) a 2-frame turn + 4 decode steps,
-    teacher-forced in HF along the native tokens (the fp8 decode GEMVs of pipeline v2): worst |dlogit| <= 6e-2 x scale, error against fp32
-    <= 1.5 x the bf16 oracle's."""
+    lm_head (the fp8 prefill GEMMs: MFMA kernels on fp8 fragments converted after the LDS read); (ii) the 6-frame + 2-frame turns with 5
+    tokens each, native and HF fp32 teacher-forced along HF bf16's own tokens (the fp8 decode GEMVs of pipeline v2): on every step the error
+    against fp32 <= 1.5 x the bf16 oracle's (worst logit) and <= 1.25 x in rms."""
     import copy
     import dataclasses
     from livecc_amd import protocol
     from livecc_amd.config import get_config
     from livecc_amd.modeling import LiveCCForConditionalGeneration
     from oracle import hf_oracle as O, layer_probe as P
-    from tests.test_gpu_e2e import _compare_stream, _replay_native
     cfg = dataclasses.replace(get_config("qwen2vl-72b"), num_hidden_layers=1, vit_depth=1, name="qwen2vl-72b-1layer")
     hf32 = O.build_hf_model_synthetic(cfg, torch.float32, "tiled:0")
     O.fake_quantize_llm_fp8(hf32)
@@ -174,7 +173,33 @@ def test_qwen2vl_72b_shaped_layer_with_fp8_weights_matches_hf_on_the_dequantised
     nat = native_probe(native, cfg, ids, frames.to(dev), a16)
     summary = _compare("per_layer_parity[qwen2vl-72b-1layer-fp8]", nat, a16, t32, cfg, ids)
     print("72B-shaped fp8 layer:", summary)
-    # (ii) decode path: a 2-frame turn + 4 generated tokens on the carried cache of a 6-frame turn
+    # (ii) the streaming replay: 6-frame turn + 2-frame turn over the carried cache, 5 tokens each (4 decode steps per turn: the fp8 decode
+    # GEMVs of pipeline v2).  HF bf16 runs free; HF fp32 and the native engine follow its tokens.  At this synthetic one-layer configuration
+    # the reference's OWN bf16 run is 10-14 % of the logit scale away from the fp32 truth in the second turn (bf16 cos / sin at positions
+    # > 1,100 with nothing to average over: measured with HF alone, tools/diag_72b.py + profiles/r04/diag_72b_call4.jsonl) -- an absolute
+    # bound against the bf16 oracle would test HF's noise, so the bound is the one of DESIGN section 5: the native error against the fp32
+    # truth <= 1.5 x the bf16 reference's own (worst logit) and <= 1.25 x in rms over the vocabulary, on every step.
     frames2 = torch.from_numpy(protocol.synth_frames(8, H, W, seed=77, layout="TCHW"))
-    turns = _replay_native(native, cfg, frames2, protocol.TurnBuilder(cfg, seed=77), max_new_tokens=5, repetition_penalty=1.05, max_turns=2)
-    _compare_stream(cfg, hf16, hf32, turns, frames2, "stream_72b_1layer_fp8", 1.05, min_exact_frac=0.0, strict_rate=None)
+    res16 = O.replay_stream(hf16, cfg, frames2, protocol.TurnBuilder(cfg, seed=77), 5, 1.05, max_turns=2)
+    s32 = O.OracleStream(hf32, cfg)
+    state, past, worst = None, None, dict(max_ratio=0.0, rms_ratio=0.0, rel_err_ref16=0.0, rel_err_native=0.0)
+    for ti, (r, (a, b)) in enumerate(zip(res16, protocol.split_clip(8))):
+        pv2, g2 = O.patchify_normalize_ref(frames2[a:b], cfg)
+        r32 = s32.turn(r["turn_ids"], pv2, g2, max_new_tokens=5, repetition_penalty=1.05, teacher_tokens=r["new_tokens"])
+        full = np.asarray(r["turn_ids"]) if past is None else np.concatenate([past, np.asarray(r["turn_ids"])])
+        rn = native.generate(input_ids=torch.from_numpy(full).view(1, -1), frames=frames2[a:b], past_key_values=state, repetition_penalty=1.05,
+                             max_new_tokens=5, min_new_tokens=5, output_logits=True, do_sample=False, teacher_tokens=r["new_tokens"])
+        state = rn.past_key_values
+        past = np.concatenate([full, np.asarray(r["new_tokens"][:-1], dtype=np.int64)])
+        for k in range(5):
+            ln, l16, l32 = rn.logits[k].float().cpu().double(), r["logits"][k].double(), r32["logits"][k].double()
+            scale = float(l32.abs().max())
+            en, eo = float((ln - l32).abs().max()), float((l16 - l32).abs().max())
+            rr = float((ln - l32).pow(2).mean().sqrt() / (l16 - l32).pow(2).mean().sqrt())
+            worst = dict(max_ratio=max(worst["max_ratio"], en / (eo + 1e-3 * scale)), rms_ratio=max(worst["rms_ratio"], rr),
+                         rel_err_ref16=max(worst["rel_err_ref16"], eo / scale), rel_err_native=max(worst["rel_err_native"], en / scale))
+            assert en <= 1.5 * eo + (1e-3 + 2.0 ** -7) * scale, f"turn {ti} step {k}: native error vs fp32 {en:.4g} > 1.5 x the bf16 reference's {eo:.4g}"
+            assert rr <= 1.25, f"turn {ti} step {k}: rms error ratio {rr:.3f}"
+    state.release()
+    record("stream_72b_1layer_fp8", worst)
+    print("72B-shaped fp8 stream:", worst)

@@ -30,6 +30,8 @@ mid)         # weight-streaming GEMV for 17-64 rows: kernel tests, then the 32-s
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "17_to_64" > $O/mid_tests.log 2>&1; tail -n 6 $O/mid_tests.log
   timeout 600 python -m pytest tests/test_gpu_facade.py -m gpu -q --timeout 500 -k "20_streams or batch" > $O/facade.log 2>&1; tail -n 4 $O/facade.log
   ( timeout 500 $B --steps 1 --warmup 1 --streams-per-gpu 32 --share8 off ) > $O/bench_32s_mid.log 2>&1; tail -n 1 $O/bench_32s_mid.log | cut -c1-1600 ;;
+b72)         # BASELINE.json configs[4]: Qwen2-VL-72B shapes, fp8 weights, the configs[1] protocol (60 frames), one stream on one GPU
+  ( timeout 900 $B --config qwen2vl-72b --weights fp8 --steps 1 --warmup 1 --share8 off ) > $O/bench_72b_fp8.log 2>$O/bench_72b_fp8.err; tail -n 1 $O/bench_72b_fp8.log | cut -c1-2200; tail -n 3 $O/bench_72b_fp8.err ;;
 ab)          # A/B of an environment switch on the multi-stream bench: bash tools/gpu_call.sh ab <streams> VAR=a VAR=b ...
   N=$1; shift
   for KV in "$@"; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu $N --share8 off ) > $O/bench_${N}s_$KV.log 2>&1; echo "== $N streams $KV: $(val $O/bench_${N}s_$KV.log value) tok/s, $(val $O/bench_${N}s_$KV.log frames_per_s) frames/s"; tail -n 2 $O/bench_${N}s_$KV.log | grep -v '^{' | cut -c1-300; done ;;
