@@ -1252,10 +1252,18 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
     int c = cb + wave;
     load_stage(c, wa, xa);
     for (; c < ce; c += 2 * STEP) {
+      // MG > 1: the issue order is PINNED (all loads of the next stage, then the whole current stage).  Left to itself hipcc sinks the next
+      // stage's activation loads behind this stage's MFMAs and waits for them a few instructions later (vmcnt retires in order: the weight
+      // loads issued before them are waited for too) -- the two-stage pipeline collapsed and the M = 32 gate/up GEMV ran at 2.8 TB/s
+      // (98.8 us, profiles/r04/bench_32streams_mg_gemv_*.json)
       load_stage(c + STEP, wb, xb);
+      if (MG > 1) __builtin_amdgcn_sched_barrier(0);
       mma_stage(wa, xa);
+      if (MG > 1) __builtin_amdgcn_sched_barrier(0);
       load_stage(c + 2 * STEP, wa, xa);
+      if (MG > 1) __builtin_amdgcn_sched_barrier(0);
       mma_stage(wb, xb);
+      if (MG > 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
 
