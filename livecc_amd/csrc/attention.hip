@@ -556,15 +556,12 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
     const bf16_t* __restrict__ q, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
     bf16_t* const* __restrict__ kv_base,
     KvLayout lay, int layer, int n_q_heads, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml,
-    float scale_log2e, DecodeDirect dd) {
+    float scale_log2e) {
   constexpr int D = 128, KS = 4, NQ = 1;
   const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int G = n_q_heads / lay.n_kv_heads;
-  // dd.n > 0 (the engine's 1-2 stream decode): slot id and KV arena pointer come with the kernel arguments, so the chain in front of the
-  // first K / V load is ONE scalar load (the device-resident length) instead of slots[b] -> kv_len[slot] | kv_base[slot]
-  const int slot_id = dd.n > 0 ? dd.slot[b] : slots[b];
-  const bf16_t* arena = dd.n > 0 ? dd.base[b] : kv_base[slot_id];
+  const int slot_id = slots[b];
   const int n = kv_len[slot_id] + 1;  // the new token's K/V were appended at index kv_len[slot] by rope_kv_append
   const int ntile = (n + 31) / 32;
   const int per = (ntile + nsplit - 1) / nsplit;
@@ -578,7 +575,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[0][ks] = ld16(qp + ks * 32 + g * 8);
   }
-  const bf16_t* base = arena + (size_t)layer * lay.layer_stride();
+  const bf16_t* base = kv_base[slot_id] + (size_t)layer * lay.layer_stride();
   const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
   const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
   auto krow = [&](int key) { return kbase + (size_t)min(key, n - 1) * D; };
@@ -993,15 +990,12 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
 }
 
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
-                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st,
-                     const DecodeDirect* direct) {
+                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st) {
   if (B <= 0) return 0;
   if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
-  DecodeDirect dd{};
-  if (direct != nullptr && direct->n >= B && B <= DecodeDirect::MAX) dd = *direct;
   g_launch_counts[LC_ATTN_DECODE]++; g_launch_counts[LC_ATTN_DECODE_COMBINE]++; g_launch_counts[LC_LAST_DECODE_NSPLIT] = nsplit;
   attn_decode_kernel<<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
-      q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128), dd);
+      q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128));
   attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(256), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
                                                                        lay.n_kv_heads, nsplit);
   return 0;

@@ -124,16 +124,8 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
                       const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
                       int layer, int n_tiles, int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o, float* ws_ml,
                       hipStream_t st);
-// slot ids + KV arena pointers of a small decode batch handed over WITH the kernel arguments (host-known), see attn_decode_kernel
-struct DecodeDirect {
-  static constexpr int MAX = 2;
-  int n = 0;
-  int slot[MAX] = {0, 0};
-  const bf16_t* base[MAX] = {nullptr, nullptr};
-};
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
-                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st,
-                     const DecodeDirect* direct = nullptr);
+                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
 void set_attn_fused_tail(int v);
 // fused decode attention: bias + M-RoPE + KV append + attention + split merge in one launch (reads the qkv GEMV's fp32 slabs)
 int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias, const bf16_t* cs, const bf16_t* sn,
