@@ -30,6 +30,38 @@ mid)         # weight-streaming GEMV for 17-64 rows: kernel tests, then the 32-s
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "17_to_64" > $O/mid_tests.log 2>&1; tail -n 6 $O/mid_tests.log
   timeout 600 python -m pytest tests/test_gpu_facade.py -m gpu -q --timeout 500 -k "20_streams or batch" > $O/facade.log 2>&1; tail -n 4 $O/facade.log
   ( timeout 500 $B --steps 1 --warmup 1 --streams-per-gpu 32 --share8 off ) > $O/bench_32s_mid.log 2>&1; tail -n 1 $O/bench_32s_mid.log | cut -c1-1600 ;;
+trace)       # kernel-trace breakdown of a multi-stream replay: bash tools/gpu_call.sh trace <streams>
+  N=${1:-8}; cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t$N -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-prefetch --streams-per-gpu $N --cpu-baseline off --parity off --share8 off > $O/bench_${N}s_under_rocprof.json 2> $O/trace_$N.err
+  T=$(find $O/t$N -name '*kernel_trace.csv' | head -1); python $R/tools/trace_breakdown.py $T 28 > $O/step_breakdown_${N}streams_noprefetch.json 2>> $O/trace_$N.err; rm -rf $O/t$N
+  python - <<PY
+import json
+d = json.load(open("$O/step_breakdown_${N}streams_noprefetch.json"))
+print("decode step", d["avg_step_us"], "us; kernels", d["avg_kernel_time_per_step_us"], "gaps", d["avg_gap_per_step_us"])
+for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["us_per_step"])[:12]:
+    print("  %-56s calls %5.1f avg %7.2f us  per step %8.1f" % (k[:56], v["calls_per_step"], v["avg_us"], v["us_per_step"]))
+PY
+  cd $R ;;
+pmc_gemv)    # counters of the weight-streaming gate/up GEMV at M = 8 / 32 / 64 (one pass per group)
+  cd /tmp; i=0
+  for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_sum" "FETCH_SIZE"; do
+    i=$((i+1)); timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p$i -o gemv -- python $R/tools/pmc_target.py --gemv-rows > $O/p$i.log 2>&1 || echo "pass $i ($C) failed: $(tail -n 1 $O/p$i.log)"
+    find $O/p$i -name '*kernel_trace.csv' -delete
+  done
+  python - <<PY > $O/gemv_rows_counters.json
+import csv, glob, json, collections
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r.get("Kernel_Name", "")
+        if "gemv_skinny_kernel" in kn:
+            key = kn.split("(")[0].replace("void lcc::", "")[:60]
+            res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res[key]["duration_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+print(json.dumps({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}, indent=1))
+PY
+  cat $O/gemv_rows_counters.json; rm -rf $O/p*/; cd $R ;;
 b72)         # BASELINE.json configs[4]: Qwen2-VL-72B shapes, fp8 weights, the configs[1] protocol (60 frames), one stream on one GPU
   ( timeout 900 $B --config qwen2vl-72b --weights fp8 --steps 1 --warmup 1 --share8 off ) > $O/bench_72b_fp8.log 2>$O/bench_72b_fp8.err; tail -n 1 $O/bench_72b_fp8.log | cut -c1-2200; tail -n 3 $O/bench_72b_fp8.err ;;
 ab)          # A/B of an environment switch on the multi-stream bench: bash tools/gpu_call.sh ab <streams> VAR=a VAR=b ...

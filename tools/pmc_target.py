@@ -34,6 +34,17 @@ if "--gemm" in sys.argv:
     torch.cuda.synchronize()
     print("ok")
     sys.exit(0)
+if "--gemv-rows" in sys.argv:
+    # the weight-streaming gate/up GEMV (+ SwiGLU) at M = 8 (one activation fragment per weight fragment) and M = 32 / 64 (MG = 2 / 4):
+    # what makes the multi-fragment kernel slower per byte (tools/gpu_call.sh pmc_gemv)
+    ws = [ops.pack_weight((torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(3)]
+    for M in (8, 32, 64):
+        x = torch.randn(M, H, device=dev).to(torch.bfloat16)
+        for i in range(9):
+            ops.linear(x, ws[i % 3], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
+    torch.cuda.synchronize()
+    print("ok")
+    sys.exit(0)
 ws = [(torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
 x = torch.randn(1, H, device=dev).to(torch.bfloat16)
 nw = torch.ones(H, device=dev, dtype=torch.bfloat16)
