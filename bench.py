@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--attn-variant", type=int, default=None, help="debug A/B: lcc_debug_set_attn_variant")
     ap.add_argument("--gemm-variant", type=int, default=None, help="debug A/B: lcc_debug_set_gemm_variant")
     ap.add_argument("--decode-path", type=int, default=None, help="debug A/B: lcc_debug_set_decode_path")
+    ap.add_argument("--skinny-rows", type=int, default=None, help="debug A/B: lcc_debug_set_skinny_rows (16 = round-3 routing of 17-64 decode "
+                                                                  "streams through the 64-row GEMM tiles; default 64 = weight-streaming GEMVs)")
     ap.add_argument("--decode-chain", type=int, default=None, choices=[0, 1], help="debug A/B: lcc_debug_set_decode_chain")
     ap.add_argument("--fused-attn", type=int, default=None, help="debug A/B: lcc_debug_set_fused_attn (bit 0 fused decode attention for "
                                                                   ">= 16 (stream, KV head) pairs, bit 2 always, bit 1 in-launch split merge)")
@@ -257,6 +259,22 @@ def decode_step_roofline(cfg, engine, spg, kv_list, fp8):
     return out
 
 
+def standalone_decode_steps(cfg, model, frames, seeds, args, protocol, spg, kv_list, fp8):
+    """Decode steps WITHOUT a vision tower sharing the GPU: one extra replay with the prefetch off (outside every timed region), whole
+    steps sampled by the engine as usual.  The `late_steps_without_vision_tower_overlap` heuristic (step index >= 8) holds only while the
+    prefetched tower is shorter than eight decode steps -- true for 1-8 streams, false for 32, where the tower outlasts the whole decode
+    phase (profiles/r04/step_breakdown_32streams_noprefetch.json: 6.06 ms standalone vs 9.8 ms "late" under the overlap)."""
+    model.engine.profile(True, 16384)
+    replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, False)
+    torch.cuda.synchronize()
+    model.engine.profile(False)
+    r = decode_step_roofline(cfg, model.engine, spg, kv_list, fp8)
+    if r is None:
+        return None
+    r.pop("late_steps_without_vision_tower_overlap", None)
+    return dict(avg_step_us=r["avg_step_us"], frac=r["frac"], achieved=r["achieved"], us_per_layer=r["us_per_layer"], steps_timed=r["steps_timed"])
+
+
 def configs2_share(cfg, arena, dev, args, protocol, streams=8, steps=2):
     """ONE GPU's share of BASELINE.json configs[2] (64 streams data-parallel over 8 GPUs = 8 co-scheduled streams per GPU) in the driver's
     own --gpus 1 run: the same 60-frame replay with 8 streams batched turn by turn (batched vision tower, packed
@@ -287,6 +305,8 @@ def configs2_share(cfg, arena, dev, args, protocol, streams=8, steps=2):
     model.engine.profile(False)
     kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
     step_roof = decode_step_roofline(cfg, model.engine, streams, kv_list, False)
+    if step_roof is not None:
+        step_roof["standalone_replay_without_prefetch"] = standalone_decode_steps(cfg, model, frames, seeds, args, protocol, streams, kv_list, False)
     # MFMA-bound phases alone: every turn's vision tower + prefill, one token per turn (no decode steps), no prefetch overlap
     replay(model, cfg, frames, seeds, 1, protocol, torch, False)
     sync()
@@ -572,6 +592,8 @@ def main():
             _lib.load().lcc_debug_set_fused_attn(args.fused_attn)
         if args.decode_path is not None:
             _lib.check(_lib.load().lcc_debug_set_decode_path(args.decode_path), "lcc_debug_set_decode_path")
+        if args.skinny_rows is not None:
+            ops.set_skinny_rows(args.skinny_rows)
         if args.workload == "oneshot480":
             kv_total = (args.frames // 2) * n_tok_turn + 128 + args.max_new_tokens
             model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=32 * ((kv_total + 31) // 32) + 64,
@@ -664,6 +686,8 @@ def main():
             kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
         step_roof = decode_step_roofline(cfg, model.engine, spg, kv_list, fp8)
         if step_roof is not None and roof is not None:
+            if not oneshot and not args.no_prefetch:
+                step_roof["standalone_replay_without_prefetch"] = standalone_decode_steps(cfg, model, frames, seeds, args, protocol, spg, kv_list, fp8)
             roof["decode_step"] = step_roof
         if oneshot:
             # the one-shot call is MFMA-bound up to its first token: the vision tower over every slice + the long prefill.  Timed live

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
     float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale) {
-  constexpr int BN = 256, BK = 64, NSTAGE = (BM == 256 && !W8) ? 2 : 3;
+  constexpr int BN = 256, BK = 64, NSTAGE = (BM >= 192 && !W8) ? 2 : 3;     // BM 192 (round 4): 56-KB stages, two of them
   constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
   constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
   constexpr int B_SUB = (BN / 16) * (W8 ? 1 : 2); // 1-KB fragment sub-tiles of the W tile
@@ -987,7 +987,7 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
   // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages
-  constexpr size_t lds = (size_t)((BM == 256 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16;
+  constexpr size_t lds = (size_t)((BM >= 192 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16;
   static DeviceOnce attr_set;   // per instantiation
   if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1029,12 +1029,13 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
   // bit-identical to the burst-behind-the-barrier order SCHED 1 -- tools/gemm_checksum.py -- and 1.6-3.3 % faster on the prefill
   // GEMMs, +0.6 / +0.8 % tokens/s at 1 / 8 streams, profiles/r03/gemm_sched_spread_dma.txt); LCC_GEMM_SCHED=1 restores SCHED 1
   static const int spread = [] { const char* v = getenv("LCC_GEMM_SCHED"); return (v && atoi(v) == 1) ? 0 : 1; }();
-  if (a.w_fp8) launch_big_s<BM, EPI, 1, true>(a, st);
+  if (a.w_fp8) launch_big_s<(BM == 192 ? 256 : BM), EPI, 1, true>(a, st);     // the 192-row tile is a bf16-weight shape (big_tile_rows never picks it for fp8)
   else if (g_gemm_sched && spread) launch_big_s<BM, EPI, 6, false>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
 }
-// variants 10 / 11 / 12: the 256-row 8-wave tile wherever eligible (like 3), served by gemm_big_kernel / gemm_pp_kernel / gemm_pp + setprio
+// variants 10 / 11 / 12: the 256-row 8-wave tile wherever eligible (like 3), served by gemm_big_kernel / gemm_pp_kernel / gemm_pp + setprio;
+// 13: the 192-row tile wherever eligible (bf16 weights)
 void set_gemm_variant(int v) {
   if (g_gemm_pp_default < 0) g_gemm_pp_default = g_gemm_pp;
   if (v >= 10 && v <= 12) { g_gemm_pp = v - 10; v = 3; }
@@ -1057,15 +1058,22 @@ static float tile_score(int M, int N, int S, int BM, int BN, int slots, float ef
   const float quant = (float)blocks / (float)((blocks + slots - 1) / slots * slots);
   return util * quant * eff;
 }
+// BM 192 (round 4, bf16 weights): a 256-row tile leaves the chip partly idle whenever (M / 256) x (N / 256) falls just short of a round --
+// the o / down projections of 8 co-scheduled chunks are M = 3088 x N = 3584 = 13 x 14 = 182 blocks on 256 CUs (29 % idle); 17 x 14 = 238
+// blocks of 192 rows fill 93 % of one round at 3/4 of the tile time.  The tile moves 17 % more L2 -> LDS bytes per flop (efficiency 0.93).
 static int big_tile_rows(const GemmArgs& a, int S) {
   if (!big_eligible(a)) return 0;
   if (g_gemm_variant == 3 || g_gemm_variant == 5) return 256;
   if (g_gemm_variant == 4 || g_gemm_variant == 6) return 128;
+  if (g_gemm_variant == 13) return a.w_fp8 ? 256 : 192;
   if (g_gemm_variant != 2) return 0;
   const float s256 = tile_score(a.M, a.N, S, 256, 256, 256, 1.0f, true);
+  static const int allow192 = [] { const char* v = getenv("LCC_GEMM_192"); return v ? atoi(v) : 1; }();     // A/B: 0 = round-3 tile choice
+  const float s192 = (a.w_fp8 || !allow192) ? 0.f : tile_score(a.M, a.N, S, 192, 256, 256, 0.93f, true);
   const float s128 = tile_score(a.M, a.N, S, 128, 256, 256, 0.85f, true);
   const float s64 = tile_score(a.M, a.N, S, 64, 128, 512, 0.55f, false);
-  if (s256 >= s128 && s256 >= s64) return 256;
+  if (s256 >= s192 && s256 >= s128 && s256 >= s64) return 256;
+  if (s192 >= s128 && s192 >= s64) return 192;
   if (s128 >= s64) return 128;
   return 0;
 }
@@ -1119,6 +1127,7 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
   }
   const int big = big_tile_rows(a, 1);
   if (big == 256) return launch_big<256, EPI>(a, st);
+  if (big == 192) return launch_big<192, EPI>(a, st);
   if (big == 128) return launch_big<128, EPI>(a, st);
   // 128-row tiles only for large M with a grid that fills the chip; otherwise 64-row tiles (less waste on a ragged M such as
   // 386 rows, more blocks, and the faster LDS-DMA kernel)
@@ -1668,6 +1677,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
     if (a.epilogue != EPI_NONE || a.nsplit < 1 || a.nsplit > 8 || a.nsplit > (a.K + 63) / 64) return LCC_ERR_ARG;
     const int big = big_tile_rows(a, a.nsplit);
     if (big == 256) launch_big<256, EPI_PARTIAL>(a, st);
+    else if (big == 192) launch_big<192, EPI_PARTIAL>(a, st);
     else if (big == 128) launch_big<128, EPI_PARTIAL>(a, st);
     else launch_tiled<64, EPI_PARTIAL>(a, st);
     return 0;

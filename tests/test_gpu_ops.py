@@ -69,11 +69,11 @@ def _layout_variants(variants):
 @pytest.mark.parametrize("M,N,K", [(200, 512, 256), (386, 1280, 1176), (130, 480, 160), (64, 1024, 640), (1456, 3840, 1280),
                                    (17, 256, 512), (300, 4608, 3584), (260, 272, 192), (100, 256, 64), (600, 768, 512)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 2, 3, 4, 5, 6, 11, 12]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 2, 3, 4, 5, 6, 11, 12, 13]))
 def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
     """variant 0: register-staged 2-stage kernel; 1: LDS-DMA (global_load_lds) 3-stage ring; 2: auto (default);
     3 / 4: the 8-wave 256x256 / 128x256 LDS-DMA kernel wherever it is eligible (packed W, K % 64 == 0), pinned fragment-read
-    schedule; 5 / 6: the same with the compiler's schedule; 11 / 12: the 256x256 tile as gemm_pp_kernel (ping-pong wave groups; 12 with
+    schedule; 5 / 6: the same with the compiler's schedule; 13: the 192x256 tile (round 4); 11 / 12: the 256x256 tile as gemm_pp_kernel (ping-pong wave groups; 12 with
     s_setprio around the MFMA clusters)."""
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
@@ -88,7 +88,7 @@ def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
 
 
 @pytest.mark.parametrize("M,I,K", [(100, 512, 256), (386, 2432, 896), (530, 400, 128)])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 6, 11, 12]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 6, 11, 12, 13]))
 def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
     from livecc_amd import ops
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
@@ -292,7 +292,7 @@ def test_gemv_17_to_64_rows_swiglu(dev, M, I, K):
 
 
 @pytest.mark.parametrize("M,N,K,S", [(100, 512, 1024, 2), (386, 3584, 3584, 4), (70, 256, 640, 3)])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 5, 11]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 5, 11, 13]))
 def test_gemm_tiled_splitk_slabs(dev, M, N, K, S, packed, variant):
     """prefill split-K: fp32 slabs [S][M][N] whose sum is the product (reduced by add_rmsnorm in the engine)."""
     from livecc_amd import ops

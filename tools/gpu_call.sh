@@ -26,14 +26,20 @@ pp)          # gemm_pp_kernel (ping-pong wave groups) vs gemm_big_kernel<256>: b
   for V in 3 11 11 11 12; do timeout 200 python tools/gemm_checksum.py $V > $O/sum_v$V.txt 2>$O/sum_v$V.err; cmp $O/sum_v3.txt $O/sum_v$V.txt && echo "variant $V: CHECKSUMS IDENTICAL to variant 3" || { echo "variant $V DIFFERS"; paste $O/sum_v3.txt $O/sum_v$V.txt; tail -n 3 $O/sum_v$V.err; }; done
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "gemm_tiled and (11 or 12)" > $O/gemm_tests.log 2>&1; tail -n 6 $O/gemm_tests.log
   for V in 3 11 12 3 11 12; do timeout 120 python tools/bench_gemm_diag.py $V 2>/dev/null | grep '^{' | tee -a $O/gemm_pp_bench.txt; done ;;
+t192)        # the 192-row tile of the 8-wave GEMM: bit-identity with the 256-row tile, kernel tests, micro-benchmark (gate/up + down_proj)
+  for V in 3 13; do timeout 200 python tools/gemm_checksum.py $V > $O/sum_v$V.txt 2>$O/sum_v$V.err; done
+  cmp $O/sum_v3.txt $O/sum_v13.txt && echo "variant 13: CHECKSUMS IDENTICAL to variant 3" || { echo "variant 13 DIFFERS"; paste $O/sum_v3.txt $O/sum_v13.txt; tail -n 3 $O/sum_v13.err; }
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "gemm_tiled and 13" > $O/gemm_tests.log 2>&1; tail -n 4 $O/gemm_tests.log
+  for V in 3 13 2; do timeout 120 python tools/bench_gemm_diag.py $V down 2>/dev/null | grep '^{' | tee -a $O/gemm_192_bench.txt; timeout 120 python tools/bench_gemm_diag.py $V 2>/dev/null | grep '^{' | tee -a $O/gemm_192_bench.txt; done ;;
 mid)         # weight-streaming GEMV for 17-64 rows: kernel tests, then the 32-stream bench with the new and the round-3 routing
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "17_to_64" > $O/mid_tests.log 2>&1; tail -n 6 $O/mid_tests.log
   timeout 600 python -m pytest tests/test_gpu_facade.py -m gpu -q --timeout 500 -k "20_streams or batch" > $O/facade.log 2>&1; tail -n 4 $O/facade.log
   ( timeout 500 $B --steps 1 --warmup 1 --streams-per-gpu 32 --share8 off ) > $O/bench_32s_mid.log 2>&1; tail -n 1 $O/bench_32s_mid.log | cut -c1-1600 ;;
 trace)       # kernel-trace breakdown of a multi-stream replay: bash tools/gpu_call.sh trace <streams>
-  N=${1:-8}; cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t$N -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-prefetch --streams-per-gpu $N --cpu-baseline off --parity off --share8 off > $O/bench_${N}s_under_rocprof.json 2> $O/trace_$N.err
+  N=${1:-8}; shift || true; X="$*"; cd /tmp      # extra bench flags after the stream count, e.g. trace 32 --skinny-rows 16
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t$N -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-prefetch --streams-per-gpu $N --cpu-baseline off --parity off --share8 off $X > $O/bench_${N}s_under_rocprof.json 2> $O/trace_$N.err
   T=$(find $O/t$N -name '*kernel_trace.csv' | head -1); python $R/tools/trace_breakdown.py $T 28 > $O/step_breakdown_${N}streams_noprefetch.json 2>> $O/trace_$N.err; rm -rf $O/t$N
+  [ -n "$X" ] && cp $O/step_breakdown_${N}streams_noprefetch.json "$O/step_breakdown_${N}streams_noprefetch_$(echo $X | tr -d ' -').json"
   python - <<PY
 import json
 d = json.load(open("$O/step_breakdown_${N}streams_noprefetch.json"))

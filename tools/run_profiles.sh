@@ -3,7 +3,7 @@
 # dominant kernel.  Only the small summary CSVs are kept under gpurun_out/ (the kernel traces are tens of MB).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 cd /tmp
 OUT=$R/gpurun_out/profiles_$TAG

@@ -2,7 +2,7 @@
 # Full validation on an MI355X box (through gpurun): every -m gpu test, smoke(), the benchmark lines kept under profiles/<round>, rocprofv3 profiles
 #   tools/validate_on_gpu.sh [TAG]      (TAG default r03; output under gpurun_out/<TAG>, collected by tools/collect_profiles.sh <TAG>)
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out/$TAG
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
