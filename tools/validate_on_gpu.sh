@@ -1,6 +1,6 @@
 #!/bin/bash
 # Full validation on an MI355X box (through gpurun): every -m gpu test, smoke(), the benchmark lines kept under profiles/<round>, rocprofv3 profiles
-#   tools/validate_on_gpu.sh [TAG]      (TAG default r03; output under gpurun_out/<TAG>, collected by tools/collect_profiles.sh <TAG>)
+#   tools/validate_on_gpu.sh [TAG]      (TAG default r04; output under gpurun_out/<TAG>, collected by tools/collect_profiles.sh <TAG>)
 set -x
 TAG=${1:-r04}
 mkdir -p gpurun_out/$TAG
@@ -14,18 +14,14 @@ echo "tests rc=$?" >> $O/test_full.log
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
 ( time timeout 1500 python bench.py ) > $O/bench_default.log 2>&1
 B="timeout 500 python bench.py --cpu-baseline off --parity off"
-( $B --steps 2 --warmup 1 --no-prefetch ) > $O/bench_noprefetch.log 2>&1
-( $B --steps 2 --warmup 1 --no-prefetch --decode-path 0 ) > $O/bench_round1_path.log 2>&1
+( $B --steps 2 --warmup 1 --no-prefetch --share8 off ) > $O/bench_noprefetch.log 2>&1
 ( $B --steps 1 --warmup 1 --streams-per-gpu 8 ) > $O/bench_8streams.log 2>&1
-( $B --steps 1 --warmup 1 --streams-per-gpu 2 ) > $O/bench_2streams.log 2>&1
 ( $B --steps 1 --warmup 0 --streams-per-gpu 32 ) > $O/bench_32streams.log 2>&1
-( $B --steps 1 --warmup 0 --workload long480 ) > $O/bench_long480.log 2>&1
 ( $B --steps 1 --warmup 0 --workload oneshot480 ) > $O/bench_oneshot480.log 2>&1
 ( $B --steps 2 --warmup 1 --config qwen2vl-2b ) > $O/bench_2b.log 2>&1
-( $B --steps 1 --warmup 1 --weights fp8 ) > $O/bench_7b_fp8.log 2>&1
-( $B --steps 1 --warmup 1 --config qwen2vl-72b --weights fp8 --frames 16 ) > $O/bench_72b_fp8.log 2>&1
+( $B --steps 1 --warmup 1 --weights fp8 --share8 off ) > $O/bench_7b_fp8.log 2>&1
 bash tools/run_profiles.sh $TAG > $O/run_profiles.log 2>&1
 tail -n 40 $O/test_full.log; tail -n 2 $O/smoke.log
-for f in bench_default bench_noprefetch bench_round1_path bench_8streams bench_2streams bench_32streams bench_long480 bench_oneshot480 bench_2b bench_7b_fp8 bench_72b_fp8; do echo "== $f $(grep -o '"value": [0-9.]*' $O/$f.log | head -1) $(grep -o '"us_per_layer": [0-9.]*' $O/$f.log | tr '\n' ' ')"; done
+for f in bench_default bench_noprefetch bench_8streams bench_32streams bench_oneshot480 bench_2b bench_7b_fp8; do echo "== $f $(grep -o '"value": [0-9.]*' $O/$f.log | head -1) $(grep -o '"us_per_layer": [0-9.]*' $O/$f.log | tr '\n' ' ')"; done
 grep -o '"parity": {.*' $O/bench_default.log | cut -c1-1500
 tail -n 12 $O/run_profiles.log
