@@ -125,7 +125,8 @@ def test_livecc7b_greedy_tokens_equal_the_committed_hf_tokens_on_decisive_weight
     6-frame + 2-frame turns, 16 greedy tokens each, repetition_penalty 1.05, on the `decisive:0` weights whose top-1 margin is 31 % of the
     logit scale at every step).  The HIP path, free-running on the same seeds, must emit the SAME 32 token ids; its raw logits at HF's
     top-8 ids stay within 6e-2 x scale of HF's.  No HF forward on the GPU box (the 97-s live version is
-    test_greedy_tokens_are_exact_on_decisive_weights)."""
+    test_greedy_tokens_are_exact_on_decisive_weights).  A token-identity test on margins this wide is NOT a sensitivity test of the
+    layers (a several-x mid-network error would pass): that is what the rms-ratio fixtures below are for."""
     from livecc_amd import protocol
     from livecc_amd.config import get_config
     from livecc_amd.modeling import LiveCCForConditionalGeneration
