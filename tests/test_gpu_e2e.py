@@ -794,3 +794,35 @@ def test_chained_decode_launch_gives_bit_identical_logits(dev, tiny_models):
         for ta, tb in zip(outs[0], o):
             assert ta["new_tokens"] == tb["new_tokens"]
             assert torch.equal(ta["logits"], tb["logits"]), "chained and separate launches must be bit-identical"
+
+
+def test_teacher_forcing_follows_a_prescribed_stream_and_leaves_the_logits_alone(dev, tiny_models):
+    """`generate(..., teacher_tokens=...)` (lcc_debug_set_forced_tokens; what the HF oracle does with a forcing LogitsProcessor): the history
+    holds the prescribed tokens, the raw logits of step 0 equal the free run's (same prompt), the logits of step k > 0 equal those of a free
+    run wherever the two histories agree, and a later turn over the carried cache continues from the forced history.  Two streams in one
+    call take their own token rows (the device table is [step][stream])."""
+    from livecc_amd import protocol
+    cfg, hf16, hf32, native = tiny_models
+    frames = torch.from_numpy(protocol.synth_frames(6, 56, 84, seed=21, layout="TCHW"))
+    ids = protocol.TurnBuilder(cfg, seed=21).turn_ids(0, protocol.num_video_tokens(protocol.grid_of(6, 56, 84, cfg), cfg))
+    free = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, max_new_tokens=6, min_new_tokens=6, output_logits=True)
+    free_toks = free.sequences[0, len(ids):].tolist()
+    free.past_key_values.release()
+    forced = [int(t) for t in free_toks]
+    forced[2] = (forced[2] + 7) % 1000           # leave the model's own path at step 2
+    r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, max_new_tokens=6, min_new_tokens=6, output_logits=True,
+                        teacher_tokens=forced)
+    assert r.sequences[0, len(ids):].tolist() == forced
+    assert torch.equal(r.logits[:3], free.logits[:3]), "steps 0-2 see the same history: bit-identical raw logits"
+    assert not torch.equal(r.logits[3], free.logits[3]), "step 3 is conditioned on the forced token"
+    r.past_key_values.release()
+    # two streams, one call: each follows its own row
+    f2 = torch.from_numpy(protocol.synth_frames(6, 56, 84, seed=22, layout="TCHW"))
+    rows = [forced, [int((t * 3 + 1) % 1000) for t in forced]]
+    outs = native.generate_batch([dict(input_ids=torch.from_numpy(ids), frames=frames), dict(input_ids=torch.from_numpy(ids), frames=f2)],
+                                 max_new_tokens=6, force_length=True, output_logits=True, teacher_tokens=rows)
+    assert [o.sequences[0, len(ids):].tolist() for o in outs] == rows
+    d = (outs[0].logits[:3].float() - r.logits[:3].float()).abs().max().item()          # batched vs alone: another evaluation order, not bit-identical
+    assert d <= 6e-2 * r.logits[:3].float().abs().max().item(), d
+    for o in outs:
+        o.past_key_values.release()
