@@ -366,6 +366,79 @@ def test_livecc7b_oneshot480_against_the_committed_hf_logits(dev):
         assert ratios.max() <= 1.25, ratios
     assert st["decided_equal"] == st["decided"], st
 
+
+def test_livecc7b_batch_of_8_streams_against_the_committed_hf_logits(dev):
+    """ONE GPU's share of BASELINE configs[2] at the REAL shapes (batched parity was at `small` / `tiny` only): 8 streams
+    (the benchmark's seeds), the 6-frame turn + a 2-frame turn, ONE `generate_batch` call per turn -- batched vision tower over 34,944 /
+    11,648 patches, packed prefill of 9,048 / 3,088 rows (the 256- and 192-row GEMM tiles, `attn_gqa32_kernel`), one weight pass per decode
+    step for the 8 streams (`gemv_skinny_kernel` + `attn_decode_fused_kernel`) -- against tests/golden/livecc7b_batch8.npz: HF run once per
+    stream (the reference has no batched path), bf16 free-running + fp32 teacher-forced (oracle/make_golden_7b_batch8.py).  Every stream
+    follows its own HF tokens; per stream and step: |native - HF_bf16| at HF's top-64 ids <= 6e-2 x scale, rms(native - fp32) <= 1.25 x
+    rms(HF_bf16 - fp32) over the 1,024 sample ids, the native path's own choice equal to HF's wherever HF's processed-score margin exceeds
+    8 x its committed rms error."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.weights import WeightArena
+    from oracle import make_golden_7b_batch8 as B
+    g = dict(np.load(B.PATH))
+    seed0, n_streams, n_frames, H, W, n_new, seed_w = (int(x) for x in g["meta"])
+    cfg = get_config("livecc-7b")
+    sid = g["sample_ids"]
+    assert np.array_equal(sid, B.sample_ids(cfg.vocab_size))
+    arena = WeightArena(cfg, dev).fill_tiled(seed=seed_w)
+    n_tok = (H // 28) * (W // 28)
+    native = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=n_streams, max_kv_len=4096, max_new_rows=n_streams * (3 * n_tok + 128),
+                                            max_patches=n_streams * 12 * n_tok + 64, max_history=16)
+    frames = [torch.from_numpy(protocol.synth_frames(n_frames, H, W, seed=seed0 + s, layout="TCHW")).to(dev) for s in range(n_streams)]
+    builders = [protocol.TurnBuilder(cfg, seed=seed0 + s) for s in range(n_streams)]
+    states, past = [None] * n_streams, [None] * n_streams
+    st = dict(steps=0, tokens_equal=0, decided=0, decided_equal=0, worst_rel_dlogit_top=0.0)
+    ratios = []
+    for ti, (a, b) in enumerate(protocol.split_clip(n_frames)[:2]):
+        reqs, rows, fulls = [], [], []
+        for s in range(n_streams):
+            new = g[f"s{s}_t{ti}_ids"]
+            assert np.array_equal(new, builders[s].turn_ids(ti, protocol.num_video_tokens(protocol.grid_of(b - a, H, W, cfg), cfg)))
+            full = new if past[s] is None else np.concatenate([past[s], new])
+            fulls.append(full)
+            rows.append([int(x) for x in g[f"s{s}_t{ti}_tokens"]])
+            reqs.append(dict(input_ids=torch.from_numpy(full), frames=frames[s][a:b], frames_layout="TCHW", state=states[s]))
+        outs = native.generate_batch(reqs, repetition_penalty=B.PENALTY, max_new_tokens=n_new, force_length=True, output_logits=True,
+                                     teacher_tokens=rows)
+        for s, o in enumerate(outs):
+            states[s] = o.past_key_values
+            assert o.sequences[0, len(fulls[s]):].tolist() == rows[s]
+            lg = o.logits.float().cpu().numpy()
+            seen = set(int(x) for x in fulls[s])
+            k0 = f"s{s}_t{ti}"
+            for k in range(n_new):
+                scale = float(g[f"{k0}_scale"][k])
+                top_ids, top_vals = g[f"{k0}_top_ids"][k].astype(np.int64), g[f"{k0}_top_vals_bf16"][k].astype(np.float64)
+                d = float(np.abs(lg[k][top_ids] - top_vals).max())
+                st["steps"] += 1
+                st["worst_rel_dlogit_top"] = max(st["worst_rel_dlogit_top"], d / scale)
+                own = own_choice(lg[k], seen, B.PENALTY)
+                st["tokens_equal"] += int(own == rows[s][k])
+                winner, margin = processed_top2(top_ids, top_vals, seen, B.PENALTY)
+                if margin > 8.0 * float(g[f"{k0}_rms_err_bf16_full_vocab"][k]) and winner == rows[s][k]:
+                    st["decided"] += 1
+                    st["decided_equal"] += int(own == rows[s][k])
+                n_, b16, t32 = lg[k][sid].astype(np.float64), g[f"{k0}_sample_vals_bf16"][k].astype(np.float64), g[f"{k0}_sample_vals_fp32"][k].astype(np.float64)
+                ratios.append(float(np.sqrt(((n_ - t32) ** 2).mean()) / np.sqrt(((b16 - t32) ** 2).mean())))
+                seen.add(rows[s][k])
+            past[s] = np.concatenate([fulls[s], np.asarray(rows[s][:-1], dtype=np.int64)])
+    for x in states:
+        x.release()
+    ratios = np.asarray(ratios)
+    record("livecc7b_batch8_vs_committed_golden", st | dict(worst_rms_ratio=float(ratios.max()), mean_rms_ratio=float(ratios.mean()),
+                                                             rms_ratio_all_steps=float(np.sqrt((ratios ** 2).mean()))))
+    assert st["steps"] == n_streams * 2 * n_new
+    assert st["worst_rel_dlogit_top"] <= 6e-2, st
+    assert ratios.max() <= 1.25 and np.sqrt((ratios ** 2).mean()) <= 1.08, (ratios.max(), ratios.mean())
+    assert st["decided_equal"] == st["decided"], st
+    assert st["tokens_equal"] >= (2 * st["steps"]) // 3, st
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The reference's own orchestrator, executed (oracle/ref_infer_harness.py): its committed call trace through the native engine
 # ---------------------------------------------------------------------------------------------------------------------

@@ -286,3 +286,39 @@ def test_livecc7b_oneshot480_fixture_is_selfconsistent_and_rebuildable_from_its_
         lg[g["t0_top_ids"][k]] = g["t0_top_vals_bf16"][k]
         assert own_choice(lg, seen, L.PENALTY) == int(g["tokens"][k]), k
         seen.add(int(g["tokens"][k]))
+
+
+def test_livecc7b_batch8_fixture_is_selfconsistent_and_rebuildable_from_its_seeds():
+    """tests/golden/livecc7b_batch8.npz (oracle/make_golden_7b_batch8.py: HF once per stream for the 8 benchmark streams, two turns, 4 tokens
+    each; bf16 free-running + fp32 teacher-forced at the real LiveCC-7B shapes): prompts rebuilt from the seeds, tokens = the bf16 run's own
+    greedy choices, the 1,024-id sample tracks the full-vocabulary rms of (bf16 - fp32) within 10 %, streams differ from each other."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from oracle import make_golden_7b_batch8 as B
+    from tests.test_gpu_golden import own_choice
+    g = dict(np.load(B.PATH))
+    seed0, n_streams, n_frames, H, W, n_new, _ = (int(x) for x in g["meta"])
+    assert (seed0, n_streams, n_frames, H, W, n_new) == (B.SEED0, B.STREAMS, B.N_FRAMES, B.H, B.W, B.N_NEW)
+    cfg = get_config("livecc-7b")
+    assert np.array_equal(g["sample_ids"], B.sample_ids(cfg.vocab_size))
+    first = []
+    for s in range(n_streams):
+        builder = protocol.TurnBuilder(cfg, seed=seed0 + s)
+        history = []                                     # cat(past_ids, new_ids): what the repetition penalty sees (ref demo/infer.py:160,169)
+        for ti, (a, b) in enumerate(protocol.split_clip(n_frames)[:2]):
+            k0 = f"s{s}_t{ti}"
+            ids = builder.turn_ids(ti, protocol.num_video_tokens(protocol.grid_of(b - a, H, W, cfg), cfg))
+            assert np.array_equal(g[f"{k0}_ids"], ids)
+            history += [int(x) for x in ids]
+            seen = set(history)
+            e = np.sqrt(((g[f"{k0}_sample_vals_bf16"] - g[f"{k0}_sample_vals_fp32"]).astype(np.float64) ** 2).mean(axis=-1))
+            full = g[f"{k0}_rms_err_bf16_full_vocab"].astype(np.float64)
+            assert e.shape == (n_new,) and (np.abs(e / full - 1.0) <= 0.10).all(), (s, ti, e / full)
+            for k in range(n_new):
+                lg = np.full(cfg.vocab_size, -1e30, dtype=np.float32)
+                lg[g[f"{k0}_top_ids"][k]] = g[f"{k0}_top_vals_bf16"][k]
+                assert own_choice(lg, seen, B.PENALTY) == int(g[f"{k0}_tokens"][k]), (s, ti, k)
+                seen.add(int(g[f"{k0}_tokens"][k]))
+            history += [int(x) for x in g[f"{k0}_tokens"][:-1]]        # past_ids = sequences[:, :-1]: the last token never enters the history
+        first.append(tuple(g[f"s{s}_t0_top_vals_bf16"][0][:4].round(3)))
+    assert len(set(first)) == n_streams, "eight different streams"
