@@ -322,3 +322,40 @@ def test_livecc7b_batch8_fixture_is_selfconsistent_and_rebuildable_from_its_seed
             history += [int(x) for x in g[f"{k0}_tokens"][:-1]]        # past_ids = sequences[:, :-1]: the last token never enters the history
         first.append(tuple(g[f"s{s}_t0_top_vals_bf16"][0][:4].round(3)))
     assert len(set(first)) == n_streams, "eight different streams"
+
+
+def test_livecc7b_long480_stream_fixture_is_selfconsistent_and_rebuildable_from_its_seeds():
+    """tests/golden/livecc7b_long480_stream.npz (oracle/make_golden_7b_long_stream.py: the executed HF bf16 reference for BASELINE
+    configs[3] in its streaming form, 238 turns at the real LiveCC-7B shapes): complete (the generator writes `final_kv` last), the cache
+    bookkeeping follows the reference's `past_ids = sequences[:, :-1]` rule (350 + 237 x 133 keys = 31,871 at the end), and at every probe turn the
+    committed tokens are the run's own greedy choices after the repetition penalty over the whole history."""
+    from livecc_amd.config import get_config
+    from oracle import make_golden_7b_long_stream as L
+    from tests.test_gpu_golden import own_choice
+    g = dict(np.load(L.PATH))
+    assert "final_kv" in g, "the fixture generator was interrupted: regenerate with python oracle/make_golden_7b_long_stream.py"
+    seed, n_frames, H, W, n_new, seed_w, n_turns = (int(x) for x in g["meta"])
+    assert (seed, n_frames, H, W, n_new, seed_w) == (L.SEED, L.N_FRAMES, L.H, L.W, L.N_NEW, 0)
+    cfg = get_config("livecc-7b")
+    chunks = protocol.split_clip(n_frames)
+    assert len(chunks) == n_turns == 238 and g["tokens"].shape == (n_turns, n_new)
+    probes = [int(x) for x in g["probe_turns"]]
+    assert probes == L.probe_turns(n_turns) == [60, 120, 180, 235, 236, 237]
+    builder = protocol.TurnBuilder(cfg, seed=seed)
+    history, kv = [], 0
+    for ti, (a, b) in enumerate(chunks):
+        ids = builder.turn_ids(ti, protocol.num_video_tokens(protocol.grid_of(b - a, H, W, cfg), cfg))
+        if ti in probes:
+            assert int(g[f"t{ti}_kv_before"]) == kv, (ti, kv)
+            assert g[f"t{ti}_top_ids"].shape == (n_new, L.TOPK) and (np.diff(g[f"t{ti}_top_vals"], axis=1) <= 0).all()
+            assert (g[f"t{ti}_scale"] >= np.abs(g[f"t{ti}_top_vals"]).max(axis=1) - 1e-6).all()
+            seen = set(history) | set(int(x) for x in ids)
+            for k in range(n_new):
+                lg = np.full(cfg.vocab_size, -1e30, dtype=np.float32)
+                lg[g[f"t{ti}_top_ids"][k]] = g[f"t{ti}_top_vals"][k]
+                assert own_choice(lg, seen, L.PENALTY) == int(g["tokens"][ti][k]), (ti, k)
+                seen.add(int(g["tokens"][ti][k]))
+        history += [int(x) for x in ids] + [int(x) for x in g["tokens"][ti][:-1]]
+        kv += len(ids) + n_new - 1
+    assert kv == int(g["final_kv"]) == 350 + 237 * 133 == 31871
+    assert len(set(map(tuple, g["tokens"]))) > n_turns // 2, "the stream's turns differ from each other"
