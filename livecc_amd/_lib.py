@@ -94,6 +94,7 @@ def load():
         "lcc_debug_set_decode_chain": (i32, [i32]),
         "lcc_debug_set_resid_waves": (i32, [i32]),
         "lcc_debug_set_skinny_rows": (i32, [i32]),
+        "lcc_debug_set_vit_fused_qkv": (i32, [i32]),
         "lcc_dgemv_down_qkv": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, i32, i32, i32, vp, C.c_uint32,
                                      vp, vp]),
         "lcc_gemv_num_splits": (i32, [i32, i32]),

@@ -115,6 +115,18 @@ enum Epilogue : int {
   EPI_RESIDUAL = 3,    // C = bf16(residual + bf16(acc + bias))
   EPI_SWIGLU = 4,      // W rows interleaved [16 gate | 16 up]; C[:, n/2] = bf16(silu(bf16 g) * bf16 u)
   EPI_PARTIAL = 5,     // internal: raw fp32 split-K slab [split][M][N] (consumer reduces, adds bias, rounds)
+  EPI_VIT_QKV = 6,     // internal: vision-tower q|k|v projection, W rows in the `qkv_w_rope` order: q, k rotated (2-D RoPE) and stored at
+                       // their natural columns, V stored blocked-transposed for the attention kernels (gemm.hip: vit_qkv_epilogue)
 };
+
+// ViT 2-D RoPE on one rotation pair (x1, x2) = (channel c, channel c + 40) of a head: HF apply_rotary_pos_emb_vision
+// (modeling_qwen2_vl.py:225-248) computes q*cos + rotate_half(q)*sin in fp32 -- two separately rounded products and one add, no FMA.
+// Contraction is switched off here so that every kernel applying the rotation (vit_rope_vt_kernel, the q|k|v GEMM epilogue) produces the
+// same bits, and those are HF's.
+LCC_DEVICE void vit_rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+#pragma clang fp contract(off)
+  o1 = x1 * c - x2 * s;
+  o2 = x2 * c + x1 * s;
+}
 
 }  // namespace lcc

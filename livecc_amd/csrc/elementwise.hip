@@ -260,8 +260,7 @@ __global__ __launch_bounds__(256) void vit_rope_vt_kernel(bf16_t* __restrict__ q
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float c = cs[(size_t)p * HALF + c0 + e], s = sn[(size_t)p * HALF + c0 + e];
-      o1[e] = x1[e] * c - x2[e] * s;  // q*cos + (-x2)*sin
-      o2[e] = x2[e] * c + x1[e] * s;
+      vit_rope_pair(x1[e], x2[e], c, s, o1[e], o2[e]);  // q*cos + rotate_half(q)*sin, products rounded separately as in HF
     }
     st16(base + c0, (u32x4){pack2(o1[0], o1[1]), pack2(o1[2], o1[3]), pack2(o1[4], o1[5]), pack2(o1[6], o1[7])});
     st16(base + c0 + HALF, (u32x4){pack2(o2[0], o2[1]), pack2(o2[2], o2[3]), pack2(o2[4], o2[5]), pack2(o2[6], o2[7])});

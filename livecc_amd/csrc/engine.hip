@@ -233,6 +233,8 @@ static int resolve_weights(lcc_engine* e, std::string* missing) {
     const std::string p = "vit." + std::to_string(i) + ".";
     VitLayerW& L = e->vit[i];
     L.ln1_w = get(p + "ln1_w"); L.ln1_b = get(p + "ln1_b"); L.qkv_w = get(p + "qkv_w"); L.qkv_b = get(p + "qkv_b");
+    { auto iw = e->w.find(p + "qkv_w_rope"), ib = e->w.find(p + "qkv_b_rope");
+      L.qkv_w_rope = iw == e->w.end() ? nullptr : (const bf16_t*)iw->second; L.qkv_b_rope = ib == e->w.end() ? nullptr : (const bf16_t*)ib->second; }
     L.proj_w = get(p + "proj_w"); L.proj_b = get(p + "proj_b"); L.ln2_w = get(p + "ln2_w"); L.ln2_b = get(p + "ln2_b");
     L.fc1_w = get(p + "fc1_w"); L.fc1_b = get(p + "fc1_b"); L.fc2_w = get(p + "fc2_w"); L.fc2_b = get(p + "fc2_b");
   }

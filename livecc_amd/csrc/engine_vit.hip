@@ -6,6 +6,9 @@
 // ------------------------------------------------------------------------------------------------
 // ViT
 // ------------------------------------------------------------------------------------------------
+static int g_vit_fused_qkv = [] { const char* v = getenv("LCC_VIT_FUSED_QKV"); return v ? atoi(v) : 1; }();
+extern "C" int lcc_debug_set_vit_fused_qkv(int on) { const int old = g_vit_fused_qkv; g_vit_fused_qkv = on ? 1 : 0; return old; }
+
 extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips, const float mean255[3], const float std255[3],
                               const float* rope_cos, const float* rope_sin, void* out_embeds, void* stream) {
   LCC_TRY(ensure_ready(e));
@@ -85,13 +88,25 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   if ((e->vit_taps || e->vit_over) && P > e->vit_tap_rows) return fail(LCC_ERR_STATE, "ViT taps bound for %d rows, call has %d patches", e->vit_tap_rows, P);
   const size_t tap_stride = (size_t)e->vit_tap_rows * E;
   if (e->vit_taps) HIP_TRY(hipMemcpyAsync(e->vit_taps, x, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));   // tap 0 = PatchEmbed output
+  // q|k|v projection with RoPE + V transpose in its epilogue: head_dim 80, shapes of the 8-wave GEMM (K % 64 == 0, > 64 patches); every
+  // segment is a multiple of 4 patches (H, W multiples of 28).  lcc_debug_set_vit_fused_qkv(0) / LCC_VIT_FUSED_QKV=0: separate launches.
+  const bool fused_qkv = g_vit_fused_qkv != 0 && e->vit_hd == 80 && gemm_vit_qkv_eligible(P, E, E);
   for (int l = 0; l < e->c.vit_depth; ++l) {
     const VitLayerW& L = e->vit[l];
     if (e->vit_over) HIP_TRY(hipMemcpyAsync(x, e->vit_over + (size_t)l * tap_stride, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));
     LCC_TRY(layernorm_bf16(x, L.ln1_w, L.ln1_b, xn, P, E, 1e-6f, st));
     g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
-    LCC_TRY(gemm_bf16(g, st));
-    LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));
+    if (fused_qkv && L.qkv_w_rope != nullptr && L.qkv_b_rope != nullptr) {
+      // round 4: the projection's epilogue rotates q, k and writes V blocked-transposed itself (gemm.hip: vit_qkv_epilogue); weight rows
+      // and bias in the rotation-pair order (`vit.<i>.qkv_w_rope` / `qkv_b_rope`).  The V columns of `qkv` are not written.
+      g.W = L.qkv_w_rope; g.bias = L.qkv_b_rope; g.epilogue = GEMM_EPI_VIT_QKV;
+      g.vq.cs = rope_cos; g.vq.sn = rope_sin; g.vq.seg_of_patch = d_seg_of_patch; g.vq.seg_start = d_seg_start; g.vq.seg_blk = d_seg_blk;
+      g.vq.vt = vt; g.vq.total_blocks = blocks; g.vq.E = E;
+      LCC_TRY(gemm_bf16(g, st));
+    } else {
+      LCC_TRY(gemm_bf16(g, st));
+      LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));
+    }
     // 32x32x16 kernel (8 waves x 32 rows per block) once its grid fills the chip: 8 streams' chunks = 768 blocks, 170 vs 359 us per
     // block of the tower; ONE 2-frame chunk is only 6 groups x 16 heads = 96 blocks (49 us) -- there the 16-row-per-wave LDS-shared
     // kernel with twice the blocks stays (41 us)

@@ -107,6 +107,95 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[AM][AN], int mbase, int nbase, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// EPI_VIT_QKV (round 4): the vision tower's q|k|v projection writes what its attention kernels read -- q and k rotated (2-D RoPE,
+// HF modeling_qwen2_vl.py:225-248) at their natural columns of C, V blocked-transposed into vt[head][32-key block][80][32] -- instead
+// of a plain [P, 3E] tensor that vit_rope_vt_kernel re-reads and re-writes (55 us per tower block at 8 streams, 179 MB of traffic).
+//
+// W rows (and bias) arrive in the `qkv_w_rope` order (weights.py: vit_qkv_rope_row_permutation): inside q and inside k every 32 stored
+// rows are [16 first-half channels | their 16 rotation partners], first-half channels enumerated head-major (f = head * 40 + c, c < 40),
+// so a lane's accumulators acc[i][j] / acc[i][j + 1] hold (x[c .. c+3], x[c+40 .. c+43]) of one head: the rotation is register-local.
+// 40 % 4 == 0, so a lane's four channels never straddle a head.  V rows keep their natural order; the 4 x 4 (patch x channel) block a
+// quad of lanes holds is transposed with two cross-lane exchanges so that each lane stores 4 consecutive keys of one channel (8 bytes,
+// four lanes = 32 contiguous bytes, the store granularity of the plain epilogue).  Segment lengths are multiples of 4 (H and W are
+// multiples of 28), so a 4-patch group never straddles a segment or a 32-key block.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+LCC_DEVICE void vit_qkv_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int g, const bf16_t* __restrict__ bias,
+                                 bf16_t* __restrict__ C, int ldc, int M, int N, const VitQkvEpi& vq) {
+  const int E = vq.E;
+  const int q4 = li & 3, m4off = li & ~3;
+  // V columns in this wave's 64-column strip?  Then: segment of every 4-patch group this lane will store.
+  int vblk[MT], vkl[MT];
+  if (nbase + NT * 16 > 2 * E) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m4 = min(mbase + i * 16 + m4off, M - 4);
+      const int sg = vq.seg_of_patch[m4];
+      const int kl = m4 - vq.seg_start[sg];
+      vblk[i] = vq.seg_blk[sg] + (kl >> 5);
+      vkl[i] = kl & 31;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; j += 2) {
+    const int n = nbase + j * 16;            // first column of a 32-column group (wave-uniform)
+    if (n >= N) continue;
+    if (n < 2 * E) {                         // ---- q or k: bias, bf16 rounding of the Linear output, rotation, one rounding
+      const int which = n >= E ? 1 : 0;
+      const int f = ((n - which * E) >> 5) * 16 + g * 4;
+      const int h = f / 40, c = f - h * 40;
+      u32x2 b1 = (u32x2){0u, 0u}, b2 = (u32x2){0u, 0u};
+      if (bias != nullptr) { b1 = ld8(bias + n + g * 4); b2 = ld8(bias + n + 16 + g * 4); }
+      bf16_t* out = C + which * E + h * 80 + c;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = mbase + i * 16 + li;
+        const int mc = min(m, M - 1);
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(vq.cs + (size_t)mc * 40 + c);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(vq.sn + (size_t)mc * 40 + c);
+        float x1[4], x2[4], o1[4], o2[4];
+        x1[0] = rbf(acc[i][j][0] + lo2f(b1.x)); x1[1] = rbf(acc[i][j][1] + hi2f(b1.x));
+        x1[2] = rbf(acc[i][j][2] + lo2f(b1.y)); x1[3] = rbf(acc[i][j][3] + hi2f(b1.y));
+        x2[0] = rbf(acc[i][j + 1][0] + lo2f(b2.x)); x2[1] = rbf(acc[i][j + 1][1] + hi2f(b2.x));
+        x2[2] = rbf(acc[i][j + 1][2] + lo2f(b2.y)); x2[3] = rbf(acc[i][j + 1][3] + hi2f(b2.y));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vit_rope_pair(x1[r], x2[r], cv[r], sv[r], o1[r], o2[r]);
+        if (m < M) {
+          st8(out + (size_t)m * ldc, (u32x2){pack2(o1[0], o1[1]), pack2(o1[2], o1[3])});
+          st8(out + (size_t)m * ldc + 40, (u32x2){pack2(o2[0], o2[1]), pack2(o2[2], o2[3])});
+        }
+      }
+    } else {                                 // ---- V: bias, rounding, 4 x 4 transpose inside the quad, 4 keys of one channel per lane
+#pragma unroll
+      for (int jj = j; jj < j + 2; ++jj) {
+        const int nn = nbase + jj * 16 + g * 4;
+        u32x2 bv = (u32x2){0u, 0u};
+        if (bias != nullptr) bv = ld8(bias + nn);
+        const int col = nn - 2 * E + q4;     // this lane's channel after the transpose
+        const int h = col / 80, c = col - h * 80;
+        bf16_t* base = vq.vt + ((size_t)h * vq.total_blocks * 80 + c) * 32;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          // lane (a, q) holds Y[q][r] = X[patch 4a + q][channel g*4 + r]; a0 = (Y[q][0], Y[q][1]), a1 = (Y[q][2], Y[q][3])
+          const unsigned a0 = pack2(acc[i][jj][0] + lo2f(bv.x), acc[i][jj][1] + hi2f(bv.x));
+          const unsigned a1 = pack2(acc[i][jj][2] + lo2f(bv.y), acc[i][jj][3] + hi2f(bv.y));
+          // exchange 1 (lane ^ 1): odd lanes send their even elements, even lanes their odd ones
+          const unsigned s1 = (q4 & 1) ? ((a0 & 0xffffu) | (a1 << 16)) : ((a0 >> 16) | (a1 & 0xffff0000u));
+          const unsigned r1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+          const unsigned b0 = (q4 & 1) ? ((r1 & 0xffffu) | (a0 & 0xffff0000u)) : ((a0 & 0xffffu) | (r1 << 16));
+          const unsigned b1w = (q4 & 1) ? ((r1 >> 16) | (a1 & 0xffff0000u)) : ((a1 & 0xffffu) | (r1 & 0xffff0000u));
+          // exchange 2 (lane ^ 2): lanes 0, 1 of the quad keep b0 and take the partner's b0; lanes 2, 3 keep b1 and take the partner's b1
+          const unsigned s2 = (q4 & 2) ? b0 : b1w;
+          const unsigned r2 = (unsigned)__shfl_xor((int)s2, 2, 64);
+          const u32x2 o = (q4 & 2) ? (u32x2){r2, b1w} : (u32x2){b0, r2};     // keys 4a .. 4a+3 of channel g*4 + q
+          if (mbase + i * 16 + m4off < M) st8(base + (size_t)vblk[i] * (80 * 32) + vkl[i], o);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tiled GEMM
 // ------------------------------------------------------------------------------------------------
 template <int BM, int EPI>
@@ -362,7 +451,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
-    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale) {
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, VitQkvEpi vq) {
   constexpr int BN = 256, BK = 64, NSTAGE = (BM >= 192 && !W8) ? 2 : 3;     // BM 192 (round 4): 56-KB stages, two of them
   constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
   constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
@@ -524,7 +613,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     }
   }
   if (SCHED == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies of the last iterations
-  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
+  if constexpr (EPI == EPI_VIT_QKV) vit_qkv_epilogue<MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, li, g, bias, C, ldc, M, N, vq);
+  else tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -993,7 +1083,7 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
-      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale);
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq);
 }
 // 0: gemm_big_kernel<256> (round 2/3), 1: gemm_pp_kernel (ping-pong wave groups), 2: the same with s_setprio(1) around the MFMA clusters.
 // LCC_GEMM_PP / lcc_debug_set_gemm_variant(10 / 11 / 12) select it.
@@ -1044,6 +1134,10 @@ void set_gemm_variant(int v) {
   g_gemm_sched = (v == 5 || v == 6) ? 0 : 1;
 }
 static bool big_eligible(const GemmArgs& a) { return a.w_packed && (a.K % 64) == 0 && a.M > 16; }
+static_assert(GEMM_EPI_VIT_QKV == (int)EPI_VIT_QKV, "kernels.h / common.h disagree");
+// M > 64: up to 64 rows the plain projection runs on the weight-streaming kernels (another fp32 summation order, and the better shape for so
+// few rows) -- the fused form takes over where the plain one is an MFMA tile kernel, so both forms give the same bits
+bool gemm_vit_qkv_eligible(int M, int E, int K) { return K > 0 && (K % 64) == 0 && M > 64 && (M & 3) == 0 && E > 0 && (E & 31) == 0; }
 
 // 0 = not the 8-wave kernel, else its BM.  Variants 3 / 4 (5 / 6) force BM 256 / 128 wherever the kernel is eligible.
 // Auto (2): estimated relative throughput = row utilisation x wave quantisation x measured tile efficiency.  The 8-wave
@@ -1648,6 +1742,19 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if ((((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) != 0) return LCC_ERR_ALIGN;
   if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
   if (a.epilogue == EPI_RESIDUAL && a.residual == nullptr) return LCC_ERR_ARG;
+  if (a.epilogue == EPI_VIT_QKV) {   // vision-tower q|k|v projection with RoPE + V transpose in the epilogue: 8-wave kernel only
+    const VitQkvEpi& q = a.vq;
+    if (!a.w_packed || a.partial != nullptr || !gemm_vit_qkv_eligible(a.M, q.E, a.K) || a.N != 3 * q.E || q.cs == nullptr || q.sn == nullptr ||
+        q.seg_of_patch == nullptr || q.seg_start == nullptr || q.seg_blk == nullptr || q.vt == nullptr || q.total_blocks <= 0)
+      return LCC_ERR_ARG;
+    if ((((uintptr_t)q.cs | (uintptr_t)q.sn) & 15) != 0 || ((uintptr_t)q.vt & 7) != 0 || (a.bias != nullptr && ((uintptr_t)a.bias & 7) != 0)) return LCC_ERR_ALIGN;
+    g_launch_counts[LC_GEMM_VIT_QKV]++;
+    const int big = big_tile_rows(a, 1);
+    if (big == 256) launch_big_s<256, EPI_VIT_QKV, 6, false>(a, st);
+    else if (big == 192) launch_big_s<192, EPI_VIT_QKV, 6, false>(a, st);
+    else launch_big_s<128, EPI_VIT_QKV, 6, false>(a, st);
+    return 0;
+  }
   // weight-streaming path: up to g_skinny_rows rows (64: decode batches of 17-64 streams multiply every weight fragment with 2-4 activation
   // fragments; lcc_debug_set_skinny_rows(16) restores the round-3 routing of 17-64 rows through the 64-row GEMM tiles)
   // (a forced GEMM tile variant -- tests, A/B runs -- keeps 17-64 rows on the tiles it asks for)

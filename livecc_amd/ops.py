@@ -109,7 +109,7 @@ ATTN_DEFAULT_VARIANT = 3
 
 LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "attn_decode_fused_merge", "gemv_fused_tail", "dgemv_v2",
                    "attn_prefill_mfma32", "attn_prefill_shared", "attn_prefill_per_wave", "attn_prefill_combine", "last_decode_nsplit",
-                   "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_pp")
+                   "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_pp", "gemm_vit_qkv")
 
 
 def launch_counts(reset: bool = False) -> dict:
@@ -135,6 +135,11 @@ def set_gemm_variant(v: int) -> None:
 def set_skinny_rows(rows: int) -> int:
     """Largest M served by the weight-streaming GEMV kernels (16..64, default 64); returns the previous value."""
     return _lib.load().lcc_debug_set_skinny_rows(int(rows))
+
+
+def set_vit_fused_qkv(on: bool) -> int:
+    """Vision tower: q|k|v projection with RoPE + V transpose in its epilogue (default on) vs separate launches; returns the previous value."""
+    return _lib.load().lcc_debug_set_vit_fused_qkv(1 if on else 0)
 
 
 def gemv_num_splits(N: int, K: int) -> int:

@@ -8,6 +8,8 @@ as the reference does (ref evaluation/livesports3kcc/distributed_generate_livecc
 Layout decisions (engine names -> shapes):
   vit.patch_embed [E,1176]           Conv3d weight [E,3,2,14,14] flattened (c,t,y,x) = patch feature order
   vit.{i}.qkv_w [3E,E] ...           as HF
+  vit.{i}.qkv_w_rope / qkv_b_rope    the same rows in the rotation-pair order (vit_qkv_rope_row_permutation): RoPE + V transpose run in
+                                     the projection's epilogue
   llm.{i}.qkv_w [Hq*128+2*Hkv*128, H] q_proj|k_proj|v_proj rows concatenated (one GEMM)
   llm.{i}.gate_up_w [2I, H]          rows interleaved in blocks of 16: [16 gate rows | 16 up rows] so that
                                      the GEMM epilogue holds gate and up of the same column in one lane
@@ -35,6 +37,23 @@ def qkv_decode_row_permutation(cfg: LiveCCConfig) -> torch.Tensor:
     return (torch.arange(heads)[:, None] * 128 + inner[None, :]).reshape(-1)
 
 
+def vit_qkv_rope_row_permutation(cfg: LiveCCConfig) -> torch.Tensor:
+    """Row order of the copy of the vision q|k|v weight / bias whose GEMM epilogue applies the 2-D RoPE and writes V transposed
+    (`vit.{i}.qkv_w_rope`, `vit.{i}.qkv_b_rope`; csrc/gemm.hip: vit_qkv_epilogue): stored row -> logical row.  Inside q and inside k
+    every 32 stored rows are [16 first-half channels | their 16 rotation partners (+40)], first-half channels enumerated head-major
+    (f = head * 40 + c, c < 40), so the two 16-column MFMA tiles of a lane hold (x[c], x[c + 40]) of one head; V rows keep their order."""
+    E, hd = cfg.vit_embed_dim, cfg.vit_head_dim
+    assert hd == 80 and E % 32 == 0, (E, hd)
+    f = torch.arange(E // 2).view(-1, 16)                                    # [E/32 groups, 16]
+    first = (f // 40) * 80 + f % 40
+    qk = torch.stack([first, first + 40], dim=1).reshape(-1)                 # [E]: 16 first-half | 16 partners | ...
+    return torch.cat([qk, E + qk, 2 * E + torch.arange(E)])
+
+
+def has_vit_rope_copies(cfg: LiveCCConfig) -> bool:
+    return cfg.vit_head_dim == 80 and cfg.vit_embed_dim % 32 == 0
+
+
 def weight_shapes(cfg: LiveCCConfig, decode_copies: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
     E, H, I = cfg.vit_embed_dim, cfg.hidden_size, cfg.intermediate_size
     M = cfg.vit_mlp_dim
@@ -44,6 +63,8 @@ def weight_shapes(cfg: LiveCCConfig, decode_copies: bool = True) -> List[Tuple[s
         out += [(p + "ln1_w", (E,)), (p + "ln1_b", (E,)), (p + "qkv_w", (3 * E, E)), (p + "qkv_b", (3 * E,)),
                 (p + "proj_w", (E, E)), (p + "proj_b", (E,)), (p + "ln2_w", (E,)), (p + "ln2_b", (E,)),
                 (p + "fc1_w", (M, E)), (p + "fc1_b", (M,)), (p + "fc2_w", (E, M)), (p + "fc2_b", (E,))]
+        if decode_copies and has_vit_rope_copies(cfg):      # +0.16 GB at 7B: one launch per tower block (RoPE + V transpose in the GEMM epilogue)
+            out += [(p + "qkv_w_rope", (3 * E, E)), (p + "qkv_b_rope", (3 * E,))]
     out += [("merger.ln_w", (E,)), ("merger.ln_b", (E,)), ("merger.fc1_w", (4 * E, 4 * E)), ("merger.fc1_b", (4 * E,)),
             ("merger.fc2_w", (H, 4 * E)), ("merger.fc2_b", (H,)), ("embed", (cfg.vocab_size, H))]
     for i in range(cfg.num_hidden_layers):
@@ -208,6 +229,10 @@ class WeightArena:
                     q, s_ = quantize_fp8_rows(torch.randn((r1 - r0, K), generator=g, device=self.device, dtype=torch.float32).mul_(std))
                     pv[r0 // 16:r1 // 16].copy_(pack_weight_fp8(q).view((r1 - r0) // 16, K // 64, 4, 16, 16))
                     sc[r0:r1].copy_(s_)
+            elif name.endswith("qkv_w_rope"):  # the vision q|k|v weight in the rotation-pair row order
+                self.store(name, self.logical(name[:-5])[vit_qkv_rope_row_permutation(self.cfg).to(self.device)])
+            elif name.endswith("qkv_b_rope"):
+                v.copy_(self.view(name[:-5])[vit_qkv_rope_row_permutation(self.cfg).to(self.device)])
             elif name.endswith("qkv_w_dec"):   # the same matrix as qkv_w, rows permuted (both packed)
                 self.store(name, self.logical(name[:-4])[qkv_decode_row_permutation(self.cfg).to(self.device)])
             elif name.endswith("qkv_w"):       # kept logical -> packed so that the decode copy can be derived from it
@@ -245,6 +270,11 @@ class WeightArena:
                          ("norm2.weight", "ln2_w"), ("norm2.bias", "ln2_b"), ("mlp.fc1.weight", "fc1_w"),
                          ("mlp.fc1.bias", "fc1_b"), ("mlp.fc2.weight", "fc2_w"), ("mlp.fc2.bias", "fc2_b")):
                 put(p + b, sd_get(s + a))
+            if (p + "qkv_w_rope") in self.offsets:
+                perm = vit_qkv_rope_row_permutation(cfg)
+                w, bq = sd_get(s + "attn.qkv.weight"), sd_get(s + "attn.qkv.bias")
+                put(p + "qkv_w_rope", w[perm.to(w.device)])
+                put(p + "qkv_b_rope", bq[perm.to(bq.device)])
         for a, b in (("ln_q.weight", "ln_w"), ("ln_q.bias", "ln_b"), ("mlp.0.weight", "fc1_w"), ("mlp.0.bias", "fc1_b"),
                      ("mlp.2.weight", "fc2_w"), ("mlp.2.bias", "fc2_b")):
             put("merger." + b, sd_get("visual.merger." + a))

@@ -159,3 +159,31 @@ def test_fp8_quantise_pack_roundtrip_and_arena_layout():
     assert torch.equal(arena.logical("llm.0.qkv_w"), dequantize_fp8_rows(qq, ss))
     bf16 = WeightArena(cfg, "cpu")
     assert arena.nbytes() < bf16.nbytes() and all(o[0] % 128 == 0 for o in arena.offsets.values())
+
+
+def test_vit_rope_copy_is_the_row_permuted_qkv_weight_in_rotation_pair_order():
+    """`vit.{i}.qkv_w_rope` / `qkv_b_rope` (the q|k|v projection whose GEMM epilogue applies the 2-D RoPE, csrc/gemm.hip vit_qkv_epilogue):
+    a permutation; inside q and k every 32 stored rows are 16 first-half channels followed by their partners 40 channels later IN THE SAME
+    head, 4-row groups never straddle a head (the epilogue stores 4 channels per lane); V rows keep their order; excluded from the
+    parameter count (`decode_copies=False`); every filler derives the copies from the natural weight."""
+    from livecc_amd.weights import WeightArena, vit_qkv_rope_row_permutation
+    for cfg in (tiny(), livecc_7b()):
+        E = cfg.vit_embed_dim
+        perm = vit_qkv_rope_row_permutation(cfg)
+        assert sorted(perm.tolist()) == list(range(3 * E))
+        assert torch.equal(perm[2 * E:], torch.arange(2 * E, 3 * E))
+        for which in range(2):
+            blk = perm[which * E:(which + 1) * E].view(-1, 2, 16)
+            first, partner = blk[:, 0], blk[:, 1]
+            assert torch.equal(partner, first + 40)
+            assert ((first - which * E) % 80 < 40).all() and (first // 80 == partner // 80).all()
+            quads = first.reshape(-1, 4)
+            assert (quads[:, 3] - quads[:, 0] == 3).all() and (quads[:, 0] // 80 == quads[:, 3] // 80).all()
+        assert not any(n.endswith("_rope") for n, _ in weight_shapes(cfg, decode_copies=False))
+        assert sum(n.endswith("_rope") for n, _ in weight_shapes(cfg)) == 2 * cfg.vit_depth
+    cfg = tiny()
+    perm = vit_qkv_rope_row_permutation(cfg)
+    for arena in (WeightArena(cfg, "cpu").fill_random(seed=3), WeightArena(cfg, "cpu").fill_tiled(seed=3)):
+        for l in range(cfg.vit_depth):
+            assert torch.equal(arena.logical(f"vit.{l}.qkv_w_rope"), arena.logical(f"vit.{l}.qkv_w")[perm])
+            assert torch.equal(arena.view(f"vit.{l}.qkv_b_rope"), arena.view(f"vit.{l}.qkv_b")[perm])

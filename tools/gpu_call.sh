@@ -73,6 +73,23 @@ b72)         # BASELINE.json configs[4]: Qwen2-VL-72B shapes, fp8 weights, the c
 ab)          # A/B of an environment switch on the multi-stream bench: bash tools/gpu_call.sh ab <streams> VAR=a VAR=b ...
   N=$1; shift
   for KV in "$@"; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu $N --share8 off ) > $O/bench_${N}s_$KV.log 2>&1; echo "== $N streams $KV: $(val $O/bench_${N}s_$KV.log value) tok/s, $(val $O/bench_${N}s_$KV.log frames_per_s) frames/s"; tail -n 2 $O/bench_${N}s_$KV.log | grep -v '^{' | cut -c1-300; done ;;
+vitq)        # q|k|v projection of the vision tower with RoPE + V transpose in its epilogue: bit-identity vs the separate launches, then the
+             # tower / HF parity tests that run through it, then the 8-stream bench A/B
+  timeout 600 python -m pytest tests/test_gpu_vit_fused.py -m gpu -q --timeout 500 > $O/vitq.log 2>&1; tail -n 12 $O/vitq.log; cp gpurun_out/parity_report.json $O/parity_vitq.json; grep -A12 vit_tower_fused $O/parity_vitq.json | head -40
+  timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_e2e.py -m gpu -q --timeout 500 -k "vit_rope or vit_features or prefetch or teacher" > $O/vitq2.log 2>&1; tail -n 4 $O/vitq2.log
+  shift $# ; for KV in LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1 LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8s_$KV.log 2>&1; echo "== 8 streams $KV: $(val $O/bench_8s_$KV.log value) tok/s"; done
+  for KV in LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_$KV.log 2>&1; echo "== 1 stream $KV: $(val $O/bench_1s_$KV.log value) tok/s"; done ;;
+vitprof)     # kernel stats of the vision tower alone, fused and separate q|k|v epilogue: bash tools/gpu_call.sh vitprof <streams>
+  N=${1:-8}; cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s$N -o tower -- python $R/tools/vit_tower_target.py $N > $O/tower_$N.log 2> $O/tower_$N.err
+  S=$(find $O/s$N -name '*kernel_stats.csv' | head -1); cp $S $O/vit_tower_${N}streams_kernel_stats.csv; rm -rf $O/s$N
+  python - <<PY
+import csv
+rows = list(csv.DictReader(open("$O/vit_tower_${N}streams_kernel_stats.csv")))
+for r in rows[:16]:
+    print("%-110s calls %5s avg %9.2f us total %9.1f us" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
+PY
+  cd $R ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
