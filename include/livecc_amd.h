@@ -97,8 +97,9 @@ int lcc_debug_set_resid_waves(int mode);
 int lcc_debug_set_skinny_rows(int rows);
 /* Vision tower (lcc_vit_encode): 1 (default; LCC_VIT_FUSED_QKV=0 in the environment starts with 0) = the q|k|v projection of every block
  * applies the 2-D RoPE to q, k and writes V blocked-transposed in its own epilogue (needs the `vit.<i>.qkv_w_rope` / `qkv_b_rope` copies of
- * the weights in the rotation-pair row order, head_dim 80 and an 8-wave GEMM shape); 0 = projection + lcc_vit_rope_vt_bf16 as separate
- * launches.  Both forms produce the same bits (HF Q2VL:225-248, 342-368).  Returns the old value. */
+ * the weights in the rotation-pair row order, head_dim 80, more than 64 patches and K % 64 == 0; one launch when E % 128 == 0, else a q|k
+ * launch + a V launch); 0 = projection + lcc_vit_rope_vt_bf16 as separate launches.  Both forms produce the same bits (HF Q2VL:225-248,
+ * 342-368).  Returns the old value. */
 int lcc_debug_set_vit_fused_qkv(int on);
 int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order

@@ -115,8 +115,9 @@ enum Epilogue : int {
   EPI_RESIDUAL = 3,    // C = bf16(residual + bf16(acc + bias))
   EPI_SWIGLU = 4,      // W rows interleaved [16 gate | 16 up]; C[:, n/2] = bf16(silu(bf16 g) * bf16 u)
   EPI_PARTIAL = 5,     // internal: raw fp32 split-K slab [split][M][N] (consumer reduces, adds bias, rounds)
-  EPI_VIT_QKV = 6,     // internal: vision-tower q|k|v projection, W rows in the `qkv_w_rope` order: q, k rotated (2-D RoPE) and stored at
-                       // their natural columns, V stored blocked-transposed for the attention kernels (gemm.hip: vit_qkv_epilogue)
+  EPI_VIT_QK = 6,      // internal: vision-tower q|k projection, W rows in the `qkv_w_rope` order: 2-D RoPE in the epilogue, stored at the natural columns
+  EPI_VIT_V = 7,       // internal: vision-tower V projection, MFMA operands swapped: stored blocked-transposed for the attention kernels
+  EPI_VIT_QKV = 8,     // internal: both in one launch (N = 3E): column tiles below 2E run the q|k body, the others the V body
 };
 
 // ViT 2-D RoPE on one rotation pair (x1, x2) = (channel c, channel c + 40) of a head: HF apply_rotary_pos_emb_vision

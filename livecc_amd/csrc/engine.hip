@@ -159,7 +159,7 @@ extern "C" size_t lcc_engine_kv_bytes_per_slot(const lcc_engine* e) { return e->
 extern "C" size_t lcc_engine_meta_bytes(const lcc_engine* e) {
   const size_t S = e->lim.max_new_rows, P = e->lim.max_patches, B = e->lim.max_slots;
   const size_t llm = (7 * S + 4 * (S / 16 + B + 1) + 4 * B + 64) * 4;
-  const size_t vit = (P + 8 * (P / 16 + 64) + 64) * 4;
+  const size_t vit = (P + P / 4 + 8 * (P / 16 + 64) + 128) * 4;     // + P / 4: grp_off of the fused q|k|v projection
   return align_up(std::max(llm, vit) + 4096, 4096) * META_RING;
 }
 
@@ -189,7 +189,7 @@ extern "C" int lcc_engine_bind_buffers(lcc_engine* e, void* workspace_dev, size_
 extern "C" size_t lcc_engine_vit_workspace_bytes(const lcc_engine* e) { return e->vit_ws_bytes(); }
 extern "C" size_t lcc_engine_vit_meta_bytes(const lcc_engine* e) {
   const size_t P = e->lim.max_patches;
-  return align_up((P + 8 * (P / 16 + 64) + 64) * 4 + 4096, 4096) * 2;
+  return align_up((P + P / 4 + 8 * (P / 16 + 64) + 128) * 4 + 4096, 4096) * 2;
 }
 extern "C" int lcc_engine_bind_vit_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* meta_dev, void* meta_host_pinned,
                                            size_t meta_bytes) {

@@ -35,6 +35,12 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   }
   if (P > e->lim.max_patches) return fail(LCC_ERR_STATE, "%d patches > max_patches %d", P, e->lim.max_patches);
   const int n_tiles = (int)tile_seg.size(), n_seg = (int)seg_start.size(), n_groups = (int)grp_seg.size();
+  // V epilogue of the fused q|k|v projection: where the 4 patches 4i .. 4i+3 land inside a (head, channel) plane of vt
+  std::vector<int32_t> grp_off((size_t)(P + 3) / 4);
+  for (size_t i = 0; i < grp_off.size(); ++i) {
+    const int p = (int)i * 4, sg = seg_of_patch[std::min(p, P - 1)], kl = p - seg_start[sg];
+    grp_off[i] = (seg_blk[sg] + (kl >> 5)) * (80 * 32) + (kl & 31);
+  }
 
   const bool own = e->ws_vit != nullptr;     // private buffers: this call may overlap LLM work on another stream
   Carver cv; cv.base = own ? e->ws_vit : e->ws;
@@ -58,13 +64,13 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   } else {
     LCC_TRY(meta_begin(e, &mw));
   }
-  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0, *d_grp_seg, *d_grp_q0, *d_g8_seg, *d_g8_q0;
+  int32_t *d_seg_start, *d_seg_len, *d_seg_blk, *d_seg_of_patch, *d_tile_seg, *d_tile_q0, *d_grp_seg, *d_grp_q0, *d_g8_seg, *d_g8_q0, *d_grp_off;
   const int n_groups8 = (int)g8_seg.size();
   if (!mw.put(seg_start.data(), n_seg, &d_seg_start) || !mw.put(seg_len.data(), n_seg, &d_seg_len) ||
       !mw.put(seg_blk.data(), n_seg, &d_seg_blk) || !mw.put(seg_of_patch.data(), P, &d_seg_of_patch) ||
       !mw.put(tile_seg.data(), n_tiles, &d_tile_seg) || !mw.put(tile_q0.data(), n_tiles, &d_tile_q0) ||
       !mw.put(grp_seg.data(), n_groups, &d_grp_seg) || !mw.put(grp_q0.data(), n_groups, &d_grp_q0) ||
-      !mw.put(g8_seg.data(), n_groups8, &d_g8_seg) || !mw.put(g8_q0.data(), n_groups8, &d_g8_q0))
+      !mw.put(g8_seg.data(), n_groups8, &d_g8_seg) || !mw.put(g8_q0.data(), n_groups8, &d_g8_q0) || !mw.put(grp_off.data(), (int)grp_off.size(), &d_grp_off))
     return fail(LCC_ERR_STATE, "meta ring slot too small");
   if (own) HIP_TRY(hipMemcpyAsync(mw.dev, mw.host, mw.off, hipMemcpyHostToDevice, st));
   else LCC_TRY(meta_commit(&mw, st));
@@ -97,12 +103,19 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     LCC_TRY(layernorm_bf16(x, L.ln1_w, L.ln1_b, xn, P, E, 1e-6f, st));
     g = GemmArgs(); g.w_packed = 1; g.A = xn; g.lda = E; g.W = L.qkv_w; g.ldw = E; g.bias = L.qkv_b; g.C = qkv; g.ldc = 3 * E; g.M = P; g.N = 3 * E; g.K = E;
     if (fused_qkv && L.qkv_w_rope != nullptr && L.qkv_b_rope != nullptr) {
-      // round 4: the projection's epilogue rotates q, k and writes V blocked-transposed itself (gemm.hip: vit_qkv_epilogue); weight rows
-      // and bias in the rotation-pair order (`vit.<i>.qkv_w_rope` / `qkv_b_rope`).  The V columns of `qkv` are not written.
-      g.W = L.qkv_w_rope; g.bias = L.qkv_b_rope; g.epilogue = GEMM_EPI_VIT_QKV;
-      g.vq.cs = rope_cos; g.vq.sn = rope_sin; g.vq.seg_of_patch = d_seg_of_patch; g.vq.seg_start = d_seg_start; g.vq.seg_blk = d_seg_blk;
-      g.vq.vt = vt; g.vq.total_blocks = blocks; g.vq.E = E;
-      LCC_TRY(gemm_bf16(g, st));
+      // round 4: the projection's epilogues rotate q, k and write V blocked-transposed themselves (gemm.hip: vit_qk_epilogue / vit_v_epilogue):
+      // over the weight copy in the rotation-pair row order (`vit.<i>.qkv_w_rope` / `qkv_b_rope`; V rows = rows 2E.. of the packed copy).  The V columns of `qkv` are not written.
+      g.W = L.qkv_w_rope; g.bias = L.qkv_b_rope;
+      g.vq.cs = rope_cos; g.vq.sn = rope_sin; g.vq.grp_off = d_grp_off; g.vq.vt = vt; g.vq.total_blocks = blocks; g.vq.E = E;
+      if ((E & 127) == 0) {      // q, k and V column tiles never share a 256-column block: one launch
+        g.epilogue = GEMM_EPI_VIT_QKV;
+        LCC_TRY(gemm_bf16(g, st));
+      } else {
+        g.N = 2 * E; g.epilogue = GEMM_EPI_VIT_QK;
+        LCC_TRY(gemm_bf16(g, st));
+        g.W = L.qkv_w_rope + (size_t)2 * E * E; g.bias = L.qkv_b_rope + 2 * E; g.N = E; g.C = nullptr; g.epilogue = GEMM_EPI_VIT_V;
+        LCC_TRY(gemm_bf16(g, st));
+      }
     } else {
       LCC_TRY(gemm_bf16(g, st));
       LCC_TRY(vit_rope_vt_bf16(qkv, rope_cos, rope_sin, d_seg_of_patch, d_seg_start, d_seg_blk, vt, P, heads, blocks, st));

@@ -107,90 +107,89 @@ LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[AM][AN], int mbase, int nbase, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// EPI_VIT_QKV (round 4): the vision tower's q|k|v projection writes what its attention kernels read -- q and k rotated (2-D RoPE,
-// HF modeling_qwen2_vl.py:225-248) at their natural columns of C, V blocked-transposed into vt[head][32-key block][80][32] -- instead
-// of a plain [P, 3E] tensor that vit_rope_vt_kernel re-reads and re-writes (55 us per tower block at 8 streams, 179 MB of traffic).
+// EPI_VIT_QK / EPI_VIT_V (round 4): the vision tower's q|k|v projection writes what its attention kernels read -- q and k rotated (2-D
+// RoPE, HF modeling_qwen2_vl.py:225-248) at their natural columns of C, V blocked-transposed into vt[head][32-key block][80][32] -- instead
+// of a plain [P, 3E] tensor that vit_rope_vt_kernel re-reads and re-writes (52 us per tower block at 8 streams, 179 MB of traffic).
+// Two launches of gemm_big_kernel over the `qkv_w_rope` copy of the weight (weights.py: vit_qkv_rope_row_permutation):
 //
-// W rows (and bias) arrive in the `qkv_w_rope` order (weights.py: vit_qkv_rope_row_permutation): inside q and inside k every 32 stored
-// rows are [16 first-half channels | their 16 rotation partners], first-half channels enumerated head-major (f = head * 40 + c, c < 40),
-// so a lane's accumulators acc[i][j] / acc[i][j + 1] hold (x[c .. c+3], x[c+40 .. c+43]) of one head: the rotation is register-local.
-// 40 % 4 == 0, so a lane's four channels never straddle a head.  V rows keep their natural order; the 4 x 4 (patch x channel) block a
-// quad of lanes holds is transposed with two cross-lane exchanges so that each lane stores 4 consecutive keys of one channel (8 bytes,
-// four lanes = 32 contiguous bytes, the store granularity of the plain epilogue).  Segment lengths are multiples of 4 (H and W are
-// multiples of 28), so a 4-patch group never straddles a segment or a 32-key block.
+//  * q|k (N = 2E, EPI_VIT_QK): inside q and inside k every 32 stored rows are [16 first-half channels | their 16 rotation partners],
+//    first-half channels enumerated head-major (f = head * 40 + c, c < 40), so a lane's accumulators acc[i][j] / acc[i][j + 1] hold
+//    (x[c .. c+3], x[c+40 .. c+43]) of one head: the rotation is register-local (40 % 4 == 0: a lane's four channels never straddle a
+//    head).  The block's cos / sin rows (BM x 40 fp32 each, one contiguous piece of the tables) are DMA'd into the LDS the k-loop has
+//    finished with: the first version loaded them per (row tile, column pair) from global memory and hipcc put an s_waitcnt vmcnt(0)
+//    -- which on gfx9 also waits for the previous iteration's STORES -- into each of the 16 iterations (+15 us on a 137-us GEMM).
+//  * V (N = E, EPI_VIT_V): the MFMA operands are swapped (activations as the A operand), so a lane holds 4 consecutive PATCHES of one
+//    channel -- 8 contiguous bytes of vt, four lanes = 32 contiguous bytes, the store granularity of the plain epilogue -- and no
+//    transpose is needed.  Same products, same k order: same bits.  grp_off[p / 4] = element offset of patch p's key slot inside a
+//    (head, channel 0) plane of vt; segment lengths are multiples of 4 (H, W multiples of 28), so a 4-patch group never straddles a
+//    segment or a 32-key block.
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NT>
-LCC_DEVICE void vit_qkv_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int g, const bf16_t* __restrict__ bias,
-                                 bf16_t* __restrict__ C, int ldc, int M, int N, const VitQkvEpi& vq) {
-  const int E = vq.E;
-  const int q4 = li & 3, m4off = li & ~3;
-  // V columns in this wave's 64-column strip?  Then: segment of every 4-patch group this lane will store.
-  int vblk[MT], vkl[MT];
-  if (nbase + NT * 16 > 2 * E) {
+LCC_DEVICE void vit_qk_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int mrow0, int li, int g, const bf16_t* __restrict__ bias,
+                                bf16_t* __restrict__ C, int ldc, int M, int N, int E, const float* lcs, const float* lsn) {
+  u32x2 b1[NT / 2], b2[NT / 2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m4 = min(mbase + i * 16 + m4off, M - 4);
-      const int sg = vq.seg_of_patch[m4];
-      const int kl = m4 - vq.seg_start[sg];
-      vblk[i] = vq.seg_blk[sg] + (kl >> 5);
-      vkl[i] = kl & 31;
-    }
+  for (int jp = 0; jp < NT / 2; ++jp) {
+    b1[jp] = (u32x2){0u, 0u}; b2[jp] = (u32x2){0u, 0u};
+    const int n = min(nbase + jp * 32, N - 32);
+    if (bias != nullptr) { b1[jp] = ld8(bias + n + g * 4); b2[jp] = ld8(bias + n + 16 + g * 4); }
   }
 #pragma unroll
-  for (int j = 0; j < NT; j += 2) {
+  for (int jp = 0; jp < NT / 2; ++jp) {
+    const int j = jp * 2;
     const int n = nbase + j * 16;            // first column of a 32-column group (wave-uniform)
     if (n >= N) continue;
-    if (n < 2 * E) {                         // ---- q or k: bias, bf16 rounding of the Linear output, rotation, one rounding
-      const int which = n >= E ? 1 : 0;
-      const int f = ((n - which * E) >> 5) * 16 + g * 4;
-      const int h = f / 40, c = f - h * 40;
-      u32x2 b1 = (u32x2){0u, 0u}, b2 = (u32x2){0u, 0u};
-      if (bias != nullptr) { b1 = ld8(bias + n + g * 4); b2 = ld8(bias + n + 16 + g * 4); }
-      bf16_t* out = C + which * E + h * 80 + c;
+    const int which = n >= E ? 1 : 0;
+    const int f = ((n - which * E) >> 5) * 16 + g * 4;
+    const int h = f / 40, c = f - h * 40;
+    bf16_t* out = C + which * E + h * 80 + c;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = mbase + i * 16 + li;
-        const int mc = min(m, M - 1);
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(vq.cs + (size_t)mc * 40 + c);
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(vq.sn + (size_t)mc * 40 + c);
-        float x1[4], x2[4], o1[4], o2[4];
-        x1[0] = rbf(acc[i][j][0] + lo2f(b1.x)); x1[1] = rbf(acc[i][j][1] + hi2f(b1.x));
-        x1[2] = rbf(acc[i][j][2] + lo2f(b1.y)); x1[3] = rbf(acc[i][j][3] + hi2f(b1.y));
-        x2[0] = rbf(acc[i][j + 1][0] + lo2f(b2.x)); x2[1] = rbf(acc[i][j + 1][1] + hi2f(b2.x));
-        x2[2] = rbf(acc[i][j + 1][2] + lo2f(b2.y)); x2[3] = rbf(acc[i][j + 1][3] + hi2f(b2.y));
+    for (int i = 0; i < MT; ++i) {
+      const int m = mbase + i * 16 + li;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(lcs + (mrow0 + i * 16 + li) * 40 + c);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(lsn + (mrow0 + i * 16 + li) * 40 + c);
+      float x1[4], x2[4], o1[4], o2[4];
+      x1[0] = rbf(acc[i][j][0] + lo2f(b1[jp].x)); x1[1] = rbf(acc[i][j][1] + hi2f(b1[jp].x));
+      x1[2] = rbf(acc[i][j][2] + lo2f(b1[jp].y)); x1[3] = rbf(acc[i][j][3] + hi2f(b1[jp].y));
+      x2[0] = rbf(acc[i][j + 1][0] + lo2f(b2[jp].x)); x2[1] = rbf(acc[i][j + 1][1] + hi2f(b2[jp].x));
+      x2[2] = rbf(acc[i][j + 1][2] + lo2f(b2[jp].y)); x2[3] = rbf(acc[i][j + 1][3] + hi2f(b2[jp].y));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vit_rope_pair(x1[r], x2[r], cv[r], sv[r], o1[r], o2[r]);
-        if (m < M) {
-          st8(out + (size_t)m * ldc, (u32x2){pack2(o1[0], o1[1]), pack2(o1[2], o1[3])});
-          st8(out + (size_t)m * ldc + 40, (u32x2){pack2(o2[0], o2[1]), pack2(o2[2], o2[3])});
-        }
+      for (int r = 0; r < 4; ++r) vit_rope_pair(x1[r], x2[r], cv[r], sv[r], o1[r], o2[r]);
+      if (m < M) {
+        st8(out + (size_t)m * ldc, (u32x2){pack2(o1[0], o1[1]), pack2(o1[2], o1[3])});
+        st8(out + (size_t)m * ldc + 40, (u32x2){pack2(o2[0], o2[1]), pack2(o2[2], o2[3])});
       }
-    } else {                                 // ---- V: bias, rounding, 4 x 4 transpose inside the quad, 4 keys of one channel per lane
+    }
+  }
+}
+
+// swapped operands: acc[i][j][r] = C[mbase + i*16 + g*4 + r][nbase + j*16 + li]
+template <int MT, int NT>
+LCC_DEVICE void vit_v_epilogue(const f32x4 (&acc)[MT][NT], int mbase, int nbase, int li, int g, const bf16_t* __restrict__ bias, int M, int N,
+                               const VitQkvEpi& vq) {
+  int off[MT];
 #pragma unroll
-      for (int jj = j; jj < j + 2; ++jj) {
-        const int nn = nbase + jj * 16 + g * 4;
-        u32x2 bv = (u32x2){0u, 0u};
-        if (bias != nullptr) bv = ld8(bias + nn);
-        const int col = nn - 2 * E + q4;     // this lane's channel after the transpose
-        const int h = col / 80, c = col - h * 80;
-        bf16_t* base = vq.vt + ((size_t)h * vq.total_blocks * 80 + c) * 32;
+  for (int i = 0; i < MT; ++i) off[i] = vq.grp_off[min(mbase + i * 16 + g * 4, M - 4) >> 2];
+  bf16_t braw[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          // lane (a, q) holds Y[q][r] = X[patch 4a + q][channel g*4 + r]; a0 = (Y[q][0], Y[q][1]), a1 = (Y[q][2], Y[q][3])
-          const unsigned a0 = pack2(acc[i][jj][0] + lo2f(bv.x), acc[i][jj][1] + hi2f(bv.x));
-          const unsigned a1 = pack2(acc[i][jj][2] + lo2f(bv.y), acc[i][jj][3] + hi2f(bv.y));
-          // exchange 1 (lane ^ 1): odd lanes send their even elements, even lanes their odd ones
-          const unsigned s1 = (q4 & 1) ? ((a0 & 0xffffu) | (a1 << 16)) : ((a0 >> 16) | (a1 & 0xffff0000u));
-          const unsigned r1 = (unsigned)__shfl_xor((int)s1, 1, 64);
-          const unsigned b0 = (q4 & 1) ? ((r1 & 0xffffu) | (a0 & 0xffff0000u)) : ((a0 & 0xffffu) | (r1 << 16));
-          const unsigned b1w = (q4 & 1) ? ((r1 >> 16) | (a1 & 0xffff0000u)) : ((a1 & 0xffffu) | (r1 & 0xffff0000u));
-          // exchange 2 (lane ^ 2): lanes 0, 1 of the quad keep b0 and take the partner's b0; lanes 2, 3 keep b1 and take the partner's b1
-          const unsigned s2 = (q4 & 2) ? b0 : b1w;
-          const unsigned r2 = (unsigned)__shfl_xor((int)s2, 2, 64);
-          const u32x2 o = (q4 & 2) ? (u32x2){r2, b1w} : (u32x2){b0, r2};     // keys 4a .. 4a+3 of channel g*4 + q
-          if (mbase + i * 16 + m4off < M) st8(base + (size_t)vblk[i] * (80 * 32) + vkl[i], o);
-        }
-      }
+  for (int j = 0; j < NT; ++j) braw[j] = 0;
+  if (bias != nullptr) {      // one branch around the four loads (a select per column made hipcc wait for each load separately)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) braw[j] = bias[min(nbase + j * 16 + li, N - 1)];
+  }
+  float bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = bf2f(braw[j]);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = nbase + j * 16 + li;
+    const int nc = min(n, N - 1);
+    const int h = nc / 80, c = nc - h * 80;
+    bf16_t* base = vq.vt + ((size_t)h * vq.total_blocks * 80 + c) * 32;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const u32x2 o = (u32x2){pack2(acc[i][j][0] + bv[j], acc[i][j][1] + bv[j]), pack2(acc[i][j][2] + bv[j], acc[i][j][3] + bv[j])};
+      if (n < N && mbase + i * 16 + g * 4 < M) st8(base + off[i], o);
     }
   }
 }
@@ -446,14 +445,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
 // fragment read is one ds_read_b128 per 16 rows whose halves are converted to bf16 in registers, and the activation chunk
 // order follows PACKED8's k assignment (MFMA h of lane group g takes k = g*16 + h*8 ..).  Half the W bytes in L2 and LDS;
 // the stage shrinks to 48 KB (BM 256) so that three stages fit and one tile stays in flight across the barrier.
+// (the kernel proper is gemm_big_kernel below: it maps blockIdx to a tile (tm, tn) and runs this body -- once for every epilogue but
+// EPI_VIT_QKV, whose column tiles take the q|k body or the V body)
 template <int BM, int EPI, int SCHED, bool W8>
-__global__ __launch_bounds__(512) void gemm_big_kernel(
+LCC_DEVICE void gemm_big_body(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
-    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
-    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, VitQkvEpi vq) {
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tm, int tn,
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, const VitQkvEpi& vq) {
   constexpr int BN = 256, BK = 64, NSTAGE = (BM >= 192 && !W8) ? 2 : 3;     // BM 192 (round 4): 56-KB stages, two of them
   constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
+  constexpr bool SWAP = EPI == EPI_VIT_V;         // activations as the MFMA A operand: a lane ends with 4 consecutive rows of one column
   constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image
   constexpr int B_SUB = (BN / 16) * (W8 ? 1 : 2); // 1-KB fragment sub-tiles of the W tile
   constexpr int STAGE = A_UNITS + B_SUB * 64;     // 16-byte units per stage
@@ -462,13 +464,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
   constexpr int G = A_PER_WAVE + B_PER_WAVE;      // DMA instructions per wave per k-tile
   extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
 
-  const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;   // consecutive ids (one XCD) share the W panel
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -562,7 +557,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+          for (int j = 0; j < NT; ++j) acc[i][j] = SWAP ? mfma16(fa[i], fb[j], acc[i][j]) : mfma16(fb[j], fa[i], acc[i][j]);
       }
     } else {
       // explicit software pipeline of the fragment reads: the 8 W fragments of the k-tile are read up front, the activation
@@ -592,7 +587,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       for (int t = 0; t < 2 * MT; ++t) {
         if (t + 2 < 2 * MT) fa[(t + 2) % 3] = as_bf16x8(s[aoff[(t + 2) / MT] + ((t + 2) % MT) * 128]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[t % MT][j] = mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
+        for (int j = 0; j < NT; ++j) acc[t % MT][j] = SWAP ? mfma16(fa[t % 3], fb[t / MT][j], acc[t % MT][j]) : mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
         if (SCHED == 6 && t < G) {
           if (t < A_PER_WAVE)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t < A_PER_WAVE ? t : 0] + kt_dma * BK),
@@ -613,8 +608,53 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     }
   }
   if (SCHED == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies of the last iterations
-  if constexpr (EPI == EPI_VIT_QKV) vit_qkv_epilogue<MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, li, g, bias, C, ldc, M, N, vq);
-  else tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
+  if constexpr (EPI == EPI_VIT_QK) {
+    // cos / sin rows of this block -> LDS (the fragment stages are dead): rows m0 .. m0 + BM - 1 of the [P, 40] fp32 tables are one
+    // contiguous piece of BM * 10 16-byte units each; reads past the last row are clamped (those rows are never stored)
+    __builtin_amdgcn_s_barrier();
+    constexpr int UNITS = BM * 10;
+    const long first = (long)m0 * 10, last = (long)M * 10 - 1;
+    for (int t = wave; t * 64 < UNITS; t += 8) {
+      const long u = min(first + t * 64 + lane, last);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vq.cs + u * 4),
+                                       (__attribute__((address_space(3))) void*)(dsmem + t * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vq.sn + u * 4),
+                                       (__attribute__((address_space(3))) void*)(dsmem + UNITS + t * 64), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float* lcs = reinterpret_cast<const float*>(dsmem);
+    vit_qk_epilogue<MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, wm * WM, li, g, bias, C, ldc, M, N, vq.E, lcs, lcs + UNITS * 4);
+  } else if constexpr (EPI == EPI_VIT_V) {
+    vit_v_epilogue<MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, li, g, bias, M, N, vq);
+  } else tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
+}
+
+template <int BM, int EPI, int SCHED, bool W8>
+__global__ __launch_bounds__(512) void gemm_big_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
+    bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, VitQkvEpi vq) {
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;   // consecutive ids (one XCD) share the W panel
+  if constexpr (EPI == EPI_VIT_QKV) {
+    // one launch for q|k|v (N = 3E, 2E % 256 == 0): the column tiles of q and k run the rotation body, those of V the swapped-operand
+    // body on rows 2E.. of the packed weight -- a block-uniform choice made once, outside the k-loop
+    const int qk_tiles = (2 * vq.E) >> 8;
+    if (tn >= qk_tiles)
+      gemm_big_body<BM, EPI_VIT_V, SCHED, W8>(A, lda, W + (size_t)2 * vq.E * K, bias != nullptr ? bias + 2 * vq.E : nullptr, nullptr, 0, nullptr, 0, M,
+                                              vq.E, K, tm, tn - qk_tiles, nullptr, 0, nullptr, vq);
+    else
+      gemm_big_body<BM, EPI_VIT_QK, SCHED, W8>(A, lda, W, bias, nullptr, 0, C, ldc, M, 2 * vq.E, K, tm, tn, nullptr, 0, nullptr, vq);
+  } else {
+    gemm_big_body<BM, EPI, SCHED, W8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, tm, tn, partial, kt_per_split, wscale, vq);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1134,7 +1174,7 @@ void set_gemm_variant(int v) {
   g_gemm_sched = (v == 5 || v == 6) ? 0 : 1;
 }
 static bool big_eligible(const GemmArgs& a) { return a.w_packed && (a.K % 64) == 0 && a.M > 16; }
-static_assert(GEMM_EPI_VIT_QKV == (int)EPI_VIT_QKV, "kernels.h / common.h disagree");
+static_assert(GEMM_EPI_VIT_QK == (int)EPI_VIT_QK && GEMM_EPI_VIT_V == (int)EPI_VIT_V && GEMM_EPI_VIT_QKV == (int)EPI_VIT_QKV, "kernels.h / common.h disagree");
 // M > 64: up to 64 rows the plain projection runs on the weight-streaming kernels (another fp32 summation order, and the better shape for so
 // few rows) -- the fused form takes over where the plain one is an MFMA tile kernel, so both forms give the same bits
 bool gemm_vit_qkv_eligible(int M, int E, int K) { return K > 0 && (K % 64) == 0 && M > 64 && (M & 3) == 0 && E > 0 && (E & 31) == 0; }
@@ -1742,17 +1782,30 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if ((((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) != 0) return LCC_ERR_ALIGN;
   if (a.epilogue == EPI_SWIGLU && (a.N & 31)) return LCC_ERR_SHAPE;
   if (a.epilogue == EPI_RESIDUAL && a.residual == nullptr) return LCC_ERR_ARG;
-  if (a.epilogue == EPI_VIT_QKV) {   // vision-tower q|k|v projection with RoPE + V transpose in the epilogue: 8-wave kernel only
+  if (a.epilogue == EPI_VIT_QKV || a.epilogue == EPI_VIT_QK || a.epilogue == EPI_VIT_V) {
+    // vision-tower q|k|v projection with RoPE / the V transpose in the epilogue: all three in one launch (E % 128 == 0), or q|k and V apart
     const VitQkvEpi& q = a.vq;
-    if (!a.w_packed || a.partial != nullptr || !gemm_vit_qkv_eligible(a.M, q.E, a.K) || a.N != 3 * q.E || q.cs == nullptr || q.sn == nullptr ||
-        q.seg_of_patch == nullptr || q.seg_start == nullptr || q.seg_blk == nullptr || q.vt == nullptr || q.total_blocks <= 0)
-      return LCC_ERR_ARG;
-    if ((((uintptr_t)q.cs | (uintptr_t)q.sn) & 15) != 0 || ((uintptr_t)q.vt & 7) != 0 || (a.bias != nullptr && ((uintptr_t)a.bias & 7) != 0)) return LCC_ERR_ALIGN;
+    const bool all = a.epilogue == EPI_VIT_QKV, qk = all || a.epilogue == EPI_VIT_QK, v = all || a.epilogue == EPI_VIT_V;
+    if (!a.w_packed || a.partial != nullptr || !gemm_vit_qkv_eligible(a.M, q.E, a.K) || a.N != (all ? 3 : qk ? 2 : 1) * q.E || (all && (q.E & 127))) return LCC_ERR_ARG;
+    if (qk && (q.cs == nullptr || q.sn == nullptr || a.C == nullptr)) return LCC_ERR_ARG;
+    if (v && (q.grp_off == nullptr || q.vt == nullptr || q.total_blocks <= 0)) return LCC_ERR_ARG;
+    if (qk && (((uintptr_t)q.cs | (uintptr_t)q.sn) & 15) != 0) return LCC_ERR_ALIGN;
+    if ((v && ((uintptr_t)q.vt & 7) != 0) || (a.bias != nullptr && ((uintptr_t)a.bias & 7) != 0)) return LCC_ERR_ALIGN;
     g_launch_counts[LC_GEMM_VIT_QKV]++;
     const int big = big_tile_rows(a, 1);
-    if (big == 256) launch_big_s<256, EPI_VIT_QKV, 6, false>(a, st);
-    else if (big == 192) launch_big_s<192, EPI_VIT_QKV, 6, false>(a, st);
-    else launch_big_s<128, EPI_VIT_QKV, 6, false>(a, st);
+    if (a.epilogue == EPI_VIT_QKV) {
+      if (big == 256) launch_big_s<256, EPI_VIT_QKV, 6, false>(a, st);
+      else if (big == 192) launch_big_s<192, EPI_VIT_QKV, 6, false>(a, st);
+      else launch_big_s<128, EPI_VIT_QKV, 6, false>(a, st);
+    } else if (qk) {
+      if (big == 256) launch_big_s<256, EPI_VIT_QK, 6, false>(a, st);
+      else if (big == 192) launch_big_s<192, EPI_VIT_QK, 6, false>(a, st);
+      else launch_big_s<128, EPI_VIT_QK, 6, false>(a, st);
+    } else {
+      if (big == 256) launch_big_s<256, EPI_VIT_V, 6, false>(a, st);
+      else if (big == 192) launch_big_s<192, EPI_VIT_V, 6, false>(a, st);
+      else launch_big_s<128, EPI_VIT_V, 6, false>(a, st);
+    }
     return 0;
   }
   // weight-streaming path: up to g_skinny_rows rows (64: decode batches of 17-64 streams multiply every weight fragment with 2-4 activation

@@ -27,7 +27,7 @@ enum LaunchCounter {
   LC_GEMM_TALL = 12,
   LC_ATTN_VIT32 = 13,          // attn_vit32_kernel (vision attention on 32x32x16 MFMAs)
   LC_GEMM_PP = 14,             // gemm_pp_kernel (256 x 256 tile, ping-pong wave groups)
-  LC_GEMM_VIT_QKV = 15,        // gemm_big_kernel with the EPI_VIT_QKV epilogue (RoPE + V transpose fused into the q|k|v projection)
+  LC_GEMM_VIT_QKV = 15,        // gemm_big_kernel with the EPI_VIT_QK / EPI_VIT_V epilogues (RoPE / V transpose fused into the q|k|v projection; 2 per tower block)
   LC_COUNT = 16
 };
 extern long long g_launch_counts[LC_COUNT];
@@ -53,15 +53,14 @@ struct GemvTail {
   const int32_t* tok_stream = nullptr; const int32_t* tok_pos = nullptr; const int32_t* kv_len = nullptr;
   bf16_t* const* kv_base = nullptr; KvLayout lay = {0, 0, 0, 0}; int layer = 0; bf16_t* q_out = nullptr; int n_q_heads = 0;
 };
-constexpr int GEMM_EPI_VIT_QKV = 6;   // GemmArgs::epilogue value of the internal EPI_VIT_QKV epilogue (common.h; the public LCC_EPI_* codes are 0-4)
-// extra operands of the EPI_VIT_QKV epilogue (vision-tower q|k|v projection with 2-D RoPE and the V transpose fused in)
+constexpr int GEMM_EPI_VIT_QK = 6, GEMM_EPI_VIT_V = 7, GEMM_EPI_VIT_QKV = 8;   // GemmArgs::epilogue values of the internal vision q|k / V epilogues (common.h; the public LCC_EPI_* codes are 0-4)
+// extra operands of the EPI_VIT_QK / EPI_VIT_V epilogues (vision-tower q|k|v projection with 2-D RoPE and the V transpose fused in)
 struct VitQkvEpi {
-  const float* cs = nullptr; const float* sn = nullptr;   // fp32 [P, 40]: cos / sin of the 40 rotation pairs of a head (head_dim 80)
-  const int32_t* seg_of_patch = nullptr;                  // [P]: attention segment (one temporal grid slice) of every patch
-  const int32_t* seg_start = nullptr;                     // [n_seg]: first patch of the segment
-  const int32_t* seg_blk = nullptr;                       // [n_seg]: first 32-key block of the segment in vt
+  const float* cs = nullptr; const float* sn = nullptr;   // QK: fp32 [P, 40]: cos / sin of the 40 rotation pairs of a head (head_dim 80)
+  const int32_t* grp_off = nullptr;                       // V: [P / 4]: element offset of patch 4i's key slot inside a (head, channel 0) plane of vt
+                                                          //    = (first block of its segment + local index / 32) * 80 * 32 + local index % 32
   bf16_t* vt = nullptr; int total_blocks = 0;             // V blocked-transposed [head][block][80][32]
-  int E = 0;                                              // embed dim (N = 3E)
+  int E = 0;                                              // embed dim (QK: N = 2E, V: N = E, QKV: N = 3E with E % 128 == 0)
 };
 struct GemmArgs {
   const bf16_t* A = nullptr; int lda = 0;       // [M,K]
@@ -78,10 +77,10 @@ struct GemmArgs {
   // (y[n] = wscale[n] * sum_k x[k] q[n][k]); M > 16 needs dq_scratch = N*K bf16 (exact dequantisation into the bf16 packed
   // order, then the bf16 GEMM with the scale in its epilogue)
   int w_fp8 = 0; const float* wscale = nullptr; bf16_t* dq_scratch = nullptr;
-  VitQkvEpi vq;                                 // epilogue == EPI_VIT_QKV only
+  VitQkvEpi vq;                                 // epilogue == GEMM_EPI_VIT_QK / GEMM_EPI_VIT_V only
 };
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
-bool gemm_vit_qkv_eligible(int M, int E, int K);   // shapes the EPI_VIT_QKV epilogue serves (8-wave kernel: K % 64 == 0; M > 64, M % 4 == 0, E % 32 == 0)
+bool gemm_vit_qkv_eligible(int M, int E, int K);   // shapes the EPI_VIT_QK / EPI_VIT_V epilogues serve (8-wave kernel: K % 64 == 0; M > 64, M % 4 == 0, E % 32 == 0)
 int gemv_num_splits(int N, int K);
 int gemm_tiled_num_splits(int M, int N, int K);
 void set_gemv_variant(int v);

@@ -1,5 +1,5 @@
-"""-m gpu: the vision tower's q|k|v projection with the 2-D RoPE and the V transpose in its own epilogue (csrc/gemm.hip: vit_qkv_epilogue,
-`vit.<i>.qkv_w_rope`) against the separate-launch form (projection -> lcc_vit_rope_vt_bf16): BIT-IDENTICAL tower outputs.  The separate
+"""-m gpu: the vision tower's q|k|v projection with the 2-D RoPE and the V transpose in its own epilogues (csrc/gemm.hip: vit_qk_epilogue /
+vit_v_epilogue over `vit.<i>.qkv_w_rope`) against the separate-launch form (projection -> lcc_vit_rope_vt_bf16): BIT-IDENTICAL tower outputs.  The separate
 form is the one every parity test against HF (Q2VL:225-248, 342-449) has exercised since round 1; it stays selectable
 (lcc_debug_set_vit_fused_qkv(0) / LCC_VIT_FUSED_QKV=0)."""
 import pytest
@@ -50,7 +50,7 @@ def test_fused_qkv_epilogue_is_bit_identical_to_the_separate_launches_small(dev,
     plain, fused, c0, c1 = _both(native, _clips(shapes, dev, seed=11))
     patches = sum(((T + 1) // 2) * (H // 14) * (W // 14) for T, H, W in shapes)
     # up to 64 patches the projection stays on the weight-streaming kernels and the separate RoPE launch (gemm_vit_qkv_eligible)
-    assert c0["gemm_vit_qkv"] == 0 and c1["gemm_vit_qkv"] == (cfg.vit_depth if patches > 64 else 0), (c0, c1)
+    assert c0["gemm_vit_qkv"] == 0 and c1["gemm_vit_qkv"] == (2 * cfg.vit_depth if patches > 64 else 0), (c0, c1)      # E = 320: a q|k launch + a V launch per block
     assert torch.isfinite(fused.float()).all()
     assert torch.equal(plain, fused)
 
@@ -64,7 +64,7 @@ def test_fused_qkv_epilogue_is_bit_identical_at_7b_shapes(dev, streams):
     native = _model(cfg, dev, max_patches=16384)
     clips = _clips([(2, 392, 728)] * streams, dev, seed=21)
     plain, fused, c0, c1 = _both(native, clips)
-    assert c0["gemm_vit_qkv"] == 0 and c1["gemm_vit_qkv"] == cfg.vit_depth
+    assert c0["gemm_vit_qkv"] == 0 and c1["gemm_vit_qkv"] == cfg.vit_depth         # E % 128 == 0: q, k and V tiles in ONE launch per block
     assert torch.equal(plain, fused)
     from livecc_amd import ops
     ms = {}

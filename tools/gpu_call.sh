@@ -77,8 +77,10 @@ vitq)        # q|k|v projection of the vision tower with RoPE + V transpose in i
              # tower / HF parity tests that run through it, then the 8-stream bench A/B
   timeout 600 python -m pytest tests/test_gpu_vit_fused.py -m gpu -q --timeout 500 > $O/vitq.log 2>&1; tail -n 12 $O/vitq.log; cp gpurun_out/parity_report.json $O/parity_vitq.json; grep -A12 vit_tower_fused $O/parity_vitq.json | head -40
   timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_e2e.py -m gpu -q --timeout 500 -k "vit_rope or vit_features or prefetch or teacher" > $O/vitq2.log 2>&1; tail -n 4 $O/vitq2.log
-  shift $# ; for KV in LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1 LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8s_$KV.log 2>&1; echo "== 8 streams $KV: $(val $O/bench_8s_$KV.log value) tok/s"; done
-  for KV in LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_$KV.log 2>&1; echo "== 1 stream $KV: $(val $O/bench_1s_$KV.log value) tok/s"; done ;;
+  if [ "${1:-}" = "bench" ]; then
+    for KV in LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1 LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8s_$KV.log 2>&1; echo "== 8 streams $KV: $(val $O/bench_8s_$KV.log value) tok/s"; done
+    for KV in LCC_VIT_FUSED_QKV=0 LCC_VIT_FUSED_QKV=1; do ( env $KV timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_$KV.log 2>&1; echo "== 1 stream $KV: $(val $O/bench_1s_$KV.log value) tok/s"; done
+  fi ;;
 vitprof)     # kernel stats of the vision tower alone, fused and separate q|k|v epilogue: bash tools/gpu_call.sh vitprof <streams>
   N=${1:-8}; cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/s$N -o tower -- python $R/tools/vit_tower_target.py $N > $O/tower_$N.log 2> $O/tower_$N.err
@@ -90,6 +92,12 @@ for r in rows[:16]:
     print("%-110s calls %5s avg %9.2f us total %9.1f us" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3))
 PY
   cd $R ;;
+final)       # end-of-round validation of the final tree, most important first: GPU tier, smoke, the driver's bench line, kernel stats of the bench
+  ( time timeout 1100 python -m pytest tests -x -q -m gpu --durations=15 ) > $O/test_full.log 2>&1; echo "tests rc=$?" >> $O/test_full.log; tail -n 8 $O/test_full.log
+  ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; tail -n 2 $O/smoke.log
+  ( time timeout 1200 python bench.py ) > $O/bench_default.log 2>$O/bench_default.err; grep '^{' $O/bench_default.log | tail -n 1 | cut -c1-2500
+  cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 1 --warmup 1 --cpu-baseline off --parity off --share8 off > $O/bench_under_rocprof.json 2> $O/stats.err
+  S=$(find $O/stats -name '*kernel_stats.csv' | head -1); [ -n "$S" ] && cp $S $O/bench_kernel_stats.csv; rm -rf $O/stats; head -n 8 $O/bench_kernel_stats.csv | cut -c1-200; cd $R ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
