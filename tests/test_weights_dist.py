@@ -187,3 +187,36 @@ def test_vit_rope_copy_is_the_row_permuted_qkv_weight_in_rotation_pair_order():
         for l in range(cfg.vit_depth):
             assert torch.equal(arena.logical(f"vit.{l}.qkv_w_rope"), arena.logical(f"vit.{l}.qkv_w")[perm])
             assert torch.equal(arena.view(f"vit.{l}.qkv_b_rope"), arena.view(f"vit.{l}.qkv_b")[perm])
+
+
+def test_rotation_in_the_stored_row_order_equals_hf_rotate_half():
+    """What the q|k|v GEMM epilogue does with the `qkv_w_rope` order, restated on the CPU: take the projection output in STORED column order,
+    rotate every (column t, column t + 16) pair of a 32-column group with the cos / sin of channel c = f % 40 (f = group * 16 + t), store the
+    results at natural columns head * 80 + c and + 40 -- and compare with HF's apply_rotary_pos_emb_vision formula
+    q * cos + rotate_half(q) * sin on the natural layout (modeling_qwen2_vl.py:225-248)."""
+    from livecc_amd.weights import vit_qkv_rope_row_permutation
+    cfg = tiny()
+    E, heads = cfg.vit_embed_dim, cfg.vit_num_heads
+    perm = vit_qkv_rope_row_permutation(cfg)
+    g = torch.Generator().manual_seed(0)
+    P = 12
+    x = torch.randn(P, 3 * E, generator=g)                      # natural-order Linear output
+    ang = torch.randn(P, 40, generator=g)
+    cos, sin = ang.cos(), ang.sin()
+    # HF: cos / sin = cat(freqs, freqs) over the 80 channels of a head; rotate_half(q) = cat(-q[40:], q[:40])
+    qk = x[:, :2 * E].view(P, 2 * heads, 80)
+    c80, s80 = torch.cat([cos, cos], -1)[:, None, :], torch.cat([sin, sin], -1)[:, None, :]
+    want = (qk * c80 + torch.cat([-qk[..., 40:], qk[..., :40]], -1) * s80).reshape(P, 2 * E)
+    # the epilogue's view
+    xs = x[:, perm]
+    got = torch.full((P, 2 * E), float("nan"))
+    for n in range(0, 2 * E, 32):
+        which = n // E
+        for t in range(16):
+            f = ((n - which * E) // 32) * 16 + t
+            h, c = f // 40, f % 40
+            x1, x2 = xs[:, n + t], xs[:, n + 16 + t]
+            got[:, which * E + h * 80 + c] = x1 * cos[:, c] - x2 * sin[:, c]
+            got[:, which * E + h * 80 + c + 40] = x2 * cos[:, c] + x1 * sin[:, c]
+    assert torch.equal(got, want)
+    assert torch.equal(xs[:, 2 * E:], x[:, 2 * E:])             # V columns are not permuted
