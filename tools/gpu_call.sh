@@ -98,6 +98,10 @@ final)       # end-of-round validation of the final tree, most important first: 
   ( time timeout 1200 python bench.py ) > $O/bench_default.log 2>$O/bench_default.err; grep '^{' $O/bench_default.log | tail -n 1 | cut -c1-2500
   cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 1 --warmup 1 --cpu-baseline off --parity off --share8 off > $O/bench_under_rocprof.json 2> $O/stats.err
   S=$(find $O/stats -name '*kernel_stats.csv' | head -1); [ -n "$S" ] && cp $S $O/bench_kernel_stats.csv; rm -rf $O/stats; head -n 8 $O/bench_kernel_stats.csv | cut -c1-200; cd $R ;;
+variants)    # the bench variants of DESIGN section 6 that the vision-tower change moves: 8 and 32 streams, one stream without the prefetch
+  ( $B --steps 1 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8streams.log 2>&1; echo "8 streams: $(val $O/bench_8streams.log value)"
+  ( $B --steps 1 --warmup 0 --streams-per-gpu 32 --share8 off ) > $O/bench_32streams.log 2>&1; echo "32 streams: $(val $O/bench_32streams.log value)"
+  ( $B --steps 2 --warmup 1 --no-prefetch --share8 off ) > $O/bench_noprefetch.log 2>&1; echo "1 stream, no prefetch: $(val $O/bench_noprefetch.log value)" ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
