@@ -68,6 +68,25 @@ for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
 print(json.dumps({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}, indent=1))
 PY
   cat $O/gemv_rows_counters.json; rm -rf $O/p*/; cd $R ;;
+pmc_attn)    # counters of the decode attention (attn_decode_kernel + combine) at L = 6.5k, one stream: one pass per group
+  cd /tmp; i=0
+  for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE"; do
+    i=$((i+1)); timeout 100 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p$i -o attn -- python $R/tools/pmc_target.py --attn-decode > $O/p$i.log 2>&1 || echo "pass $i ($C) failed: $(tail -n 1 $O/p$i.log)"
+    find $O/p$i -name '*kernel_trace.csv' -delete
+  done
+  python - <<PY > $O/attn_decode_counters.json
+import csv, glob, json, collections
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r.get("Kernel_Name", "")
+        if "attn_decode" in kn:
+            key = kn.split("(")[0].replace("void lcc::", "").replace("lcc::", "")[:60]
+            res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res[key]["duration_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+print(json.dumps({k: {c: sum(v[len(v) // 3:]) / len(v[len(v) // 3:]) for c, v in cs.items()} for k, cs in res.items()}, indent=1))
+PY
+  cat $O/attn_decode_counters.json; rm -rf $O/p*/; cd $R ;;
 b72)         # BASELINE.json configs[4]: Qwen2-VL-72B shapes, fp8 weights, the configs[1] protocol (60 frames), one stream on one GPU
   ( timeout 900 $B --config qwen2vl-72b --weights fp8 --steps 1 --warmup 1 --share8 off ) > $O/bench_72b_fp8.log 2>$O/bench_72b_fp8.err; tail -n 1 $O/bench_72b_fp8.log | cut -c1-2200; tail -n 3 $O/bench_72b_fp8.err ;;
 ab)          # A/B of an environment switch on the multi-stream bench: bash tools/gpu_call.sh ab <streams> VAR=a VAR=b ...

@@ -45,6 +45,21 @@ if "--gemv-rows" in sys.argv:
     torch.cuda.synchronize()
     print("ok")
     sys.exit(0)
+if "--attn-decode" in sys.argv:
+    # the per-wave decode attention + its split merge at the benchmark's mean cache length (one stream, L = 6,552 keys, 4 KV heads x 7 query
+    # heads, 52 key splits as the engine picks them): 13.4 MB of K + V per launch, rotated over 20 caches (268 MB > the Infinity Cache) so
+    # that the reads come from HBM as in a decode step, where 14.5 GB of weights pass between two uses of a layer's cache
+    NS, L, HQ, HKV = 20, 6552, 28, 4
+    kv = ops.KvArena(NS, 1, HKV, 8192, dev)
+    kv.buf.copy_((torch.randn(NS, kv.per_slot, device=dev) * 0.5).to(torch.bfloat16))
+    kv_len = torch.full((NS,), L, dtype=torch.int32, device=dev)
+    q = torch.randn(1, HQ * 128, device=dev).to(torch.bfloat16)
+    nsplit = min(64, ((L + 31) // 32 + 3) // 4)
+    for i in range(60):
+        ops.attn_decode(q, kv, 0, torch.tensor([i % NS], dtype=torch.int32, device=dev), kv_len, HQ, nsplit)
+    torch.cuda.synchronize()
+    print("ok", nsplit)
+    sys.exit(0)
 ws = [(torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
 x = torch.randn(1, H, device=dev).to(torch.bfloat16)
 nw = torch.ones(H, device=dev, dtype=torch.bfloat16)
