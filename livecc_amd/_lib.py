@@ -11,7 +11,8 @@ import re
 from typing import Dict, List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_C", "liblivecc_amd.so")
+# LCC_LIB_PATH: A/B runs of two builds of the library on one box (tools/); the product always loads the in-tree build
+LIB_PATH = os.environ.get("LCC_LIB_PATH") or os.path.join(_HERE, "_C", "liblivecc_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "livecc_amd.h")
 
 _lib = None

@@ -442,6 +442,10 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
       qf[n][ks] = (d0 < D) ? ld16(qrow0 + (size_t)r * qstride + d0) : (u32x4){0u, 0u, 0u, 0u};
     }
   }
+#pragma unroll
+  for (int n = 0; n < NQ; ++n)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) settle_load(qf[n][ks]);     // before the first LDS-DMA piece (common.h: glds16)
 
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn_zero_page) + lane * 8;
   // Per-lane source pointers of this wave's pieces for key tile 0 and their per-tile strides are computed ONCE: a DMA issue is
@@ -476,8 +480,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
       const bf16_t* src = pbase[j] + (size_t)tc * pstride[j];
       if (MODE == 0 && tc == ntile - 1 && pkey0[j] >= 0 && pd0[j] < D)
         src = kbase + (size_t)min(tc * 32 + pkey0[j], nkeys - 1) * kstride + pd0[j];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
+      glds16(src, lds_addr(sbase + p * 64));
     }
   };
 

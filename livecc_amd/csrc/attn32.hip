@@ -198,6 +198,8 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
     const bf16_t* qp = q + (size_t)(q0 + qr) * ldq + h * D + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < KP; ++ks) qf[ks] = ld16(qp + ks * 16);
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) settle_load(qf[ks]);     // before the first LDS-DMA piece (common.h: glds16)
   }
 
   // DMA sources of this wave's pieces for key tile 0 + per-tile strides (computed once: a DMA issue is one multiply-add per piece).
@@ -222,8 +224,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const int p = min(j * NWAVE + wave, NP - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pbase[j] + (size_t)tc * pstride[j]),
-                                       (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
+      glds16((pbase[j] + (size_t)tc * pstride[j]), lds_addr(sbase + p * 64));
     }
   };
 
@@ -298,6 +299,8 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
     const bf16_t* qp = qkv + (size_t)(s0 + qrow) * ld + h * D + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < KP; ++ks) qf[ks] = ld16(qp + ks * 16);
+#pragma unroll
+    for (int ks = 0; ks < KP; ++ks) settle_load(qf[ks]);     // before the first LDS-DMA piece (common.h: glds16)
   }
   const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn32_zero_page) + lane * 8;
   const bf16_t* pbase[PW];
@@ -326,8 +329,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
       const bf16_t* src = pbase[j] + (size_t)tc * pstride[j];
       if (pkrow[j] >= 0 && tc == ntile - 1)              // last tile: rows past the segment end are clamped (and masked)
         src = kbase + (size_t)min(tc * 32 + pkrow[j], nkeys - 1) * ld + p * 16 + hh * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + p * 64), 16, 0, 0);
+      glds16(src, lds_addr(sbase + p * 64));
     }
   };
   f32x16 o[DT];

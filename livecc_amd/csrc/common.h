@@ -41,6 +41,26 @@ LCC_DEVICE void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 LCC_DEVICE u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
 LCC_DEVICE void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes at `gsrc` land at LDS byte address `lds_dst` + l * 16
+// (`lds_dst` wave-uniform).  INLINE ASM ON PURPOSE (round 5): the builtin is a FLAT-encoded instruction with an LDS memory operand, so
+// hipcc's waitcnt pass books it as "may access LDS through flat" -- from then on EVERY s_waitcnt it inserts in front of a ds_read
+// consumer is lgkmcnt(0) (and vmcnt(0) in front of the use of any plain load), i.e. the counted fragment-read pipelines of the MFMA
+// kernels collapsed into read-wait-use (ISA of gemm_big_kernel: an lgkmcnt(0) right behind the ds_read issued for two steps later, every
+// third row-tile step).  Hidden in an asm statement the DMA is absent from the compiler's bookkeeping: its completion is counted by
+// the kernels' own `s_waitcnt vmcnt(N)` + barrier (they did that already), and the ds_read waits become lgkmcnt(N) ladders.
+// M0 is saved and restored around the statement (cdna_hip_programming.md section 5.7); the s_nop covers the M0 write -> LDS-DMA hazard.
+LCC_DEVICE void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");   // readfirstlane: free when provably uniform
+}
+// Make the compiler wait HERE for a plain global load it is tracking (it must insert its own s_waitcnt in front of a statement that reads
+// the registers).  Needed wherever plain loads are followed by glds16() pieces: a vmcnt(N) the compiler places later -- at the first use
+// of the value, possibly inside the ring loop -- would also drain the LDS-DMAs it cannot see (vmcnt retires in order).
+LCC_DEVICE void settle_load(u32x4& v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
+// LDS byte address of a __shared__ object (wave-uniform when the pointer is)
+LCC_DEVICE unsigned lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+
 LCC_DEVICE f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

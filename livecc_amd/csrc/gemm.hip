@@ -375,16 +375,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
     for (int q = 0; q < A_PER_WAVE; ++q) {
       const int kb = kt * 2 + akb[q];
       const bf16_t* src = (kb * 32 + g * 8 < K) ? asrc[q] + kb * 32 : zp;   // A: K % 8 == 0, chunk inside or outside
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+      glds16(src, lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
     }
 #pragma unroll
     for (int q = 0; q < B_PER_WAVE; ++q) {
       const int kb = kt * 2 + bkb[q];
       const bool ok = w_packed ? (kb < K32) : (kb * 32 + g * 8 < K);
       const bf16_t* src = ok ? bsrc[q] + (size_t)kb * bstep : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + (A_SUB + wave * B_PER_WAVE + q) * 64), 16, 0, 0);
+      glds16(src, lds_addr(sbase + (A_SUB + wave * B_PER_WAVE + q) * 64));
     }
   };
 
@@ -447,7 +445,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
 // the stage shrinks to 48 KB (BM 256) so that three stages fit and one tile stays in flight across the barrier.
 // (the kernel proper is gemm_big_kernel below: it maps blockIdx to a tile (tm, tn) and runs this body -- once for every epilogue but
 // EPI_VIT_QKV, whose column tiles take the q|k body or the V body)
-template <int BM, int EPI, int SCHED, bool W8>
+template <int BM, int EPI, int SCHED, bool W8, int PF = 0>
 LCC_DEVICE void gemm_big_body(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
@@ -490,19 +488,66 @@ LCC_DEVICE void gemm_big_body(
     }
   }
 
+  // ---- PF > 0 (round 5, two 64-KB stages only): an L2 run-ahead.  With two stages a k-tile's DMA is issued one tile (~1 us) before it
+  // is needed, about the latency of a fill from HBM / the Infinity Cache under load (DMA ring alone 1.38 us per k-tile, profiles/r03/
+  // gemm_diag.jsonl), and the LDS has no room for a third stage.  So wave 7 issues no ring pieces: its LDS-DMA slots read one 16-byte
+  // piece of every 128-byte line of the tile PF tiles AHEAD of the ring into a 1-KB scratch -- the line is in this XCD's L2 when the
+  // ring asks for it -- and, having nothing else on its vmcnt queue (loads retire in order: a run-ahead piece in FRONT of ring pieces
+  // would have to land within one tile again), it never waits for them.  The 64 (56) ring pieces go to waves 0-6.  Every wave runs the
+  // same instruction stream over a per-wave piece table (source pointer, LDS destination, per-k-tile advance); surplus slots copy 16
+  // bytes of one line (all lanes the same address) into the scratch.
+  constexpr bool L2PF = PF > 0 && NSTAGE == 2 && !W8 && SCHED == 6;
+  constexpr int NPA = BM / 8, NPIECE = NPA + B_SUB, NSLOT = L2PF ? (NPIECE + 6) / 7 : 1;
+  static_assert(!L2PF || NSLOT <= 2 * MT, "one piece per row-tile step");
+  constexpr unsigned SCRATCH_BYTES = (unsigned)NSTAGE * STAGE * 16;          // 1 KB behind the stages (launcher: lds + 1024)
+  const bf16_t* psrc[NSLOT];
+  unsigned pdst[NSLOT];     // byte offset inside a stage, or 0xffffffff: the scratch
+  int pstep[NSLOT];         // elements per k-tile
+  int kcap = 0;             // largest k-tile index this wave's pieces may read (run-ahead: PF less)
+  if constexpr (L2PF) {
+    kcap = K / BK - 1 - (wave == 7 ? PF : 0);
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+      psrc[q] = A; pdst[q] = 0xffffffffu; pstep[q] = 0;
+      if (wave < 7) {
+        const int p = wave + 7 * q;
+        if (p < NPA) {                      // activation rows p*8 .. +7, swizzled full lines (as asrc above)
+          psrc[q] = A + (size_t)min(m0 + p * 8 + (lane >> 3), M - 1) * lda + (((lane & 7) ^ (lane >> 3)) << 3);
+          pdst[q] = (unsigned)p * 64 * 16; pstep[q] = BK;
+        } else if (p < NPIECE) {            // W sub-tile st: n-fragment row st >> 1, 32-k block st & 1
+          const int st = p - NPA, fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
+          psrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+          pdst[q] = (unsigned)(A_UNITS + st * 64) * 16; pstep[q] = 1024;
+        }
+      } else if (q < BM / 64) {             // run-ahead, activations: lane = one row's 128-byte line of the k-tile
+        psrc[q] = A + (size_t)min(m0 + q * 64 + lane, M - 1) * lda + PF * BK;
+        pstep[q] = BK;
+      } else if (q < BM / 64 + 4) {         // run-ahead, W: 4 fragment rows x 16 lines (one fragment row's k-tile = 2 KB contiguous)
+        const int fr = min((n0 >> 4) + (q - BM / 64) * 4 + (lane >> 4), nfrag - 1);
+        psrc[q] = W + (size_t)fr * K32 * 512 + (lane & 15) * 64 + PF * 1024;
+        pstep[q] = 1024;
+      }
+    }
+  }
+
   auto issue = [&](int kt, int stage) {
     u32x4* sbase = dsmem + stage * STAGE;
+    if constexpr (L2PF) {
+      const int kc = min(kt, kcap);
+#pragma unroll
+      for (int q = 0; q < NSLOT; ++q)
+        glds16(psrc[q] + (size_t)max(kc, 0) * pstep[q], pdst[q] == 0xffffffffu ? lds_addr(dsmem) + SCRATCH_BYTES : lds_addr(sbase) + pdst[q]);
+      return;
+    }
     if (SCHED != 5) {      // (SCHED 4 / 5: timing diagnostics, only the activation / only the W half of the DMA ring)
 #pragma unroll
     for (int q = 0; q < A_PER_WAVE; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[q] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+      glds16((asrc[q] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
     }
     if (SCHED != 4)
 #pragma unroll
     for (int q = 0; q < B_PER_WAVE; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * (W8 ? 512 : 1024)),
-                                       (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (wave * B_PER_WAVE + q) * 64), 16, 0, 0);
+      glds16((bsrc[q] + (size_t)kt * (W8 ? 512 : 1024)), lds_addr(sbase + A_UNITS + (wave * B_PER_WAVE + q) * 64));
   };
 
   f32x4 acc[MT][NT];
@@ -530,7 +575,7 @@ LCC_DEVICE void gemm_big_body(
       if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (G == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
+    } else if (!L2PF || wave != 7) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
@@ -583,19 +628,23 @@ LCC_DEVICE void gemm_big_body(
       // region): past the last tile the source is clamped and the copy lands in a stage nobody reads any more.
       const int kt_dma = min(kt + NSTAGE - 1, nkt - 1);
       u32x4* dma_base = dsmem + ((kt + NSTAGE - 1 - kt0) % NSTAGE) * STAGE;
+      const int kc_dma = L2PF ? __builtin_amdgcn_readfirstlane(max(min(kt_dma, kcap), 0)) : 0;
+      const unsigned dma_lds = lds_addr(dma_base), scratch_lds = lds_addr(dsmem) + SCRATCH_BYTES;
 #pragma unroll
       for (int t = 0; t < 2 * MT; ++t) {
         if (t + 2 < 2 * MT) fa[(t + 2) % 3] = as_bf16x8(s[aoff[(t + 2) / MT] + ((t + 2) % MT) * 128]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[t % MT][j] = SWAP ? mfma16(fa[t % 3], fb[t / MT][j], acc[t % MT][j]) : mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
-        if (SCHED == 6 && t < G) {
+        if constexpr (L2PF) {
+          if (t < NSLOT) {
+            const int q = t < NSLOT ? t : 0;
+            glds16(psrc[q] + (size_t)kc_dma * pstep[q], pdst[q] == 0xffffffffu ? scratch_lds : dma_lds + pdst[q]);
+          }
+        } else if (SCHED == 6 && t < G) {
           if (t < A_PER_WAVE)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t < A_PER_WAVE ? t : 0] + kt_dma * BK),
-                                             (__attribute__((address_space(3))) void*)(dma_base + (wave * A_PER_WAVE + t) * 64), 16, 0, 0);
+            glds16((asrc[t < A_PER_WAVE ? t : 0] + kt_dma * BK), lds_addr(dma_base + (wave * A_PER_WAVE + t) * 64));
           else
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(bsrc[t >= A_PER_WAVE ? t - A_PER_WAVE : 0] + (size_t)kt_dma * (W8 ? 512 : 1024)),
-                (__attribute__((address_space(3))) void*)(dma_base + A_UNITS + (wave * B_PER_WAVE + (t - A_PER_WAVE)) * 64), 16, 0, 0);
+            glds16((bsrc[t >= A_PER_WAVE ? t - A_PER_WAVE : 0] + (size_t)kt_dma * (W8 ? 512 : 1024)), lds_addr(dma_base + A_UNITS + (wave * B_PER_WAVE + (t - A_PER_WAVE)) * 64));
         }
       }
       __builtin_amdgcn_sched_group_barrier(0x100, (W8 ? NT : 2 * NT) + 2, 0);
@@ -603,7 +652,7 @@ LCC_DEVICE void gemm_big_body(
       for (int t = 0; t < 2 * MT; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-        if (SCHED == 6 && t < G) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one VMEM (the LDS-DMA piece)
+        if (SCHED == 6 && !L2PF && t < G) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one VMEM (the LDS-DMA piece)
       }
     }
   }
@@ -616,10 +665,8 @@ LCC_DEVICE void gemm_big_body(
     const long first = (long)m0 * 10, last = (long)M * 10 - 1;
     for (int t = wave; t * 64 < UNITS; t += 8) {
       const long u = min(first + t * 64 + lane, last);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vq.cs + u * 4),
-                                       (__attribute__((address_space(3))) void*)(dsmem + t * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vq.sn + u * 4),
-                                       (__attribute__((address_space(3))) void*)(dsmem + UNITS + t * 64), 16, 0, 0);
+      glds16((vq.cs + u * 4), lds_addr(dsmem + t * 64));
+      glds16((vq.sn + u * 4), lds_addr(dsmem + UNITS + t * 64));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -630,30 +677,43 @@ LCC_DEVICE void gemm_big_body(
   } else tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
-template <int BM, int EPI, int SCHED, bool W8>
+template <int BM, int EPI, int SCHED, bool W8, int PF = 0>
 __global__ __launch_bounds__(512) void gemm_big_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
-    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, VitQkvEpi vq) {
+    float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, VitQkvEpi vq, int raster) {
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;   // consecutive ids (one XCD) share the W panel
+  // tile id -> (tm, tn).  An XCD (one L2) runs a contiguous range of ids, ~32 of them at a time.
+  //   raster 0: column-major -- the 32 share ~2.5 W panels and ALL row panels (M = 3088: 13 + 2.5 panels of 1.8 MB per 32 tiles);
+  //   raster G (round 5): bands of G column tiles, row-major inside a band -- 32 consecutive ids are a (32 / G) x G super-tile
+  //   (G = 8: 4 + 8 panels per 32 tiles: 0.77 x the bytes from beyond the L2, and the four blocks of a W panel run side by side).
+  int tn, tm;
+  if (raster > 0) {
+    const int band = bid / (raster * tiles_m), rem = bid - band * raster * tiles_m;
+    const int bw = min(raster, tiles_n - band * raster);       // the last band may be narrower
+    tm = rem / bw;
+    tn = band * raster + (rem - tm * bw);
+  } else {
+    tn = bid / tiles_m;
+    tm = bid - tn * tiles_m;
+  }
   if constexpr (EPI == EPI_VIT_QKV) {
     // one launch for q|k|v (N = 3E, 2E % 256 == 0): the column tiles of q and k run the rotation body, those of V the swapped-operand
     // body on rows 2E.. of the packed weight -- a block-uniform choice made once, outside the k-loop
     const int qk_tiles = (2 * vq.E) >> 8;
     if (tn >= qk_tiles)
-      gemm_big_body<BM, EPI_VIT_V, SCHED, W8>(A, lda, W + (size_t)2 * vq.E * K, bias != nullptr ? bias + 2 * vq.E : nullptr, nullptr, 0, nullptr, 0, M,
-                                              vq.E, K, tm, tn - qk_tiles, nullptr, 0, nullptr, vq);
+      gemm_big_body<BM, EPI_VIT_V, SCHED, W8, PF>(A, lda, W + (size_t)2 * vq.E * K, bias != nullptr ? bias + 2 * vq.E : nullptr, nullptr, 0, nullptr, 0, M,
+                                                  vq.E, K, tm, tn - qk_tiles, nullptr, 0, nullptr, vq);
     else
-      gemm_big_body<BM, EPI_VIT_QK, SCHED, W8>(A, lda, W, bias, nullptr, 0, C, ldc, M, 2 * vq.E, K, tm, tn, nullptr, 0, nullptr, vq);
+      gemm_big_body<BM, EPI_VIT_QK, SCHED, W8, PF>(A, lda, W, bias, nullptr, 0, C, ldc, M, 2 * vq.E, K, tm, tn, nullptr, 0, nullptr, vq);
   } else {
-    gemm_big_body<BM, EPI, SCHED, W8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, tm, tn, partial, kt_per_split, wscale, vq);
+    gemm_big_body<BM, EPI, SCHED, W8, PF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, tm, tn, partial, kt_per_split, wscale, vq);
   }
 }
 
@@ -724,9 +784,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(
   auto issue = [&](int kt, u32x4* sbase, int j) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src[j][u] + (size_t)kt * ((j == 0 || j == 3) ? BK : 1024)),
-          (__attribute__((address_space(3))) void*)(sbase + dst[j][u]), 16, 0, 0);
+      glds16((src[j][u] + (size_t)kt * ((j == 0 || j == 3) ? BK : 1024)), lds_addr(sbase + dst[j][u]));
   };
 
   f32x4 acc[MT][NT];
@@ -863,13 +921,11 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
     u32x4* sbase = dsmem + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < A_PER_WAVE; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoffs[q] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+      glds16((A + aoffs[q] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       if (q < nb)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[q] + (size_t)kt * 1024),
-                                         (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (st0 + q) * 64), 16, 0, 0);
+        glds16((bsrc[q] + (size_t)kt * 1024), lds_addr(sbase + A_UNITS + (st0 + q) * 64));
   };
 
   // SCHED 2: the 10 pieces of a wave (7 activation + 3 W; waves 4-7 repeat their second W sub-tile as the third) go out ONE at a time
@@ -878,12 +934,10 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
   auto issue_piece = [&](int kt, int stage, int q) {
     u32x4* sbase = dsmem + stage * STAGE;
     if (q < A_PER_WAVE)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + aoffs[q < A_PER_WAVE ? q : 0] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + q) * 64), 16, 0, 0);
+      glds16((A + aoffs[q < A_PER_WAVE ? q : 0] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
     else {
       const int qq = min(q - A_PER_WAVE, nb - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[qq] + (size_t)kt * 1024),
-                                       (__attribute__((address_space(3))) void*)(sbase + A_UNITS + (st0 + qq) * 64), 16, 0, 0);
+      glds16((bsrc[qq] + (size_t)kt * 1024), lds_addr(sbase + A_UNITS + (st0 + qq) * 64));
     }
   };
   constexpr int NPIECE = A_PER_WAVE + 3;
@@ -1020,8 +1074,7 @@ __global__ __launch_bounds__(512) void gemm_tall4_kernel(
     u32x4* sbase = dsmem + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < PW; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (size_t)kt * kstep[q]),
-                                       (__attribute__((address_space(3))) void*)(sbase + dst[q]), 16, 0, 0);
+      glds16((src[q] + (size_t)kt * kstep[q]), lds_addr(sbase + dst[q]));
   };
 
   f32x4 acc[MT][NT0];
@@ -1112,18 +1165,32 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
       (nkt + S - 1) / S, a.wscale);
 }
 
-template <int BM, int EPI, int SCHED, bool W8>
+// round-5 tuning knobs of the 8-wave kernel (A/B: environment, read once): LCC_GEMM_RASTER = band width of the tile order (0: column-major),
+// LCC_GEMM_L2PF = run-ahead distance in k-tiles of the L2 prefetch wave (0: off; two-stage bf16 tiles with the spread DMA schedule only)
+static int g_gemm_raster = [] { const char* v = getenv("LCC_GEMM_RASTER"); return v ? atoi(v) : 0; }();
+static int g_gemm_l2pf = [] { const char* v = getenv("LCC_GEMM_L2PF"); return v ? atoi(v) : 0; }();
+template <int BM, int EPI, int SCHED, bool W8, int PF = 0>
 static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages
-  constexpr size_t lds = (size_t)((BM >= 192 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16;
+  // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages; PF: + 1 KB of scratch
+  constexpr size_t lds = (size_t)((BM >= 192 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16 + (PF > 0 ? 1024 : 0);
   static DeviceOnce attr_set;   // per instantiation
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
-      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq);
+  gemm_big_kernel<BM, EPI, SCHED, W8, PF><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq,
+      g_gemm_raster);
+}
+// the default schedule (SCHED 6) of a bf16 two-stage tile, with or without the L2 run-ahead wave
+template <int BM, int EPI>
+static void launch_big_6(const GemmArgs& a, hipStream_t st) {
+  if constexpr (BM >= 192) {
+    if (g_gemm_l2pf >= 3 && a.K / 64 >= 8) return launch_big_s<BM, EPI, 6, false, 3>(a, st);
+    if (g_gemm_l2pf >= 1 && a.K / 64 >= 8) return launch_big_s<BM, EPI, 6, false, 2>(a, st);
+  }
+  launch_big_s<BM, EPI, 6, false>(a, st);
 }
 // 0: gemm_big_kernel<256> (round 2/3), 1: gemm_pp_kernel (ping-pong wave groups), 2: the same with s_setprio(1) around the MFMA clusters.
 // LCC_GEMM_PP / lcc_debug_set_gemm_variant(10 / 11 / 12) select it.
@@ -1160,7 +1227,7 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
   // GEMMs, +0.6 / +0.8 % tokens/s at 1 / 8 streams, profiles/r03/gemm_sched_spread_dma.txt); LCC_GEMM_SCHED=1 restores SCHED 1
   static const int spread = [] { const char* v = getenv("LCC_GEMM_SCHED"); return (v && atoi(v) == 1) ? 0 : 1; }();
   if (a.w_fp8) launch_big_s<(BM == 192 ? 256 : BM), EPI, 1, true>(a, st);     // the 192-row tile is a bf16-weight shape (big_tile_rows never picks it for fp8)
-  else if (g_gemm_sched && spread) launch_big_s<BM, EPI, 6, false>(a, st);
+  else if (g_gemm_sched && spread) launch_big_6<BM, EPI>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
 }
@@ -1794,17 +1861,17 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
     g_launch_counts[LC_GEMM_VIT_QKV]++;
     const int big = big_tile_rows(a, 1);
     if (a.epilogue == EPI_VIT_QKV) {
-      if (big == 256) launch_big_s<256, EPI_VIT_QKV, 6, false>(a, st);
-      else if (big == 192) launch_big_s<192, EPI_VIT_QKV, 6, false>(a, st);
-      else launch_big_s<128, EPI_VIT_QKV, 6, false>(a, st);
+      if (big == 256) launch_big_6<256, EPI_VIT_QKV>(a, st);
+      else if (big == 192) launch_big_6<192, EPI_VIT_QKV>(a, st);
+      else launch_big_6<128, EPI_VIT_QKV>(a, st);
     } else if (qk) {
-      if (big == 256) launch_big_s<256, EPI_VIT_QK, 6, false>(a, st);
-      else if (big == 192) launch_big_s<192, EPI_VIT_QK, 6, false>(a, st);
-      else launch_big_s<128, EPI_VIT_QK, 6, false>(a, st);
+      if (big == 256) launch_big_6<256, EPI_VIT_QK>(a, st);
+      else if (big == 192) launch_big_6<192, EPI_VIT_QK>(a, st);
+      else launch_big_6<128, EPI_VIT_QK>(a, st);
     } else {
-      if (big == 256) launch_big_s<256, EPI_VIT_V, 6, false>(a, st);
-      else if (big == 192) launch_big_s<192, EPI_VIT_V, 6, false>(a, st);
-      else launch_big_s<128, EPI_VIT_V, 6, false>(a, st);
+      if (big == 256) launch_big_6<256, EPI_VIT_V>(a, st);
+      else if (big == 192) launch_big_6<192, EPI_VIT_V>(a, st);
+      else launch_big_6<128, EPI_VIT_V>(a, st);
     }
     return 0;
   }

@@ -121,6 +121,23 @@ variants)    # the bench variants of DESIGN section 6 that the vision-tower chan
   ( $B --steps 1 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8streams.log 2>&1; echo "8 streams: $(val $O/bench_8streams.log value)"
   ( $B --steps 1 --warmup 0 --streams-per-gpu 32 --share8 off ) > $O/bench_32streams.log 2>&1; echo "32 streams: $(val $O/bench_32streams.log value)"
   ( $B --steps 2 --warmup 1 --no-prefetch --share8 off ) > $O/bench_noprefetch.log 2>&1; echo "1 stream, no prefetch: $(val $O/bench_noprefetch.log value)" ;;
+r5a)         # round 5, call 1: LDS-DMA through inline asm (counted lgkmcnt ladders) vs the round-4 build; raster / L2 run-ahead knobs
+  NEW=$R/livecc_amd/_C/liblivecc_amd.so; OLD=$R/livecc_amd/_C_r4/liblivecc_amd.so
+  LCC_LIB_PATH=$OLD timeout 200 python tools/gemm_checksum.py > $O/sum_r4.txt 2>$O/sum_r4.err
+  for KV in "X=0" "LCC_GEMM_RASTER=8" "LCC_GEMM_L2PF=2" "LCC_GEMM_L2PF=3" "LCC_GEMM_RASTER=4 LCC_GEMM_L2PF=2"; do
+    T=$(echo $KV | tr -d ' ='); env $KV timeout 200 python tools/gemm_checksum.py > $O/sum_$T.txt 2>$O/sum_$T.err
+    cmp -s $O/sum_r4.txt $O/sum_$T.txt && echo "checksums [$KV]: IDENTICAL to the round-4 build" || { echo "checksums [$KV] DIFFER"; paste $O/sum_r4.txt $O/sum_$T.txt; tail -n 3 $O/sum_$T.err; }
+  done
+  LCC_LIB_PATH=$OLD timeout 300 python tools/r5_bench_gemm.py r4 2>$O/g_r4.err | tee -a $O/gemm_ab.jsonl | cut -c1-200
+  for KV in "X=0" "LCC_GEMM_RASTER=8" "LCC_GEMM_RASTER=4" "LCC_GEMM_L2PF=2" "LCC_GEMM_L2PF=3" "LCC_GEMM_RASTER=8 LCC_GEMM_L2PF=2" "LCC_GEMM_RASTER=4 LCC_GEMM_L2PF=3"; do
+    T=$(echo $KV | tr -d ' ='); env $KV timeout 300 python tools/r5_bench_gemm.py "$T" 2>$O/g_$T.err | tee -a $O/gemm_ab.jsonl | cut -c1-200
+  done
+  LCC_LIB_PATH=$OLD timeout 300 python tools/r5_bench_gemm.py r4_again gate_up_M3088,down_M3088,vit_fc1_P11648 2>>$O/g_r4.err | tee -a $O/gemm_ab.jsonl | cut -c1-200
+  LCC_LIB_PATH=$OLD timeout 300 python tools/bench_attn.py --quick 2>$O/attn_r4.err | sed 's/^/r4 /' | tee -a $O/attn_ab.txt | grep '"variant": 3' | cut -c1-220
+  timeout 300 python tools/bench_attn.py --quick 2>$O/attn_new.err | sed 's/^/new /' | tee -a $O/attn_ab.txt | grep '"variant": 3' | cut -c1-220
+  LCC_LIB_PATH=$OLD timeout 300 python tools/r5_tower.py r4 2>$O/tower_r4.err | tee -a $O/tower_ab.jsonl
+  timeout 300 python tools/r5_tower.py new 2>$O/tower_new.err | tee -a $O/tower_ab.jsonl
+  timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_vit_fused.py -m gpu -q -x --timeout 500 > $O/ops_tests.log 2>&1; tail -n 5 $O/ops_tests.log ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
