@@ -275,24 +275,29 @@ def standalone_decode_steps(cfg, model, frames, seeds, args, protocol, spg, kv_l
     return dict(avg_step_us=r["avg_step_us"], frac=r["frac"], achieved=r["achieved"], us_per_layer=r["us_per_layer"], steps_timed=r["steps_timed"])
 
 
-def configs2_share(cfg, arena, dev, args, protocol, streams=8, steps=2):
-    """ONE GPU's share of BASELINE.json configs[2] (64 streams data-parallel over 8 GPUs = 8 co-scheduled streams per GPU) in the driver's
-    own --gpus 1 run: the same 60-frame replay with 8 streams batched turn by turn (batched vision tower, packed
-    prefill, one weight pass per decode step for the 8 streams) -> tokens/s, tokens/s/stream, frames/s; and its MFMA-bound roofline: a
-    second replay that stops after each turn's first token (vision tower + LLM prefill of every turn, no decode steps, no prefetch
-    overlap), algorithmic flops over its wall time against the 2.5 PFLOP/s dense bf16 peak.  The 8-GPU job itself (x 8
-    replicas, one RCCL weight broadcast, no collective in the data path) is NOT measured here: no multi-GPU box is reachable."""
-    from livecc_amd.modeling import LiveCCForConditionalGeneration
+def configs2_share(cfg, make_model, dev, args, protocol, streams=8, steps=2, rank=0, world=1, D=None, bcast=None):
+    """BASELINE.json configs[2] (64 streams data-parallel over 8 GPUs = 8 co-scheduled streams per GPU), timed in the same run as the
+    configs[1] line.  EVERY rank runs its share: the same 60-frame replay with 8 streams batched turn by turn (batched vision tower,
+    packed prefill, one weight pass per decode step for the 8 streams) between a barrier and a max-over-ranks clock -> tokens/s of the
+    whole job, tokens/s/stream (minimum over ranks), frames/s; and the MFMA-bound roofline of the job: a second replay that stops after
+    each turn's first token (vision tower + LLM prefill of every turn, no decode steps, no prefetch overlap), algorithmic flops
+     of all ranks over the slowest rank's wall time against world x 2.5 PFLOP/s dense bf16.
+    world == 1 (the driver's --gpus 1 line): `configs2_share`, ONE GPU's share.  world > 1: `configs2`, the job itself -- 8 x world
+    streams, weights broadcast once over RCCL (`bcast`: seconds per rank + the xGMI bound), no collective in prefill / decode (ref
+    evaluation/livesports3kcc/distributed_generate_livecc.py:46-50, 105-122: N processes, strided shards, nothing shared)."""
     n_tok_turn = (args.height // 28) * (args.width // 28)
-    kv_need = 32 * ((args.frames // 2 + 2) * (n_tok_turn + 64) // 32 + 4)
-    model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=streams, max_kv_len=min(32768, max(4096, kv_need)),
-                                           max_new_rows=streams * (3 * n_tok_turn + 128), max_patches=streams * 12 * n_tok_turn + 64,
-                                           max_history=max(16, args.max_new_tokens))
-    frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + i)).to(dev) for i in range(streams)]
-    seeds = [1234 + i for i in range(streams)]
-    sync = lambda: torch.cuda.synchronize(dev)      # noqa: E731
+    model = make_model(streams)
+    frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + rank * streams + i)).to(dev) for i in range(streams)]
+    seeds = [1234 + rank * streams + i for i in range(streams)]
+    sync = (lambda: torch.cuda.synchronize(dev)) if torch.device(dev).type == "cuda" else (lambda: None)
+    allmax = (lambda v: D.max_over_ranks(v, dev)) if D is not None else (lambda v: v)
+    allsum = (lambda v: D.sum_over_ranks(v, dev)) if D is not None else (lambda v: v)
+    gather = (lambda v: D.gather_floats(v, dev)) if D is not None else (lambda v: [float(v)])
+    barrier = (lambda: D.barrier(dev)) if D is not None else (lambda: None)
     replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, True)          # warm-up
-    model.engine.profile(True, 16384)
+    if model.engine is not None:
+        model.engine.profile(True, 16384)
+    barrier()
     sync()
     t0 = time.perf_counter()
     toks = nfr = 0
@@ -301,40 +306,60 @@ def configs2_share(cfg, arena, dev, args, protocol, streams=8, steps=2):
         toks += a
         nfr += b
     sync()
-    dt = time.perf_counter() - t0
-    model.engine.profile(False)
-    kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
-    step_roof = decode_step_roofline(cfg, model.engine, streams, kv_list, False)
-    if step_roof is not None:
-        step_roof["standalone_replay_without_prefetch"] = standalone_decode_steps(cfg, model, frames, seeds, args, protocol, streams, kv_list, False)
+    my_dt = time.perf_counter() - t0
+    barrier()
+    dt = allmax(time.perf_counter() - t0)
+    step_roof = None
+    if model.engine is not None:
+        model.engine.profile(False)
+        kv_list = kv_lengths_of_decode_steps(cfg, args.frames, args.height, args.width, args.max_new_tokens, protocol)
+        step_roof = decode_step_roofline(cfg, model.engine, streams, kv_list, False)
+        if step_roof is not None:
+            step_roof["standalone_replay_without_prefetch"] = standalone_decode_steps(cfg, model, frames, seeds, args, protocol, streams, kv_list, False)
     # MFMA-bound phases alone: every turn's vision tower + prefill, one token per turn (no decode steps), no prefetch overlap
     replay(model, cfg, frames, seeds, 1, protocol, torch, False)
+    barrier()
     sync()
     t1 = time.perf_counter()
     for _ in range(steps):
         replay(model, cfg, frames, seeds, 1, protocol, torch, False)
     sync()
-    dt1 = (time.perf_counter() - t1) / steps
+    barrier()
+    dt1 = allmax(time.perf_counter() - t1) / steps
     fl = stream_phase_flops(cfg, args.frames, args.height, args.width, 0, protocol)
-    flops = streams * (fl["vit_flops"] + fl["llm_prefill_flops"])
+    flops = world * streams * (fl["vit_flops"] + fl["llm_prefill_flops"])
     tf = flops / dt1 / 1e12
-    per_stream = toks / dt / streams
+    total_toks, total_fr = allsum(float(toks)), allsum(float(nfr))
+    per_rank = gather(toks / my_dt)
+    per_stream_min = min(per_rank) / streams
     del model, frames
-    torch.cuda.empty_cache()
-    return dict(
-        workload=f"{cfg.name}, {streams} co-scheduled streams on ONE GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, {args.max_new_tokens} "
-                 f"tokens/turn, greedy = one GPU's share of BASELINE.json configs[2] (64 streams over 8 GPUs)",
-        streams_per_gpu=streams, steps=steps, value=round(toks / dt, 2), unit="tokens/s", tokens_per_s_per_stream=round(per_stream, 2),
-        frames_per_s=round(nfr / dt, 2), ms_per_replay=round(dt / steps * 1e3, 1),
-        north_star_target_tokens_per_s_per_stream=30.0, meets_target_on_this_gpu=bool(per_stream >= 30.0),
-        eight_gpu_job="unmeasured (no multi-GPU box reachable): x 8 independent replicas of this share, weights broadcast once over RCCL, no "
-                      "collective in prefill / decode",
-        roofline=dict(bound="mfma", kernel="vision tower + LLM prefill of every turn (every GEMM / attention launch), 8 streams batched; replay "
+    if torch.device(dev).type == "cuda":
+        torch.cuda.empty_cache()
+    n_all = streams * world
+    out = dict(
+        workload=(f"{cfg.name}, {n_all} streams = {streams} co-scheduled streams on each of {world} GPU(s), 2 fps, {args.frames} frames {args.height}x{args.width}, "
+                  f"{args.max_new_tokens} tokens/turn, greedy" + (" = BASELINE.json configs[2]" if n_all == 64 else
+                                                                   (" = one GPU's share of BASELINE.json configs[2] (64 streams over 8 GPUs)" if world == 1 else
+                                                                    f" = BASELINE.json configs[2] scaled to {world} GPUs"))),
+        streams=n_all, streams_per_gpu=streams, n_gpus=world, steps=steps, value=round(total_toks / dt, 2), unit="tokens/s",
+        tokens_per_s_per_stream=round(per_stream_min, 2), tokens_per_s_per_stream_is="minimum over ranks",
+        tokens_per_s_per_rank=[round(x, 2) for x in per_rank],
+        frames_per_s=round(total_fr / dt, 2), ms_per_replay=round(dt / steps * 1e3, 1),
+        north_star_target_tokens_per_s_per_stream=30.0, meets_target=bool(per_stream_min >= 30.0),
+        roofline=dict(bound="mfma", kernel=f"vision tower + LLM prefill of every turn (every GEMM / attention launch), {streams} streams batched per GPU; replay "
                                            "stopped after each turn's first token, no prefetch overlap",
-                      achieved=round(tf, 1), peak=2500.0, unit="TFLOP/s", frac=round(tf / 2500.0, 4), traffic=None,
+                      achieved=round(tf, 1), peak=2500.0 * world, unit="TFLOP/s", frac=round(tf / (2500.0 * world), 4), traffic=None,
                       algorithmic_flops_per_replay=flops, vit_flops_per_stream=fl["vit_flops"], llm_prefill_flops_per_stream=fl["llm_prefill_flops"],
                       prefill_rows_per_stream=fl["prefill_rows"], seconds_per_replay=round(dt1, 4)),
         decode_step=step_roof)
+    if world == 1:
+        out["meets_target_on_this_gpu"] = out["meets_target"]
+        out["eight_gpu_job"] = ("not in this record (--gpus 1): `bench.py --gpus N` times it as `configs2` -- N ranks each running this share, weights "
+                                "broadcast once over RCCL, no collective in prefill / decode")
+    else:
+        out["data_path_collectives"] = 0
+        out["weight_broadcast"] = bcast
+    return out
 
 
 def kv_lengths_of_decode_steps(cfg, nframes, height, width, max_new, protocol):
@@ -656,6 +681,28 @@ def main():
     step_ms_per_rank = D.gather_floats(my_step_ms, dev)
     bcast_per_rank = D.gather_floats(bcast_s, dev)
     numa_pinned = D.sum_over_ranks(1.0 if numa.get("pinned") else 0.0, dev)
+    # BASELINE.json configs[2]: world == 1 -> one GPU's share (`configs2_share`); world > 1 -> every rank runs its 8-stream share and the
+    # line carries the job (`configs2`: 8 x world streams).  `value` stays the configs[1] replay above, so that N = 1 agrees with BENCH.
+    share = None
+    share_on = args.share8 == "on" or (args.share8 == "auto" and spg == 1 and args.workload == "stream60" and not fp8 and
+                                       (args.standin or (cfg.name == "livecc-7b" and args.frames == 60)))
+    if share_on:
+        if args.standin:
+            def make_model(streams):
+                return StandInModel(cfg)
+        else:
+            def make_model(streams):
+                kv_need8 = 32 * ((args.frames // 2 + 2) * (n_tok_turn + 64) // 32 + 4)
+                return LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=streams, max_kv_len=min(32768, max(4096, kv_need8)),
+                                                      max_new_rows=streams * (3 * n_tok_turn + 128), max_patches=streams * 12 * n_tok_turn + 64,
+                                                      max_history=max(16, args.max_new_tokens))
+        bc = dict(seconds_max=round(bcast_max, 3), seconds_per_rank=[round(x, 3) for x in bcast_per_rank], arena_bytes=int(arena.nbytes()) if arena is not None else 0,
+                  xgmi_bound_s=round(arena.nbytes() / 153e9, 3) if arena is not None else 0.0,
+                  how="one chunked torch.distributed.broadcast of the flat arena from rank 0 (RCCL over xGMI, ~153 GB/s per link)")
+        try:
+            share = configs2_share(cfg, make_model, dev, args, protocol, rank=rank, world=world, D=D if world > 1 else None, bcast=bc)
+        except Exception as e:       # never takes the main line down (every rank fails or none: the collectives inside are symmetric)
+            share = dict(error=repr(e))
     if rank != 0:
         return
     I, H = cfg.intermediate_size, cfg.hidden_size
@@ -709,14 +756,6 @@ def main():
                         vit_flops=fl["vit_flops"], llm_prefill_flops=fl["llm_prefill_flops"], prefill_rows=fl["prefill_rows"], patches=fl["patches"],
                         prefill_rows_per_launch_sequence=args.prefill_rows, frames_per_s_to_first_token=round(spg * args.frames / (ms1 * 1e-3), 1),
                         decode_gate_up=roof)
-    share = None
-    want_share = args.share8 == "on" or (args.share8 == "auto" and world == 1 and spg == 1 and cfg.name == "livecc-7b" and args.workload == "stream60"
-                                         and args.frames == 60 and not fp8)
-    if want_share and not args.standin:
-        try:
-            share = configs2_share(cfg, arena, dev, args, protocol)
-        except Exception as e:       # never takes the main line down
-            share = dict(error=repr(e))
     cpu = par = None
     want_cpu = (args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)) and not args.standin
     if want_cpu:
@@ -798,7 +837,7 @@ def main():
         "weight_broadcast_s_per_rank": [round(x, 3) for x in bcast_per_rank],
         "weight_broadcast_xgmi_bound_s": round(arena.nbytes() / 153e9, 3) if (arena is not None and world > 1) else 0.0,
         "ranks_pinned_to_gpu_numa_node": int(numa_pinned),
-        "roofline": roof, "cpu_baseline": cpu, "parity": par, "configs2_share": share,
+        "roofline": roof, "cpu_baseline": cpu, "parity": par, ("configs2_share" if world == 1 else "configs2"): share,
         "timed_region": "frames resident in HBM as uint8 (resize / H2D outside the timed region); back-to-back replay: the NEXT turn's vision tower "
                         "is prefetched on a side stream under this turn's decode steps" + (" (disabled: --no-prefetch)" if args.no_prefetch else "") +
                         " -- available to a replay / a server that fetches ahead, NOT to a live 2-fps stream whose next frames do not exist yet",

@@ -30,6 +30,13 @@ def test_gpus_2_self_launches_two_ranks():
     assert out["config"]["streams"] == 2 and len(out["tokens_per_s_per_rank"]) == 2
     # 10 frames = 1 + 2 turns of 16 tokens per stream, 2 streams, one step
     assert out["value"] == pytest.approx(2 * 3 * 16 / (out["ms_per_step"] / 1e3), rel=1e-3)
+    # N > 1: every rank also runs its 8-stream share and the line carries the north_star job (BASELINE.json configs[2] scaled to N GPUs)
+    c2 = out["configs2"]
+    assert "configs2_share" not in out and c2["streams"] == 16 and c2["streams_per_gpu"] == 8 and c2["n_gpus"] == 2
+    assert len(c2["tokens_per_s_per_rank"]) == 2 and c2["data_path_collectives"] == 0 and "xgmi_bound_s" in c2["weight_broadcast"]
+    assert c2["tokens_per_s_per_stream"] == pytest.approx(min(c2["tokens_per_s_per_rank"]) / 8, rel=1e-2)
+    assert c2["value"] == pytest.approx(16 * 3 * 16 * c2["steps"] / (c2["ms_per_replay"] * c2["steps"] / 1e3), rel=1e-2)
+    assert c2["roofline"]["peak"] == 5000.0 and c2["roofline"]["bound"] == "mfma"
 
 
 @pytest.mark.timeout(120)
