@@ -82,6 +82,12 @@ def parse(argv=None):
     ap.add_argument("--share8", choices=["auto", "on", "off"], default="auto",
                     help="also time ONE GPU's share of BASELINE.json configs[2] (8 co-scheduled streams) in the same run and emit it as "
                          "`configs2_share` (auto: on for the default line -- LiveCC-7B, stream60, bf16, one stream per GPU, --gpus 1)")
+    ap.add_argument("--live2fps", choices=["auto", "on", "off"], default="auto",
+                    help="also measure the live-paced capacity of the multi-stream server (frames arriving at 2 fps, no look-ahead): p50 / p99 "
+                         "arrival -> text latency per N and the largest N under a 1-s deadline, emitted as `live2fps` (auto: on for the default line)")
+    ap.add_argument("--more-configs", choices=["auto", "on", "off"], default="auto",
+                    help="also run BASELINE.json configs[3] (one-shot 480 frames) and configs[4] (72B fp8) as child runs + their committed-fixture parity "
+                         "tests and emit them as `configs3_oneshot480` / `configs4_72b_fp8` (auto: on for the default line)")
     ap.add_argument("--standin", action="store_true",
                     help="launcher self-test: a stand-in model on CPU ranks over gloo (no GPU work, numbers meaningless)")
     a = ap.parse_args(argv)
@@ -359,6 +365,163 @@ def configs2_share(cfg, make_model, dev, args, protocol, streams=8, steps=2, ran
     else:
         out["data_path_collectives"] = 0
         out["weight_broadcast"] = bcast
+    return out
+
+
+def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64), video_s=12.0, deadline_s=1.0):
+    """SURVEY 8f-2 under LIVE pacing (north_star: "concurrent 2 fps streams"; ref demo/infer.py:105-129, 165-175: one blocking generate per
+    due chunk): N streams whose frames ARRIVE at 2 fps on the server's wall clock, `livecc_amd.server.StreamServer` batching whatever is
+    due at each step, `max_new_tokens` forced greedy tokens per chunk, NO look-ahead (prefetch off: a chunk's vision tower starts only
+    once its frames exist).  Stream i starts i / N s into the first second (no artificial phase alignment); its clock is shifted by one
+    frame interval so that the server's pacing rule (a 2-frame chunk is due when the video clock passes its FIRST frame time) fires at
+    the arrival of the chunk's LAST frame.  Latency of a streaming chunk = that arrival -> the chunk's text returned (its last token
+    read back).  The 6-frame initial chunk (the reference takes 3 s at once) is reported apart.  Reports p50 / p99 / max per N and the
+    largest N of the ladder whose p99 stays under `deadline_s` with every chunk served."""
+    from livecc_amd.infer import LiveCCDemoInfer
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.server import StreamServer
+    fti = protocol.FRAME_TIME_INTERVAL
+    nfr = int(round(video_s / fti))
+    pts = np.arange(nfr) * fti
+    n_tok_turn = (args.height // 28) * (args.width // 28)
+    n_chunks = 1 + (nfr - protocol.INITIAL_FPS_FRAMES) // protocol.STREAMING_FPS_FRAMES
+    kv_need = 32 * (((n_chunks + 2) * (n_tok_turn + 64 + args.max_new_tokens)) // 32 + 4)
+    base_frames = [torch.from_numpy(protocol.synth_frames(nfr, args.height, args.width, seed=4321 + i)).to(dev) for i in range(8)]
+    rows, capacity = [], None
+    for N in ladder:
+        model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=N, max_kv_len=min(32768, max(4096, kv_need)),
+                                               max_new_rows=N * (3 * n_tok_turn + 128), max_patches=N * 12 * n_tok_turn + 64,
+                                               max_history=max(16, args.max_new_tokens))
+        srv = StreamServer(LiveCCDemoInfer(model=model), max_new_tokens=args.max_new_tokens, force_length=True, prefetch=False)
+        if not rows:      # warm-up outside every clock: one initial chunk + one streaming chunk of a single stream
+            srv.add_stream("w", base_frames[0], pts, t_start=0.0, max_pixels=args.height * args.width)
+            srv.step(0.0); srv.step(3.01)
+            srv.remove_stream("w")
+        t_live = {}
+        for i in range(N):
+            f = base_frames[i % 8] if i < 8 else base_frames[i % 8].roll(i // 8, dims=0).contiguous()     # distinct content per stream
+            t_live[i] = i / N
+            srv.add_stream(i, f, pts, t_start=t_live[i] + fti, max_pixels=args.height * args.width)
+        lat, first, steps = [], [], []
+        base = time.monotonic()
+        inner = srv.step
+
+        def timed_step(now, hf_spaces=False):
+            t0 = time.monotonic()
+            res = inner(now, hf_spaces)
+            if res:
+                steps.append((time.monotonic() - t0, len(res)))
+            return res
+        srv.step = timed_step
+
+        def on_result(sid, span, text, state):
+            t = time.monotonic() - base
+            if span[0] == 0.0:                             # the initial 6-frame chunk: taken as buffered history the moment the stream joins
+                first.append(t - (t_live[sid] + fti))      # (the reference's rule, ref demo/infer.py:107-110): join -> text
+            else:
+                lat.append(t - (t_live[sid] + span[1] - fti))      # arrival of the chunk's last frame on the stream's live clock -> text
+        torch.cuda.synchronize(dev)
+        srv.run(until=video_s + 8.0, realtime=True, on_result=on_result, t0=base)
+        wall = time.monotonic() - base
+        served = len(lat) + len(first)
+        expected = N * n_chunks
+        for sid in list(srv.streams):
+            srv.remove_stream(sid)
+        del srv, model
+        torch.cuda.empty_cache()
+        a = np.sort(np.asarray(lat)) if lat else np.asarray([float("inf")])
+        busy = float(sum(d for d, _ in steps))
+        row = dict(streams=N, chunks_served=served, chunks_expected=expected, p50_s=round(float(np.percentile(a, 50)), 3),
+                   p99_s=round(float(np.percentile(a, 99)), 3), max_s=round(float(a[-1]), 3),
+                   initial_chunk_s_mean=round(float(np.mean(first)), 3) if first else None,
+                   scheduler_steps=len(steps), mean_chunks_per_step=round(served / max(1, len(steps)), 2),
+                   gpu_busy_frac=round(busy / wall, 3), tokens_per_s=round(served * args.max_new_tokens / wall, 1), wall_s=round(wall, 2))
+        row["meets_deadline"] = bool(served == expected and row["p99_s"] <= deadline_s)
+        rows.append(row)
+        if row["meets_deadline"]:
+            capacity = N
+        if not row["meets_deadline"] and (served < expected or row["p99_s"] > 2 * deadline_s):
+            break          # overloaded: larger N only queue longer
+    return dict(
+        workload=f"{cfg.name}, N live streams on ONE GPU, frames arriving at 2 fps ({args.height}x{args.width}), {video_s:.0f} s of video each = one 6-frame "
+                 f"initial chunk + {n_chunks - 1} two-frame chunks, {args.max_new_tokens} forced greedy tokens per chunk, StreamServer continuous batching, "
+                 "no look-ahead (vision-tower prefetch off)",
+        latency_is="arrival of a 2-frame chunk's last frame -> its text returned (last token read back); streaming chunks only",
+        deadline_s=deadline_s, ladder=rows, capacity_streams_under_deadline=capacity,
+        eight_streams=next((r for r in rows if r["streams"] == 8), None))
+
+
+def _sub_bench(extra, timeout_s):
+    """Another workload of this file in a child process (its own model and arena; the parent keeps its HBM): the child's JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(extra) + ["--cpu-baseline", "off", "--parity", "off", "--share8", "off", "--live2fps", "off",
+                                                                        "--more-configs", "off"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LCC_BENCH_SELF_LAUNCHED")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"child bench {extra} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-400:]}")
+    return json.loads(lines[-1])
+
+
+def _fixture_test(test_file, expr, keys, timeout_s):
+    """One committed-fixture parity test of the GPU tier as a child pytest (the checker stays in tests/ + oracle/: bench.py only reads the
+    record it writes): {passed, seconds, record of `keys`}."""
+    tmp = tempfile.mkdtemp(prefix="lcc_fixture_")
+    try:
+        env = dict(os.environ, LCC_PARITY_OUT=tmp, LCC_ALLOW_BUDGET_SKIPS="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-m", "gpu", "-q", "-x", "-k", expr, "-p", "no:cacheprovider"],
+                           capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+        rec = {}
+        rp = os.path.join(tmp, "parity_report.json")
+        if os.path.exists(rp):
+            allrec = json.load(open(rp))
+            rec = {k: allrec[k] for k in keys if k in allrec}
+        return dict(test=f"tests/{test_file} -k '{expr}'", passed=r.returncode == 0, seconds=round(time.perf_counter() - t0, 1),
+                    tail=r.stdout.strip().splitlines()[-1][:160] if r.stdout.strip() else "", **rec)
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def more_configs(args):
+    """BASELINE.json configs[3] and configs[4] in the driver's own record: each as a child run of this file at its own
+    shapes + the committed-fixture parity test of that configuration; a failure of either leaves an `error` in its block, never in the line."""
+    out = {}
+    try:
+        j = _sub_bench(["--workload", "oneshot480", "--steps", "1", "--warmup", "1"], 600)
+        rf = j.get("roofline") or {}
+        blk = dict(workload=j["config"]["workload"], value=j["value"], unit=j["unit"], frames_per_s=j["frames_per_s"],
+                   frames_per_s_to_first_token=rf.get("frames_per_s_to_first_token"), ms_to_first_token=rf.get("avg_call_ms"),
+                   prefill_rows=rf.get("prefill_rows"), patches=rf.get("patches"),
+                   roofline=dict(bound="mfma", kernel=rf.get("kernel"), achieved=rf.get("achieved"), peak=rf.get("peak"), unit=rf.get("unit"), frac=rf.get("frac"),
+                                 traffic=None, algorithmic_flops_per_call=rf.get("algorithmic_flops_per_call")),
+                   decode_step_at_24k_keys=((rf.get("decode_gate_up") or {}).get("decode_step")))
+        out["configs3_oneshot480"] = blk
+        try:
+            blk["parity"] = _fixture_test("test_gpu_golden.py", "oneshot480", ["livecc7b_oneshot480_vs_committed_golden"], 600)
+        except Exception as e:
+            blk["parity"] = dict(error=repr(e))
+    except Exception as e:
+        out["configs3_oneshot480"] = dict(error=repr(e))
+    try:
+        j = _sub_bench(["--config", "qwen2vl-72b", "--weights", "fp8", "--steps", "1", "--warmup", "1"], 900)
+        rf = j.get("roofline") or {}
+        ds = rf.get("decode_step") or {}
+        blk = dict(workload=j["config"]["workload"], value=j["value"], unit=j["unit"], frames_per_s=j["frames_per_s"], ms_per_replay=j["ms_per_step"],
+                   mfma="bf16 (e4m3 weights expanded in registers)", dtype=j["dtype"],
+                   roofline=dict(bound="hbm", kernel=rf.get("kernel"), achieved=rf.get("achieved"), peak=rf.get("peak"), unit=rf.get("unit"), frac=rf.get("frac"),
+                                 traffic=None, avg_launch_us=rf.get("avg_launch_us"), algorithmic_bytes_per_launch=rf.get("algorithmic_bytes_per_launch")),
+                   decode_step=dict(avg_step_us=ds.get("avg_step_us"), frac=ds.get("frac"), achieved=ds.get("achieved"), weight_bytes=ds.get("weight_bytes"),
+                                    standalone_replay_without_prefetch=ds.get("standalone_replay_without_prefetch")))
+        out["configs4_72b_fp8"] = blk
+        try:
+            blk["parity"] = _fixture_test("test_gpu_layer_parity.py", "72b", ["qwen2vl72b_fp8_layer_stages_vs_hf", "qwen2vl72b_fp8_one_layer_stream_vs_hf",
+                                                                              "qwen2vl72b_fp8_full_depth_first_token"], 900)
+        except Exception as e:
+            blk["parity"] = dict(error=repr(e))
+    except Exception as e:
+        out["configs4_72b_fp8"] = dict(error=repr(e))
     return out
 
 
@@ -756,6 +919,30 @@ def main():
                         vit_flops=fl["vit_flops"], llm_prefill_flops=fl["llm_prefill_flops"], prefill_rows=fl["prefill_rows"], patches=fl["patches"],
                         prefill_rows_per_launch_sequence=args.prefill_rows, frames_per_s_to_first_token=round(spg * args.frames / (ms1 * 1e-3), 1),
                         decode_gate_up=roof)
+    live = None
+    want_live = args.live2fps == "on" or (args.live2fps == "auto" and world == 1 and spg == 1 and cfg.name == "livecc-7b" and args.workload == "stream60"
+                                          and args.frames == 60 and not fp8)
+    if want_live and not args.standin:
+        try:
+            del model
+            torch.cuda.empty_cache()
+            live = live2fps(cfg, arena, dev, args, protocol)
+        except Exception as e:       # never takes the main line down
+            live = dict(error=repr(e))
+        model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
+                                               max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
+                                               max_history=max(16, args.max_new_tokens))      # the parity legs below use it
+    more = None
+    if (args.more_configs == "on" or (args.more_configs == "auto" and want_live)) and not args.standin:
+        try:
+            del model
+            torch.cuda.empty_cache()
+            more = more_configs(args)
+        except Exception as e:
+            more = dict(error=repr(e))
+        model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
+                                               max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
+                                               max_history=max(16, args.max_new_tokens))
     cpu = par = None
     want_cpu = (args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)) and not args.standin
     if want_cpu:
@@ -837,7 +1024,7 @@ def main():
         "weight_broadcast_s_per_rank": [round(x, 3) for x in bcast_per_rank],
         "weight_broadcast_xgmi_bound_s": round(arena.nbytes() / 153e9, 3) if (arena is not None and world > 1) else 0.0,
         "ranks_pinned_to_gpu_numa_node": int(numa_pinned),
-        "roofline": roof, "cpu_baseline": cpu, "parity": par, ("configs2_share" if world == 1 else "configs2"): share,
+        "roofline": roof, "cpu_baseline": cpu, "parity": par, ("configs2_share" if world == 1 else "configs2"): share, "live2fps": live, **(more or {}),
         "timed_region": "frames resident in HBM as uint8 (resize / H2D outside the timed region); back-to-back replay: the NEXT turn's vision tower "
                         "is prefetched on a side stream under this turn's decode steps" + (" (disabled: --no-prefetch)" if args.no_prefetch else "") +
                         " -- available to a replay / a server that fetches ahead, NOT to a live 2-fps stream whose next frames do not exist yet",

@@ -4,7 +4,8 @@ import os
 
 import torch
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+# LCC_PARITY_OUT: bench.py runs single fixture tests as a subprocess and reads their record from a scratch directory
+OUT = os.environ.get("LCC_PARITY_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
 def rb(x: torch.Tensor) -> torch.Tensor:

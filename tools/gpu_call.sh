@@ -9,7 +9,7 @@ O=$R/gpurun_out/$RECIPE
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-B="python bench.py --cpu-baseline off --parity off"
+B="python bench.py --cpu-baseline off --parity off --live2fps off --more-configs off"
 val() { grep -o "\"$2\": [0-9.]*" $1 | head -1 | cut -d' ' -f2; }
 
 case $RECIPE in
@@ -138,6 +138,51 @@ r5a)         # round 5, call 1: LDS-DMA through inline asm (counted lgkmcnt ladd
   LCC_LIB_PATH=$OLD timeout 300 python tools/r5_tower.py r4 2>$O/tower_r4.err | tee -a $O/tower_ab.jsonl
   timeout 300 python tools/r5_tower.py new 2>$O/tower_new.err | tee -a $O/tower_ab.jsonl
   timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_vit_fused.py -m gpu -q -x --timeout 500 > $O/ops_tests.log 2>&1; tail -n 5 $O/ops_tests.log ;;
+r5b)         # round 5, call 2: SQ counters of the MFMA-bound kernels (where do the wave cycles go?) + the new bench legs end to end
+  cd /tmp; i=0
+  for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+    i=$((i+1)); timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p$i -o k -- python $R/tools/r5_pmc_target.py > $O/p$i.log 2>&1 || echo "pass $i failed: $(tail -n 2 $O/p$i.log)"
+    find $O/p$i -name '*kernel_trace.csv' -delete
+  done
+  python - <<PY > $O/sq_counters.json
+import csv, glob, json, collections
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        kn = r.get("Kernel_Name", "")
+        if any(t in kn for t in ("gemm_big_kernel", "attn_gqa32", "attn_vit32", "layernorm_kernel", "gemm_glds")):
+            key = kn.split("(")[0].replace("void lcc::", "").replace("lcc::", "")[:60] + " grid=" + r["Grid_Size"]
+            res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res[key]["duration_us"].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+out = {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, launches=len(cs["duration_us"])) for k, cs in res.items()}
+print(json.dumps(out, indent=1))
+PY
+  python - <<PY
+import json
+d = json.load(open("$O/sq_counters.json"))
+for k, c in sorted(d.items(), key=lambda kv: -kv[1].get("duration_us", 0) * kv[1].get("launches", 0))[:9]:
+    w = c.get("SQ_WAVE_CYCLES", 0) or 1
+    print("%-70s %8.1f us x%3d | of wave cycles: wait_any %.2f wait_inst %.2f active_any %.2f valu %.2f lds %.2f vmem %.2f | mfma_busy/busy %.2f | vmem_inst_cycles/wave %.2f ta_addr_full %.3f lds_cmd_full %.3f bank_conf/idx %.2f | insts valu %.0f mfma %.0f lds %.0f vmem %.0f" % (
+        k[:70], c.get("duration_us", 0), c.get("launches", 0), c.get("SQ_WAIT_ANY", 0) / w, c.get("SQ_WAIT_INST_ANY", 0) / w, c.get("SQ_ACTIVE_INST_ANY", 0) / w,
+        c.get("SQ_ACTIVE_INST_VALU", 0) / w, c.get("SQ_ACTIVE_INST_LDS", 0) / w, c.get("SQ_ACTIVE_INST_VMEM", 0) / w,
+        c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(c.get("SQ_BUSY_CYCLES", 1), 1), c.get("SQ_INST_CYCLES_VMEM", 0) / w, c.get("SQ_VMEM_TA_ADDR_FIFO_FULL", 0) / w,
+        c.get("SQ_LDS_CMD_FIFO_FULL", 0) / w, c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1), c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_MFMA", 0),
+        c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0)))
+PY
+  rm -rf $O/p*/; cd $R
+  ( time timeout 1500 python bench.py --steps 1 --warmup 1 --cpu-baseline off --parity off ) > $O/bench_legs.log 2>$O/bench_legs.err; tail -n 4 $O/bench_legs.err
+  python - <<PY
+import json
+l = [x for x in open("$O/bench_legs.log") if x.startswith("{")]
+d = json.loads(l[-1]) if l else {}
+print("value", d.get("value"), "share", (d.get("configs2_share") or {}).get("value"), (d.get("configs2_share") or {}).get("error"))
+print("live2fps", json.dumps(d.get("live2fps"))[:1500])
+print("configs3", json.dumps(d.get("configs3_oneshot480"))[:1200])
+print("configs4", json.dumps(d.get("configs4_72b_fp8"))[:1200])
+PY
+  ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
