@@ -62,8 +62,9 @@ int lcc_debug_set_gemv_variant(int variant);
  * 8-wave kernel with 256 / 128 rows where eligible, 5 / 6 = the same with the compiler's fragment-read schedule, 7 = 2 without the
  * 8-wave kernel, 8 = force the "tall" kernel (one block row covers all of M <= 448, 448x160 tiles) wherever it is legal; the default
  * takes it when 256 < M <= 448 and ceil(N/160) fills 75-100 % of one round of the chip (LiveCC-7B gate/up of a streaming chunk);
- * 9 = the tall tile with an LDS ring of four 32-k half tiles instead of two whole k-tiles (three half tiles in flight across every
- * barrier; bit-identical results; measured equal-to-slower: the L2 -> LDS DMA is throughput-bound) */
+ * 13 = the 192-row 8-wave tile wherever eligible; 14 = row tiles of variable height (256 / 272 / 288 rows: ceil(M/16) row fragments dealt
+ * out over floor(ceil(M/16)/16) tiles, no ragged last tile; round 5) wherever legal, else as 3 -- the default picks them by score (e.g. the
+ * gate/up GEMM of 8 co-scheduled chunks: 12 x 148 tiles instead of 13 x 148).  Every tile shape produces the same bits. */
 int lcc_debug_set_gemm_variant(int variant);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
  * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs
@@ -105,8 +106,10 @@ int lcc_gemv_num_splits(int N, int K);
 /* nn.Linear with fp8 (OCP e4m3) weights, the 72B single-GPU path (BASELINE.json configs[4]): W8 = bytes in the PACKED8 order
  * [N/16][K/64][4 g][16 rows][16 k] (lane (g,row) owns 16 consecutive k), wscale = fp32 [N] per-output-row scale:
  * y[m][n] = epilogue(wscale[n] * sum_k x[m][k] * q[n][k] (+ bias[n])).  M <= 16: weight-streaming GEMV (e4m3 -> bf16 exactly
- * in registers, bf16 MFMA, fp32 accumulate).  M > 16: exact dequantisation into dq_scratch (N*K bf16, caller-provided), then
- * the bf16 GEMM with the scale in its epilogue.  K % 64 == 0, N % 16 == 0.  partial / nsplit as in lcc_gemm_bf16. */
+ * in registers, bf16 MFMA, fp32 accumulate).  M > 16: the 8-wave GEMM stages the fp8 fragments themselves (half the L2 -> LDS bytes) and
+ * expands them to bf16 after the LDS read, the row scale in its epilogue; only shapes with too few 256-column tiles for that kernel fall
+ * back to an exact dequantisation into dq_scratch (N*K bf16, caller-provided) + the bf16 GEMM.  K % 64 == 0, N % 16 == 0.  partial /
+ * nsplit as in lcc_gemm_bf16. */
 int lcc_gemm_w8_bf16(const void* A, int lda, const void* W8, const float* wscale, const void* bias, const void* residual, int ldr,
                      void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* dq_scratch, void* stream);
 /* self-test of the MFMA fragment maps: D[16,16] fp32 = A[16,32] bf16 * B[32,16] bf16 on one wave */
@@ -197,7 +200,8 @@ int lcc_debug_bench_grid_barrier(int mode, int blocks, int iters, void* scratch,
  * 0 per-wave decode attention, 1 decode split-merge launches, 2 fused decode attention (+ combine launch), 3 fused decode attention with
  * the in-launch merge, 4 split-K GEMV with a fused consumer tail, 5 decode-pipeline-v2 GEMVs, 6 prefill attention on 32x32x16 MFMAs
  * (attn32.hip), 7 LDS-shared prefill attention, 8 per-wave prefill attention, 9 prefill split-merge launches, 10 / 11 = key splits of the
- * most recent decode / prefill attention launch (values, not counts). */
+ * most recent decode / prefill attention launch (values, not counts), 12 tall-tile GEMM, 13 32x32x16 vision attention, 14 variable-height
+ * GEMM tiles (gemm_vh_kernel), 15 vision q|k|v projection with the RoPE / V-transpose epilogue. */
 int lcc_debug_launch_counts(int64_t* out, int n, int reset);
 int lcc_debug_set_fused_attn(int mode); /* bit 0 (default on): engine decode uses the fused kernel for batches of >= 16 (stream,
                                           KV head) pairs; bit 2: for every batch; bit 1: key splits merged in the same launch by the

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
 // the stage shrinks to 48 KB (BM 256) so that three stages fit and one tile stays in flight across the barrier.
 // (the kernel proper is gemm_big_kernel below: it maps blockIdx to a tile (tm, tn) and runs this body -- once for every epilogue but
 // EPI_VIT_QKV, whose column tiles take the q|k body or the V body)
-template <int BM, int EPI, int SCHED, bool W8, int PF = 0>
+template <int BM, int EPI, int SCHED, bool W8>
 LCC_DEVICE void gemm_big_body(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
@@ -488,57 +488,8 @@ LCC_DEVICE void gemm_big_body(
     }
   }
 
-  // ---- PF > 0 (round 5, two 64-KB stages only): an L2 run-ahead.  With two stages a k-tile's DMA is issued one tile (~1 us) before it
-  // is needed, about the latency of a fill from HBM / the Infinity Cache under load (DMA ring alone 1.38 us per k-tile, profiles/r03/
-  // gemm_diag.jsonl), and the LDS has no room for a third stage.  So wave 7 issues no ring pieces: its LDS-DMA slots read one 16-byte
-  // piece of every 128-byte line of the tile PF tiles AHEAD of the ring into a 1-KB scratch -- the line is in this XCD's L2 when the
-  // ring asks for it -- and, having nothing else on its vmcnt queue (loads retire in order: a run-ahead piece in FRONT of ring pieces
-  // would have to land within one tile again), it never waits for them.  The 64 (56) ring pieces go to waves 0-6.  Every wave runs the
-  // same instruction stream over a per-wave piece table (source pointer, LDS destination, per-k-tile advance); surplus slots copy 16
-  // bytes of one line (all lanes the same address) into the scratch.
-  constexpr bool L2PF = PF > 0 && NSTAGE == 2 && !W8 && SCHED == 6;
-  constexpr int NPA = BM / 8, NPIECE = NPA + B_SUB, NSLOT = L2PF ? (NPIECE + 6) / 7 : 1;
-  static_assert(!L2PF || NSLOT <= 2 * MT, "one piece per row-tile step");
-  constexpr unsigned SCRATCH_BYTES = (unsigned)NSTAGE * STAGE * 16;          // 1 KB behind the stages (launcher: lds + 1024)
-  const bf16_t* psrc[NSLOT];
-  unsigned pdst[NSLOT];     // byte offset inside a stage, or 0xffffffff: the scratch
-  int pstep[NSLOT];         // elements per k-tile
-  int kcap = 0;             // largest k-tile index this wave's pieces may read (run-ahead: PF less)
-  if constexpr (L2PF) {
-    kcap = K / BK - 1 - (wave == 7 ? PF : 0);
-#pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-      psrc[q] = A; pdst[q] = 0xffffffffu; pstep[q] = 0;
-      if (wave < 7) {
-        const int p = wave + 7 * q;
-        if (p < NPA) {                      // activation rows p*8 .. +7, swizzled full lines (as asrc above)
-          psrc[q] = A + (size_t)min(m0 + p * 8 + (lane >> 3), M - 1) * lda + (((lane & 7) ^ (lane >> 3)) << 3);
-          pdst[q] = (unsigned)p * 64 * 16; pstep[q] = BK;
-        } else if (p < NPIECE) {            // W sub-tile st: n-fragment row st >> 1, 32-k block st & 1
-          const int st = p - NPA, fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
-          psrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
-          pdst[q] = (unsigned)(A_UNITS + st * 64) * 16; pstep[q] = 1024;
-        }
-      } else if (q < BM / 64) {             // run-ahead, activations: lane = one row's 128-byte line of the k-tile
-        psrc[q] = A + (size_t)min(m0 + q * 64 + lane, M - 1) * lda + PF * BK;
-        pstep[q] = BK;
-      } else if (q < BM / 64 + 4) {         // run-ahead, W: 4 fragment rows x 16 lines (one fragment row's k-tile = 2 KB contiguous)
-        const int fr = min((n0 >> 4) + (q - BM / 64) * 4 + (lane >> 4), nfrag - 1);
-        psrc[q] = W + (size_t)fr * K32 * 512 + (lane & 15) * 64 + PF * 1024;
-        pstep[q] = 1024;
-      }
-    }
-  }
-
   auto issue = [&](int kt, int stage) {
     u32x4* sbase = dsmem + stage * STAGE;
-    if constexpr (L2PF) {
-      const int kc = min(kt, kcap);
-#pragma unroll
-      for (int q = 0; q < NSLOT; ++q)
-        glds16(psrc[q] + (size_t)max(kc, 0) * pstep[q], pdst[q] == 0xffffffffu ? lds_addr(dsmem) + SCRATCH_BYTES : lds_addr(sbase) + pdst[q]);
-      return;
-    }
     if (SCHED != 5) {      // (SCHED 4 / 5: timing diagnostics, only the activation / only the W half of the DMA ring)
 #pragma unroll
     for (int q = 0; q < A_PER_WAVE; ++q)
@@ -575,7 +526,7 @@ LCC_DEVICE void gemm_big_body(
       if (G == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (G == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (!L2PF || wave != 7) {
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
@@ -628,19 +579,12 @@ LCC_DEVICE void gemm_big_body(
       // region): past the last tile the source is clamped and the copy lands in a stage nobody reads any more.
       const int kt_dma = min(kt + NSTAGE - 1, nkt - 1);
       u32x4* dma_base = dsmem + ((kt + NSTAGE - 1 - kt0) % NSTAGE) * STAGE;
-      const int kc_dma = L2PF ? __builtin_amdgcn_readfirstlane(max(min(kt_dma, kcap), 0)) : 0;
-      const unsigned dma_lds = lds_addr(dma_base), scratch_lds = lds_addr(dsmem) + SCRATCH_BYTES;
 #pragma unroll
       for (int t = 0; t < 2 * MT; ++t) {
         if (t + 2 < 2 * MT) fa[(t + 2) % 3] = as_bf16x8(s[aoff[(t + 2) / MT] + ((t + 2) % MT) * 128]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[t % MT][j] = SWAP ? mfma16(fa[t % 3], fb[t / MT][j], acc[t % MT][j]) : mfma16(fb[t / MT][j], fa[t % 3], acc[t % MT][j]);
-        if constexpr (L2PF) {
-          if (t < NSLOT) {
-            const int q = t < NSLOT ? t : 0;
-            glds16(psrc[q] + (size_t)kc_dma * pstep[q], pdst[q] == 0xffffffffu ? scratch_lds : dma_lds + pdst[q]);
-          }
-        } else if (SCHED == 6 && t < G) {
+        if (SCHED == 6 && t < G) {
           if (t < A_PER_WAVE)
             glds16((asrc[t < A_PER_WAVE ? t : 0] + kt_dma * BK), lds_addr(dma_base + (wave * A_PER_WAVE + t) * 64));
           else
@@ -652,7 +596,7 @@ LCC_DEVICE void gemm_big_body(
       for (int t = 0; t < 2 * MT; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-        if (SCHED == 6 && !L2PF && t < G) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one VMEM (the LDS-DMA piece)
+        if (SCHED == 6 && t < G) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);      // one VMEM (the LDS-DMA piece)
       }
     }
   }
@@ -677,7 +621,7 @@ LCC_DEVICE void gemm_big_body(
   } else tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
 }
 
-template <int BM, int EPI, int SCHED, bool W8, int PF = 0>
+template <int BM, int EPI, int SCHED, bool W8>
 __global__ __launch_bounds__(512) void gemm_big_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
@@ -708,45 +652,45 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     // body on rows 2E.. of the packed weight -- a block-uniform choice made once, outside the k-loop
     const int qk_tiles = (2 * vq.E) >> 8;
     if (tn >= qk_tiles)
-      gemm_big_body<BM, EPI_VIT_V, SCHED, W8, PF>(A, lda, W + (size_t)2 * vq.E * K, bias != nullptr ? bias + 2 * vq.E : nullptr, nullptr, 0, nullptr, 0, M,
+      gemm_big_body<BM, EPI_VIT_V, SCHED, W8>(A, lda, W + (size_t)2 * vq.E * K, bias != nullptr ? bias + 2 * vq.E : nullptr, nullptr, 0, nullptr, 0, M,
                                                   vq.E, K, tm, tn - qk_tiles, nullptr, 0, nullptr, vq);
     else
-      gemm_big_body<BM, EPI_VIT_QK, SCHED, W8, PF>(A, lda, W, bias, nullptr, 0, C, ldc, M, 2 * vq.E, K, tm, tn, nullptr, 0, nullptr, vq);
+      gemm_big_body<BM, EPI_VIT_QK, SCHED, W8>(A, lda, W, bias, nullptr, 0, C, ldc, M, 2 * vq.E, K, tm, tn, nullptr, 0, nullptr, vq);
   } else {
-    gemm_big_body<BM, EPI, SCHED, W8, PF>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, tm, tn, partial, kt_per_split, wscale, vq);
+    gemm_big_body<BM, EPI, SCHED, W8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, tm, tn, partial, kt_per_split, wscale, vq);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// tiled GEMM v5 ("ping-pong", round 4): the 256 x 256 x 64 tile with the two wave groups of a CU running HALF A PHASE APART
+// tiled GEMM v6 (round 5): the pipeline of gemm_big_kernel<256> over row tiles of VARIABLE height (16, 17 or 18 row fragments = 256 /
+// 272 / 288 rows x 256 columns)
 // ------------------------------------------------------------------------------------------------
-// Why.  gemm_big_kernel<256> has ONE barrier per k-tile; both waves of a SIMD leave it together, both wait for their first fragments,
-// both multiply, both drain: MFMAs alone 654 us, DMA ring alone 580 us, kernel 830 us at M = 3088 (profiles/r03/gemm_diag.jsonl),
-// MfmaUtil 51 %.  A deeper ring does not help (gemm_big4 experiment, profiles/r04/gemm_ring4_vs_ring2.txt: 0.97 vs 1.01 PF) -- the lost
-// time is the lock step, not the DMA round trip.  Here the k-tile is cut into FOUR phases = the four 64 x 32 quadrants of a wave's
-// 128 x 64 output tile (16 MFMAs each), every phase is [fragment reads + 2 DMA pieces] barrier [16 MFMAs] barrier, and the waves of
-// group 1 (wm = 1: the second wave of every SIMD) execute one extra barrier up front: in every barrier interval one wave of a SIMD
-// multiplies while the other reads fragments and feeds the DMA ring (the 8-phase structure of cdna_hip_programming.md section 5,
-// rebuilt on this library's packed-W / swizzled-A LDS images).
-//   quadrant order (0,0) (0,1) (1,1) (1,0): phase 1 reads A rows 0-3 (8 ds_read_b128) + W cols 0-1 (4), phase 2 W cols 2-3 (4),
-//   phase 3 A rows 4-7 (8), phase 4 nothing (both W halves stay in registers) -> 24 fragment reads per k-tile instead of 40.
-//   DMA: the next k-tile is staged in four 16-KB regions, one per phase (A rows 0-63 of both row halves | W cols 0-1 of the four
-//   column groups | W cols 2-3 | A rows 64-127), 2 pieces per wave and phase, into the OTHER 64-KB stage: a region is written >= 4
-//   phases after its last reader and needed >= 3 phases after its issue.  Every wave waits `vmcnt(4)` (its two youngest phases may
-//   stay in flight) before every EVEN barrier -- group 0 at the end of its phase, group 1 in the middle of its own -- so that whoever
-//   reads a region next has passed a barrier behind every issuing wave's wait (MI355X_MICROARCH.md item 7: one barrier more between
-//   staggered groups).  The DMA stream never drains inside the k loop.
-// Same accumulation order per accumulator as gemm_big_kernel (k-step 0, then 1, tile after tile): outputs are bit-identical.
-template <int EPI, int PRIO>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(
+// Why.  M is whatever the turn packs: 8 co-scheduled streaming chunks are 8 x 386 = 3088 rows = 12 x 256 + 16, so the 13th row tile of
+// gemm_big_kernel<256> multiplies 16 live rows (and moves a whole W panel for them), and 13 x 148 = 1924 blocks are 7.5 rounds of the
+// 256 CUs: the gate/up GEMM pays 8 rounds for 7.0 rounds of work (1.01 PF algorithmic against 1.18 PF inside full tiles).  Here the
+// F = ceil(M / 16) row fragments are dealt out over floor(F / 16) row tiles, the first F % tiles of them one fragment taller: no ragged
+// last tile wherever the leftover is at most two fragments per tile (3088 rows: 11 tiles of 256 + one of 272 -> 12 x 148 = 1776 blocks
+// = 6.94 rounds; the first turn's 1131 rows: 4 tiles of 288 / 272 instead of 5; 9048 rows: 35 tiles instead of 36).
+//   * waves: 2 (M) x 4 (N) as gemm_big_kernel; the M-wave pair splits the f fragments f/2 : f - f/2, i.e. a wave multiplies 8 or 9 row
+//     fragments x 4 column fragments -- one copy of the k loop per count (the accumulator array must have a compile-time shape), same
+//     barrier sequence in both.  Waves w and w + 4 share a SIMD, so a SIMD issues 4 f MFMAs per 32-k step: a 272-row tile costs 17/16 of
+//     a 256-row tile, not two tiles.
+//   * LDS image of a stage: [288 rows][8 x 16 B] activations (XOR-swizzled chunks, as gemm_big_kernel) + 32 W fragment sub-tiles = 69,632
+//     B, two stages + a 1-KB scratch.  DMA pieces per wave and k-tile: 4 activation pieces (rows 0-255), ONE more for waves 0-3 when the
+//     tile has the rows 256 + 8 w .. (else the slot copies one 16-byte piece into the scratch: uniform instruction stream), 4 W sub-tiles,
+//     spread one per row-tile step behind the barrier (gemm_big_kernel's SCHED 6).
+// Accumulation order per output element = gemm_big_kernel's (k-step 0, then 1, tile after tile): bit-identical outputs.
+// Requires packed bf16 W, K % 64 == 0, F >= 16, F <= 18 * floor(F / 16).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_vh_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
-    float* __restrict__ partial, int kt_per_split) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int WM = BM / 2, MT = WM / 16, NT = 4;
-  constexpr int A_UNITS = BM * 8;                 // 16-byte units of the A image (128 B per row, chunks XOR-swizzled with row & 7)
-  constexpr int STAGE = A_UNITS + 32 * 64;        // + 32 W sub-tiles of 1 KB: 4096 units = 64 KB
+    float* __restrict__ partial, int kt_per_split, int raster) {
+  constexpr int BN = 256, BK = 64, NT = 4, MTX = 9, NSLOT = 9;
+  constexpr int A_UNITS = 288 * 8;                // 16-byte units of the activation image
+  constexpr int STAGE = A_UNITS + 32 * 64;        // + 32 W sub-tiles of 1 KB: 4352 units = 69,632 B
+  constexpr unsigned SCRATCH = 2u * STAGE * 16u;  // byte offset of the 1-KB scratch behind the two stages
   extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
 
   const int nblk = tiles_m * tiles_n;
@@ -755,114 +699,120 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;   // consecutive ids (one XCD) share the W panel
-  const int m0 = tm * BM, n0 = tn * BN;
+  int tn, tm;                                     // tile order: see gemm_big_kernel
+  if (raster > 0) {
+    const int band = bid / (raster * tiles_m), rem = bid - band * raster * tiles_m;
+    const int bw = min(raster, tiles_n - band * raster);
+    tm = rem / bw;
+    tn = band * raster + (rem - tm * bw);
+  } else {
+    tn = bid / tiles_m;
+    tm = bid - tn * tiles_m;
+  }
+  const int F = (M + 15) >> 4, fbase = F / tiles_m, frem = F - fbase * tiles_m;
+  const int f = fbase + (tm < frem ? 1 : 0);                       // row fragments of this tile: 16..18
+  const int m0 = (tm * fbase + min(tm, frem)) << 4, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 15, g = lane >> 4;
   const int K32 = K >> 5, nfrag = N >> 4;
-  const bool wave_has_rows = m0 + wm * WM < M;
+  const int f0 = f >> 1;                                           // M-wave 0: f0 fragments, M-wave 1: the rest
+  const int my_mt = wm ? f - f0 : f0, my_row0 = wm ? f0 * 16 : 0;
+  const bool wave_has_rows = m0 + my_row0 < M;
 
-  // DMA pieces of this wave: in phase j it copies pieces 2*wave and 2*wave + 1 of region j
-  const bf16_t* src[4][2];
-  int dst[4][2];
+  // DMA piece table of this wave: slots 0-3 activation rows (wave*4 + q)*8 .. +7, slot 4 rows 256 + wave*8 .. (waves 0-3, if the tile
+  // has them), slots 5-8 W sub-tiles wave*4 + q (n-fragment row st >> 1, 32-k block st & 1)
+  const bf16_t* psrc[NSLOT];
+  unsigned pdst[NSLOT];
+  const int swz = ((lane & 7) ^ (lane >> 3)) << 3;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wave * 4 + q) * 8 + (lane >> 3);
+    psrc[q] = A + (size_t)min(m0 + row, M - 1) * lda + swz;
+    pdst[q] = (unsigned)(wave * 4 + q) * 1024u;
+  }
+  {
+    const bool have = wave < 4 && 256 + wave * 8 < f * 16;         // wave-uniform
+    const int row = 256 + (wave & 3) * 8 + (lane >> 3);
+    psrc[4] = have ? A + (size_t)min(m0 + row, M - 1) * lda + swz : A;
+    pdst[4] = have ? (unsigned)(32 + wave) * 1024u : SCRATCH;
+  }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = wave * 2 + u;                 // 0..15
-      if (j == 0 || j == 3) {                     // A rows [h*128 + (j ? 64 : 0) + (q & 7)*8, + 8)
-        const int row0 = (q >> 3) * WM + (j == 3 ? 64 : 0) + (q & 7) * 8;
-        src[j][u] = A + (size_t)min(m0 + row0 + (lane >> 3), M - 1) * lda + (((lane & 7) ^ (lane >> 3)) << 3);
-        dst[j][u] = row0 * 8;
-      } else {                                    // W sub-tile: column group c = q >> 2, fragment row c*4 + (j == 2 ? 2 : 0) + bit 1 of q, k-step q & 1
-        const int fr = (q >> 2) * NT + (j == 2 ? 2 : 0) + ((q >> 1) & 1), kk = q & 1;
-        src[j][u] = W + ((size_t)min((n0 >> 4) + fr, nfrag - 1) * K32 + kk) * 512 + lane * 8;
-        dst[j][u] = A_UNITS + (fr * 2 + kk) * 64;
-      }
-    }
-  auto issue = [&](int kt, u32x4* sbase, int j) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      glds16((src[j][u] + (size_t)kt * ((j == 0 || j == 3) ? BK : 1024)), lds_addr(sbase + dst[j][u]));
+  for (int q = 0; q < 4; ++q) {
+    const int st = wave * 4 + q, fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
+    psrc[5 + q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+    pdst[5 + q] = (unsigned)(A_UNITS + st * 64) * 16u;
+  }
+  const unsigned lds0 = lds_addr(dsmem);
+  auto piece = [&](int q, int kt, unsigned stage_lds) {             // q < 5: activations advance 64 elements per k-tile, W 1024
+    glds16(psrc[q] + (size_t)kt * (q < 5 ? BK : 1024), pdst[q] == SCRATCH ? lds0 + SCRATCH : stage_lds + pdst[q]);
   };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt_all = K / BK;
   const int kt0 = (EPI == EPI_PARTIAL) ? blockIdx.y * kt_per_split : 0;
   const int nkt = (EPI == EPI_PARTIAL) ? min(nkt_all, kt0 + kt_per_split) : nkt_all;
-
-  // fragment read offsets (16-byte units within a stage)
+  if (kt0 < nkt) {
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) piece(q, kt0, lds0);
+  }
   int aoff[2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (wm * WM + li) * 8 + ((kk * 4 + g) ^ (li & 7));
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = (my_row0 + li) * 8 + ((kk * 4 + g) ^ (li & 7));
   const int boff = A_UNITS + (wn * NT * 2) * 64 + lane;
 
-  // prologue: the whole first k-tile (regions in their steady-state order), then group 1 falls one barrier interval behind
+  auto run = [&](auto mt_c) {
+    constexpr int MTW = decltype(mt_c)::value;
+    f32x4 acc[MTW > 0 ? MTW : 1][NT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) issue(kt0, dsmem, j);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  if (wm == 1) {
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  bf16x8 fa[4][2], fb[2][2][2];      // A rows of the current quadrant row [row tile][k-step]; W [column half][column tile][k-step]
-  for (int kt = kt0; kt < nkt; ++kt) {
-    const u32x4* s = dsmem + ((kt - kt0) & 1) * STAGE;
-    u32x4* d = dsmem + ((kt - kt0 + 1) & 1) * STAGE;
-    const int kt_dma = min(kt + 1, nkt - 1);      // past the last tile: a clamped copy into the stage nobody reads any more (uniform counts)
+    for (int i = 0; i < (MTW > 0 ? MTW : 1); ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // ---- read half: this phase's fragments, this phase's two DMA pieces
-      if (wave_has_rows) {
-        if (j == 0 || j == 2) {
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = kt0; kt < nkt; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
+      const u32x4* s = dsmem + ((kt - kt0) & 1) * STAGE;
+      // the pieces of tile kt+1 go out unconditionally (a branch would cut the scheduling region): past the last tile the source is clamped
+      // and the copy lands in the stage nobody reads any more
+      const int kt_dma = min(kt + 1, nkt - 1);
+      const unsigned dma_lds = lds0 + (unsigned)(((kt + 1 - kt0) & 1) * STAGE) * 16u;
+      if constexpr (MTW == 0) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[i][kk] = as_bf16x8(s[aoff[kk] + ((j == 2 ? 4 : 0) + i) * 128]);
-        }
-        if (j == 0 || j == 1) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb[j][c][kk] = as_bf16x8(s[boff + ((j * 2 + c) * 2 + kk) * 64]);
-        }
-      }
-      issue(kt_dma, d, j);
-      if (wm == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- multiply half: quadrant (qi, qj) = (0,0) (0,1) (1,1) (1,0)
-      if (wave_has_rows) {
-        constexpr int QI[4] = {0, 0, 1, 1}, QJ[4] = {0, 1, 1, 0};
-        const int qi = QI[j], qj = QJ[j];
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        for (int q = 0; q < NSLOT; ++q) piece(q, kt_dma, dma_lds);
+      } else {
+        // pinned software pipeline of the fragment reads (gemm_big_kernel SCHED 6): the 8 W fragments of the k-tile up front, the
+        // activation fragments through a 3-register ring two steps ahead, one DMA piece behind each of the first 9 row-tile steps
+        bf16x8 fb[2][NT], fa[3];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < NT; ++j) fb[kk][j] = as_bf16x8(s[boff + (j * 2 + kk) * 64]);
+        fa[0] = as_bf16x8(s[aoff[0]]);
+        fa[1] = as_bf16x8(s[aoff[0] + 128]);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[qi * 4 + i][qj * 2 + c] = mfma16(fb[qj][c][kk], fa[i][kk], acc[qi * 4 + i][qj * 2 + c]);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        for (int t = 0; t < 2 * MTW; ++t) {
+          if (t + 2 < 2 * MTW) fa[(t + 2) % 3] = as_bf16x8(s[aoff[(t + 2) / MTW] + ((t + 2) % MTW) * 128]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[t % MTW][j] = mfma16(fb[t / MTW][j], fa[t % 3], acc[t % MTW][j]);
+          if (t < NSLOT) piece(t < NSLOT ? t : 0, kt_dma, dma_lds);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT + 2, 0);
+#pragma unroll
+        for (int t = 0; t < 2 * MTW; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        }
       }
-      if (wm == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();      // group 0 finishes one interval early: same barrier count for every wave
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies of the last k-tile
-  tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped copies of the last iteration
+    if constexpr (MTW > 0)
+      tile_epilogue<EPI, MTW, NT>(acc, m0 + my_row0, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, nullptr);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I8 = std::integral_constant<int, 8>;
+  using I9 = std::integral_constant<int, MTX>;
+  if (!wave_has_rows) run(I0{});
+  else if (my_mt == MTX) run(I9{});
+  else run(I8{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1016,133 +966,11 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
   else { if (mt_live <= 4) run(I4{}, I4{}); else run(I7{}, I4{}); }
 }
 
-// ------------------------------------------------------------------------------------------------
-// tall GEMM, 4-stage ring of 32-k HALF tiles (round 3)
-// ------------------------------------------------------------------------------------------------
-// Hypothesis tested: with two stages the DMA of tile kt+1 can only be issued once tile kt-1 is released, so if one L2 -> LDS round trip
-// were as long as a tile's MFMAs every k-step would pay max(MFMA, round trip) plus the barrier.  The tall tile cannot hold a third
-// 76-KB stage, so here the stage is a 32-k HALF tile (38 KB: 448 rows x 64 B of activations + 10 W fragment sub-tiles), four of them in
-// the same 152 KB: three half tiles (1.5 k-tiles) are in flight across every barrier and the accumulation order over k is unchanged
-// (bit-identical to gemm_tall_kernel).  RESULT: not faster (see g_tall_ring below: the DMA is throughput-bound) -- kept as variant 9.
-//   * A half image: [448 rows][4 x 16 B]; a DMA instruction copies 16 rows x 64 B; the 16-byte chunk of row r sits at position
-//     chunk ^ ((r >> 1) & 3) -- measured conflict-free for ds_read_b128 on gfx950 (tools/probes/lds_b128_probe.hip: 4.3 clk per wave
-//     instruction like the linear W read; unswizzled 64-byte rows or chunk ^ (r >> 2) take 8.0); applied to the per-lane DMA source
-//     and again on the fragment read.
-//   * every wave issues exactly 5 DMA instructions per half tile (28 activation pieces + 10 W sub-tiles + 2 repeats), so ONE counted
-//     s_waitcnt vmcnt(10) leaves the two later half tiles in flight.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_tall4_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
-    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
-    bf16_t* __restrict__ C, int ldc, int M, int N, int K) {
-  constexpr int BM = 448, BN = 160, BK = 32, WM = 112, MT = 7, NT0 = 6, NSTAGE = 4, PW = 5;
-  constexpr int A_UNITS = BM * 4;                 // 16-byte units of the A half image (64 B per row)
-  constexpr int A_PIECES = BM / 16;               // 28 DMA pieces of 16 rows
-  constexpr int B_SUB = BN / 16;                  // 10 fragment sub-tiles of 1 KB (one 32-k block each)
-  constexpr int STAGE = A_UNITS + B_SUB * 64;     // 2432 units = 38,912 B
-  extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
-
-  const int n0 = blockIdx.x * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
-  const int li = lane & 15, g = lane >> 4;
-  const int K32 = K >> 5, nfrag = N >> 4;
-  const int rows_left = M - wm * WM;                                     // wave-uniform
-  const int mt_live = rows_left <= 0 ? 0 : min(MT, (rows_left + 15) >> 4);
-
-  // DMA pieces of this wave: p = wave * 5 + q; p < 28: activation rows 16p..16p+15; 28 <= p < 38: W sub-tile p - 28; else a repeat
-  const bf16_t* src[PW];
-  int dst[PW], kstep[PW];                          // LDS unit inside a stage; source advance per half tile (elements)
-#pragma unroll
-  for (int q = 0; q < PW; ++q) {
-    int p = wave * PW + q;
-    if (p >= A_PIECES + B_SUB) p -= A_PIECES + B_SUB;        // pieces 38, 39 repeat pieces 0, 1 (same bytes to the same place)
-    if (p < A_PIECES) {
-      const int rl = lane >> 2, c = (lane & 3) ^ ((rl >> 1) & 3);
-      src[q] = A + (size_t)min(p * 16 + rl, M - 1) * lda + c * 8;
-      dst[q] = p * 64;
-      kstep[q] = BK;
-    } else {
-      const int st = p - A_PIECES;
-      const int fr = min((n0 >> 4) + st, nfrag - 1);
-      src[q] = W + (size_t)fr * K32 * 512 + lane * 8;
-      dst[q] = A_UNITS + st * 64;
-      kstep[q] = 512;
-    }
-  }
-  auto issue = [&](int kt, int stage) {
-    u32x4* sbase = dsmem + stage * STAGE;
-#pragma unroll
-    for (int q = 0; q < PW; ++q)
-      glds16((src[q] + (size_t)kt * kstep[q]), lds_addr(sbase + dst[q]));
-  };
-
-  f32x4 acc[MT][NT0];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT0; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K / BK;
-#pragma unroll
-  for (int p = 0; p < NSTAGE - 1; ++p)
-    if (p < nkt) issue(p, p);
-  const int aoff = (wm * WM + li) * 4 + (g ^ ((li >> 1) & 3));
-  const int boff = A_UNITS + (wn * NT0) * 64 + lane;
-
-  // one half tile of this wave: the NTW W fragments are read up front, the activation fragments stream through a 3-register ring two
-  // row tiles ahead of their MFMAs
-  auto htile = [&](const u32x4* s, auto mtw_c, auto ntw_c) {
-    constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
-    bf16x8 fb[NTW], fa[3];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) fb[j] = as_bf16x8(s[boff + j * 64]);
-    fa[0] = as_bf16x8(s[aoff]);
-    if (MTW > 1) fa[1] = as_bf16x8(s[aoff + 64]);
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      if (i + 2 < MTW) fa[(i + 2) % 3] = as_bf16x8(s[aoff + (i + 2) * 64]);
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(fb[j], fa[i % 3], acc[i][j]);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, NTW + (MTW > 1 ? 2 : 1), 0);
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      if (i + 2 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);
-    }
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I4 = std::integral_constant<int, 4>;
-  using I6 = std::integral_constant<int, 6>;
-  using I7 = std::integral_constant<int, 7>;
-  const int nbase = n0 + wn * NT0 * 16;
-  auto run = [&](auto mtw_c, auto ntw_c) {
-    constexpr int MTW = decltype(mtw_c)::value, NTW = decltype(ntw_c)::value;
-    for (int kt = 0; kt < nkt; ++kt) {
-      // this wave's pieces of half tile kt have landed; up to two later half tiles stay in flight across the barrier
-      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // half tile kt complete in LDS; every wave is done reading half tile kt-1 (= the stage refilled next)
-      if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) & (NSTAGE - 1));
-      if constexpr (MTW > 0) htile(dsmem + (kt & (NSTAGE - 1)) * STAGE, mtw_c, ntw_c);
-    }
-    if constexpr (MTW > 0)
-      tile_epilogue<EPI, (MTW > 0 ? MTW : 1), (MTW > 0 ? NTW : 2), MT, NT0>(acc, wm * WM, nbase, nbase / 2, li, g, bias, residual, ldr, C, ldc, M, N,
-                                                                        nullptr, nullptr);
-  };
-  if (mt_live == 0) run(I0{}, I4{});                 // no rows: DMA + barriers only
-  else if (wn == 0) { if (mt_live <= 4) run(I4{}, I6{}); else run(I7{}, I6{}); }
-  else { if (mt_live <= 4) run(I4{}, I4{}); else run(I7{}, I4{}); }
-}
-
 // 0: register-staged 2-stage kernel; 1: LDS-DMA 3-stage kernel; 2 (default): measured best per tile shape --
 // 64-row tiles (72 KB ring, 2 blocks/CU) take the LDS-DMA kernel (1.5-1.6x), 128-row tiles keep the register-staged
 // kernel (64 KB, 2 blocks/CU; the 96 KB ring would leave 1 block/CU and measured 0.75x).
 static int g_gemm_variant = 2;
 static int g_gemm_sched = 1;   // fragment-read schedule of gemm_big_kernel: 0 compiler order, 1 pinned software pipeline
-static int g_gemm_pp_default = -1;
 void set_gemm_variant(int v);
 
 template <int BM, int EPI>
@@ -1165,55 +993,41 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
       (nkt + S - 1) / S, a.wscale);
 }
 
-// round-5 tuning knobs of the 8-wave kernel (A/B: environment, read once): LCC_GEMM_RASTER = band width of the tile order (0: column-major),
-// LCC_GEMM_L2PF = run-ahead distance in k-tiles of the L2 prefetch wave (0: off; two-stage bf16 tiles with the spread DMA schedule only)
-static int g_gemm_raster = [] { const char* v = getenv("LCC_GEMM_RASTER"); return v ? atoi(v) : 0; }();
-static int g_gemm_l2pf = [] { const char* v = getenv("LCC_GEMM_L2PF"); return v ? atoi(v) : 0; }();
-template <int BM, int EPI, int SCHED, bool W8, int PF = 0>
+// LCC_GEMM_RASTER (A/B, read once): band width of the tile order of the 8-wave kernels; default 4 (bands of 4 column tiles walked row-major:
+// the ~32 tiles an XCD runs at a time form an 8 x 4 super-tile), 0 = column-major (rounds 2-4)
+static int g_gemm_raster = [] { const char* v = getenv("LCC_GEMM_RASTER"); return v ? atoi(v) : 4; }();
+template <int BM, int EPI, int SCHED, bool W8>
 static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages; PF: + 1 KB of scratch
-  constexpr size_t lds = (size_t)((BM >= 192 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16 + (PF > 0 ? 1024 : 0);
+  // bf16: 128 KB (BM 256, 2 stages) / 144 KB (BM 128, 3 stages); fp8 W: 144 KB (BM 256) / 96 KB (BM 128), 3 stages
+  constexpr size_t lds = (size_t)((BM >= 192 && !W8) ? 2 : 3) * (BM * 8 + (W8 ? 1024 : 2048)) * 16;
   static DeviceOnce attr_set;   // per instantiation
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  gemm_big_kernel<BM, EPI, SCHED, W8, PF><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+  gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq,
       g_gemm_raster);
 }
-// the default schedule (SCHED 6) of a bf16 two-stage tile, with or without the L2 run-ahead wave
-template <int BM, int EPI>
-static void launch_big_6(const GemmArgs& a, hipStream_t st) {
-  if constexpr (BM >= 192) {
-    if (g_gemm_l2pf >= 3 && a.K / 64 >= 8) return launch_big_s<BM, EPI, 6, false, 3>(a, st);
-    if (g_gemm_l2pf >= 1 && a.K / 64 >= 8) return launch_big_s<BM, EPI, 6, false, 2>(a, st);
-  }
-  launch_big_s<BM, EPI, 6, false>(a, st);
+// variable-height row tiles (gemm_vh_kernel): tiles_m = floor(F / 16) row tiles for F = ceil(M / 16) row fragments
+static bool vh_legal(const GemmArgs& a) {
+  const int F = (a.M + 15) >> 4, t = F >> 4;
+  return a.w_packed && !a.w_fp8 && (a.K % 64) == 0 && t >= 1 && F <= 18 * t && (a.N & 15) == 0;
 }
-// 0: gemm_big_kernel<256> (round 2/3), 1: gemm_pp_kernel (ping-pong wave groups), 2: the same with s_setprio(1) around the MFMA clusters.
-// LCC_GEMM_PP / lcc_debug_set_gemm_variant(10 / 11 / 12) select it.
-static int g_gemm_pp = [] { const char* v = getenv("LCC_GEMM_PP"); return v ? atoi(v) : 0; }();
-template <int EPI, int PRIO>
-static void launch_pp(const GemmArgs& a, hipStream_t st) {
-  const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
+template <int EPI>
+static void launch_vh(const GemmArgs& a, hipStream_t st) {
+  const int F = (a.M + 15) >> 4, tiles_m = F >> 4, tiles_n = (a.N + 255) / 256;
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  constexpr size_t lds = (size_t)2 * (256 * 8 + 2048) * 16;      // two 64-KB stages
+  constexpr size_t lds = (size_t)2 * (288 * 8 + 2048) * 16 + 1024;      // two 69,632-B stages + the scratch
   static DeviceOnce attr_set;   // per instantiation
-  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  g_launch_counts[LC_GEMM_PP]++;
-  gemm_pp_kernel<EPI, PRIO><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
-      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S);
+  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_vh_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  g_launch_counts[LC_GEMM_VH]++;
+  gemm_vh_kernel<EPI><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, g_gemm_raster);
 }
 template <int BM, int EPI>
 static void launch_big(const GemmArgs& a, hipStream_t st) {
-  if constexpr (BM == 256) {
-    if (g_gemm_pp != 0 && !a.w_fp8) {
-      if (g_gemm_pp == 2) return launch_pp<EPI, 1>(a, st);
-      return launch_pp<EPI, 0>(a, st);
-    }
-  }
   if constexpr (BM == 256 && EPI == EPI_SWIGLU) {
     // LCC_GEMM_DIAG (tools/bench_gemm_diag.py; results are WRONG by construction): 2 = no DMA after the prologue, 3 = no MFMAs
     static const int diag = [] { const char* v = getenv("LCC_GEMM_DIAG"); return v ? atoi(v) : 0; }();
@@ -1227,16 +1041,12 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
   // GEMMs, +0.6 / +0.8 % tokens/s at 1 / 8 streams, profiles/r03/gemm_sched_spread_dma.txt); LCC_GEMM_SCHED=1 restores SCHED 1
   static const int spread = [] { const char* v = getenv("LCC_GEMM_SCHED"); return (v && atoi(v) == 1) ? 0 : 1; }();
   if (a.w_fp8) launch_big_s<(BM == 192 ? 256 : BM), EPI, 1, true>(a, st);     // the 192-row tile is a bf16-weight shape (big_tile_rows never picks it for fp8)
-  else if (g_gemm_sched && spread) launch_big_6<BM, EPI>(a, st);
+  else if (g_gemm_sched && spread) launch_big_s<BM, EPI, 6, false>(a, st);
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
 }
-// variants 10 / 11 / 12: the 256-row 8-wave tile wherever eligible (like 3), served by gemm_big_kernel / gemm_pp_kernel / gemm_pp + setprio;
-// 13: the 192-row tile wherever eligible (bf16 weights)
+// 13: the 192-row tile wherever eligible (bf16 weights); 14: variable-height row tiles (gemm_vh_kernel) wherever legal, else as 3
 void set_gemm_variant(int v) {
-  if (g_gemm_pp_default < 0) g_gemm_pp_default = g_gemm_pp;
-  if (v >= 10 && v <= 12) { g_gemm_pp = v - 10; v = 3; }
-  else g_gemm_pp = g_gemm_pp_default;
   g_gemm_variant = v;
   g_gemm_sched = (v == 5 || v == 6) ? 0 : 1;
 }
@@ -1262,8 +1072,12 @@ static float tile_score(int M, int N, int S, int BM, int BN, int slots, float ef
 // BM 192 (round 4, bf16 weights): a 256-row tile leaves the chip partly idle whenever (M / 256) x (N / 256) falls just short of a round --
 // the o / down projections of 8 co-scheduled chunks are M = 3088 x N = 3584 = 13 x 14 = 182 blocks on 256 CUs (29 % idle); 17 x 14 = 238
 // blocks of 192 rows fill 93 % of one round at 3/4 of the tile time.  The tile moves 17 % more L2 -> LDS bytes per flop (efficiency 0.93).
+// Variable-height tiles (round 5; returned as 272): floor(F / 16) row tiles of 16-18 fragments -- scored with every tile as tall as the
+// tallest (a 17-fragment tile costs 17/16 of a 256-row tile on every SIMD), no ragged tile, the 256-row tile's efficiency.
+// LCC_GEMM_VH=0: rounds 2-4 tile choice.
 static int big_tile_rows(const GemmArgs& a, int S) {
   if (!big_eligible(a)) return 0;
+  if (g_gemm_variant == 14) return vh_legal(a) ? 272 : 256;
   if (g_gemm_variant == 3 || g_gemm_variant == 5) return 256;
   if (g_gemm_variant == 4 || g_gemm_variant == 6) return 128;
   if (g_gemm_variant == 13) return a.w_fp8 ? 256 : 192;
@@ -1273,6 +1087,13 @@ static int big_tile_rows(const GemmArgs& a, int S) {
   const float s192 = (a.w_fp8 || !allow192) ? 0.f : tile_score(a.M, a.N, S, 192, 256, 256, 0.93f, true);
   const float s128 = tile_score(a.M, a.N, S, 128, 256, 256, 0.85f, true);
   const float s64 = tile_score(a.M, a.N, S, 64, 128, 512, 0.55f, false);
+  static const int allow_vh = [] { const char* v = getenv("LCC_GEMM_VH"); return v ? atoi(v) : 1; }();
+  if (allow_vh && vh_legal(a) && (((a.M + 15) >> 4) & 15) != 0) {      // F % 16 == 0: the 256-row tiles are the same thing
+    const int F = (a.M + 15) >> 4, t = F >> 4, maxf = (F + t - 1) / t;
+    const long blocks = (long)t * ((a.N + 255) / 256) * S;
+    const float svh = (float)a.M / (float)(t * maxf * 16) * (float)blocks / (float)((blocks + 255) / 256 * 256);
+    if (svh > s256 && svh > s192 && svh > s128 && svh > s64) return 272;
+  }
   if (s256 >= s192 && s256 >= s128 && s256 >= s64) return 256;
   if (s192 >= s128 && s192 >= s64) return 192;
   if (s128 >= s64) return 128;
@@ -1284,27 +1105,16 @@ static int big_tile_rows(const GemmArgs& a, int S) {
 static bool tall_legal(const GemmArgs& a) { return big_eligible(a) && !a.w_fp8 && a.M <= 448 && (a.N & 15) == 0; }
 static bool tall_wanted(const GemmArgs& a) {
   if (!tall_legal(a)) return false;
-  if (g_gemm_variant == 8 || g_gemm_variant == 9) return true;
+  if (g_gemm_variant == 8) return true;
   if (g_gemm_variant != 2) return false;
   const int blocks = (a.N + 159) / 160;
   return a.M > 256 && blocks >= 192 && blocks <= 256;
 }
-// ring of the tall tile: 2 whole k-tiles (default) or 4 half tiles (LCC_TALL_RING=4 / variant 9).  Measured equal-to-slower on MI355X
-// (122.5 vs 125.2 us at M = 386 on random operands, 278.6 vs 277.2 tokens/s end to end, profiles/r03/gemm_tall_ring.txt): the L2 -> LDS
-// DMA is THROUGHPUT-bound, not round-trip-bound -- in gemm_big_kernel<256> the activation half of the ring alone takes 327 us, the W
-// half alone 374 us, both 580 us (~12 TB/s chip-wide, ~25 B/clk/CU) against 654 us for the MFMAs alone and 830 us for the kernel
-// (LCC_GEMM_DIAG 0-5, profiles/r03/gemm_diag.jsonl) -- so a deeper ring has nothing to hide.
-static int g_tall_ring = [] { const char* v = getenv("LCC_TALL_RING"); return (v && atoi(v) == 4) ? 4 : 2; }();
+// (a 4-stage ring of 32-k half tiles in the same LDS was measured equal-to-slower -- 122.5 vs 125.2 us at M = 386, profiles/r03/gemm_tall_ring.txt:
+// the L2 -> LDS DMA is throughput-bound, a deeper ring has nothing to hide -- and was retired in round 5)
 template <int EPI>
 static void launch_tall(const GemmArgs& a, hipStream_t st) {
   g_launch_counts[LC_GEMM_TALL]++;
-  if (g_tall_ring == 4 || g_gemm_variant == 9) {     // variant 9 forces the tall tile with the 4-stage ring of half tiles (A/B, tests)
-    constexpr size_t lds4 = (size_t)4 * (448 * 4 + 10 * 64) * 16;   // 155,648 B
-    static DeviceOnce attr4;   // per instantiation
-    if (attr4.first()) (void)hipFuncSetAttribute((const void*)gemm_tall4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-    gemm_tall4_kernel<EPI><<<dim3((a.N + 159) / 160), dim3(512), lds4, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
-    return;
-  }
   constexpr size_t lds = (size_t)2 * (448 * 8 + 20 * 64) * 16;   // 155,648 B
   static DeviceOnce attr_set;   // per instantiation
   if (attr_set.first()) {
@@ -1327,6 +1137,7 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
     if (tall_wanted(a)) return launch_tall<EPI>(a, st);
   }
   const int big = big_tile_rows(a, 1);
+  if (big == 272) return launch_vh<EPI>(a, st);
   if (big == 256) return launch_big<256, EPI>(a, st);
   if (big == 192) return launch_big<192, EPI>(a, st);
   if (big == 128) return launch_big<128, EPI>(a, st);
@@ -1859,19 +1670,20 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
     if (qk && (((uintptr_t)q.cs | (uintptr_t)q.sn) & 15) != 0) return LCC_ERR_ALIGN;
     if ((v && ((uintptr_t)q.vt & 7) != 0) || (a.bias != nullptr && ((uintptr_t)a.bias & 7) != 0)) return LCC_ERR_ALIGN;
     g_launch_counts[LC_GEMM_VIT_QKV]++;
-    const int big = big_tile_rows(a, 1);
+    int big = big_tile_rows(a, 1);
+    if (big == 272) big = 256;      // the rotation / transposed-V epilogues live on the fixed-height tiles
     if (a.epilogue == EPI_VIT_QKV) {
-      if (big == 256) launch_big_6<256, EPI_VIT_QKV>(a, st);
-      else if (big == 192) launch_big_6<192, EPI_VIT_QKV>(a, st);
-      else launch_big_6<128, EPI_VIT_QKV>(a, st);
+      if (big == 256) launch_big_s<256, EPI_VIT_QKV, 6, false>(a, st);
+      else if (big == 192) launch_big_s<192, EPI_VIT_QKV, 6, false>(a, st);
+      else launch_big_s<128, EPI_VIT_QKV, 6, false>(a, st);
     } else if (qk) {
-      if (big == 256) launch_big_6<256, EPI_VIT_QK>(a, st);
-      else if (big == 192) launch_big_6<192, EPI_VIT_QK>(a, st);
-      else launch_big_6<128, EPI_VIT_QK>(a, st);
+      if (big == 256) launch_big_s<256, EPI_VIT_QK, 6, false>(a, st);
+      else if (big == 192) launch_big_s<192, EPI_VIT_QK, 6, false>(a, st);
+      else launch_big_s<128, EPI_VIT_QK, 6, false>(a, st);
     } else {
-      if (big == 256) launch_big_6<256, EPI_VIT_V>(a, st);
-      else if (big == 192) launch_big_6<192, EPI_VIT_V>(a, st);
-      else launch_big_6<128, EPI_VIT_V>(a, st);
+      if (big == 256) launch_big_s<256, EPI_VIT_V, 6, false>(a, st);
+      else if (big == 192) launch_big_s<192, EPI_VIT_V, 6, false>(a, st);
+      else launch_big_s<128, EPI_VIT_V, 6, false>(a, st);
     }
     return 0;
   }
@@ -1903,7 +1715,8 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   if (a.partial != nullptr) {   // split-K slabs on the tiled path (prefill GEMMs with few output tiles)
     if (a.epilogue != EPI_NONE || a.nsplit < 1 || a.nsplit > 8 || a.nsplit > (a.K + 63) / 64) return LCC_ERR_ARG;
     const int big = big_tile_rows(a, a.nsplit);
-    if (big == 256) launch_big<256, EPI_PARTIAL>(a, st);
+    if (big == 272) launch_vh<EPI_PARTIAL>(a, st);
+    else if (big == 256) launch_big<256, EPI_PARTIAL>(a, st);
     else if (big == 192) launch_big<192, EPI_PARTIAL>(a, st);
     else if (big == 128) launch_big<128, EPI_PARTIAL>(a, st);
     else launch_tiled<64, EPI_PARTIAL>(a, st);

@@ -26,7 +26,7 @@ enum LaunchCounter {
   LC_LAST_PREFILL_NSPLIT = 11, // key splits of the most recent prefill attention launch
   LC_GEMM_TALL = 12,
   LC_ATTN_VIT32 = 13,          // attn_vit32_kernel (vision attention on 32x32x16 MFMAs)
-  LC_GEMM_PP = 14,             // gemm_pp_kernel (256 x 256 tile, ping-pong wave groups)
+  LC_GEMM_VH = 14,             // gemm_vh_kernel (row tiles of 256 / 272 / 288 rows; round 5 -- the slot of the retired gemm_pp_kernel)
   LC_GEMM_VIT_QKV = 15,        // gemm_big_kernel with the EPI_VIT_QK / EPI_VIT_V epilogues (RoPE / V transpose fused into the q|k|v projection; 2 per tower block)
   LC_COUNT = 16
 };

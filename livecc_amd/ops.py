@@ -109,7 +109,7 @@ ATTN_DEFAULT_VARIANT = 3
 
 LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "attn_decode_fused_merge", "gemv_fused_tail", "dgemv_v2",
                    "attn_prefill_mfma32", "attn_prefill_shared", "attn_prefill_per_wave", "attn_prefill_combine", "last_decode_nsplit",
-                   "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_pp", "gemm_vit_qkv")
+                   "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_vh", "gemm_vit_qkv")
 
 
 def launch_counts(reset: bool = False) -> dict:

@@ -69,12 +69,13 @@ def _layout_variants(variants):
 @pytest.mark.parametrize("M,N,K", [(200, 512, 256), (386, 1280, 1176), (130, 480, 160), (64, 1024, 640), (1456, 3840, 1280),
                                    (17, 256, 512), (300, 4608, 3584), (260, 272, 192), (100, 256, 64), (600, 768, 512)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 2, 3, 4, 5, 6, 11, 12, 13]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 2, 3, 4, 5, 6, 13, 14]))
 def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
     """variant 0: register-staged 2-stage kernel; 1: LDS-DMA (global_load_lds) 3-stage ring; 2: auto (default);
     3 / 4: the 8-wave 256x256 / 128x256 LDS-DMA kernel wherever it is eligible (packed W, K % 64 == 0), pinned fragment-read
-    schedule; 5 / 6: the same with the compiler's schedule; 13: the 192x256 tile (round 4); 11 / 12: the 256x256 tile as gemm_pp_kernel (ping-pong wave groups; 12 with
-    s_setprio around the MFMA clusters)."""
+    schedule; 5 / 6: the same with the compiler's schedule; 13: the 192x256 tile (round 4); 14: row tiles of variable height (256 / 272 / 288
+    rows, gemm_vh_kernel, round 5) wherever they are legal (M = 260, 300: one tile of 17 / 19 -> two tiles; 386: 25 fragments -> not legal,
+    256-row tiles; 600: two tiles of 19 fragments -> not legal; 1456: 91 fragments = 5 tiles of 18 / 19 -> not legal)."""
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
     res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
@@ -88,7 +89,7 @@ def test_gemm_tiled(dev, M, N, K, epi, packed, variant):
 
 
 @pytest.mark.parametrize("M,I,K", [(100, 512, 256), (386, 2432, 896), (530, 400, 128)])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 6, 11, 12, 13]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 6, 13, 14]))
 def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
     from livecc_amd import ops
     x, w = _rand((M, K), dev, 1.0, 1), _rand((2 * I, K), dev, 0.05, 2)
@@ -104,11 +105,11 @@ def test_gemm_tiled_swiglu(dev, M, I, K, packed, variant):
 @pytest.mark.parametrize("M", [17, 113, 225, 337, 386, 448])
 @pytest.mark.parametrize("N,K", [(160, 64), (352, 256), (4608, 3584)])
 @pytest.mark.parametrize("epi", [0, 1, 3, 4])
-@pytest.mark.parametrize("variant", [8, 9], ids=["ring_of_2_tiles", "ring_of_4_half_tiles"])
+@pytest.mark.parametrize("variant", [8], ids=["ring_of_2_tiles"])
 def test_gemm_tall_kernel(dev, M, N, K, epi, variant):
-    """Variants 8 / 9 force the tall tile (one block row covers all of M <= 448, 448 x 160 tiles, 4 x 2 waves with 6 + 4 column
-    tiles) with the 2-stage ring of whole k-tiles (`gemm_tall_kernel`, the default) / the 4-stage ring of 32-k half tiles
-    (`gemm_tall4_kernel`, a measured variant): every live-row-tile path of the last M-wave (M = 337: one row tile, 386: four, 448: seven), M-waves without
+    """Variant 8 forces the tall tile (one block row covers all of M <= 448, 448 x 160 tiles, 4 x 2 waves with 6 + 4 column
+    tiles, 2-stage ring of whole k-tiles; the 4-stage ring of 32-k half tiles of round 3 was retired in round 5 as a measured
+    loser): every live-row-tile path of the last M-wave (M = 337: one row tile, 386: four, 448: seven), M-waves without
     rows (M = 17, 113, 225), a ragged last column block (N = 352), bias / quick-GELU / residual / SwiGLU epilogues."""
     from livecc_amd import ops
     x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
@@ -124,6 +125,45 @@ def test_gemm_tall_kernel(dev, M, N, K, epi, variant):
     assert_bf16_close(got, ref, f"gemm_tall[{M}x{N}x{K},epi{epi},v{variant}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
+@pytest.mark.parametrize("M", [256 + 16, 272 + 7, 288, 2 * 256 + 1, 2 * 288 - 16, 3088, 1131])
+@pytest.mark.parametrize("N,K,epi", [(512, 256, 0), (768, 192, 3), (3584, 1024, 4)])
+def test_gemm_variable_height_tiles_are_bit_identical_to_the_256_row_tiles(dev, M, N, K, epi):
+    """gemm_vh_kernel (round 5): F = ceil(M / 16) row fragments dealt out over floor(F / 16) row tiles of 16-18 fragments -- one tile of
+    17 / 18 fragments, a partial last fragment (M = 279, 513), two tiles of 17 + 16 and 18 + 17, the benchmark's 8 x 386 = 3088 rows (12
+    tiles, one of them 272 rows) and the first turn's 1131 rows (4 tiles of 288 / 272) -- with bias, residual and SwiGLU epilogues: the
+    accumulation order per output element is gemm_big_kernel<256>'s, so the outputs are bit-identical to variant 3, and the kernel really
+    ran (launch counter)."""
+    from livecc_amd import ops
+    x, w, b = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2), _rand((N,), dev, 0.1, 3)
+    res = _rand((M, N), dev, 1.0, 4) if epi == 3 else None
+    wp = ops.pack_weight(w)
+    try:
+        ops.set_gemm_variant(3)
+        ref = ops.linear(x, wp, None if epi == 4 else b, epi, res, packed_shape=(N, K))
+        ops.set_gemm_variant(14)
+        before = ops.launch_counts()["gemm_vh"]
+        got = ops.linear(x, wp, None if epi == 4 else b, epi, res, packed_shape=(N, K))
+        assert ops.launch_counts()["gemm_vh"] == before + 1
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} outputs differ from the 256-row tiles"
+    exp, atol = _ref_linear(x, w, None if epi == 4 else b, epi, res, with_atol=True)
+    assert_bf16_close(got, exp, f"gemm_vh[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
+
+
+def test_gemm_auto_choice_picks_the_variable_height_tiles_for_eight_chunks(dev):
+    """M = 3088 (8 x 386 rows), 7B gate/up: the default tile choice takes gemm_vh_kernel (12 x 148 blocks = 6.9 rounds instead of 13 x 148 =
+    7.5 -> 8); the o / down shapes (14 column tiles) keep the 192-row tile."""
+    from livecc_amd import ops
+    x, w = _rand((3088, 512), dev, 1.0, 1), _rand((2 * 18944, 512), dev, 0.05, 2)
+    before = ops.launch_counts()["gemm_vh"]
+    ops.linear(x, ops.pack_weight(w), None, ops.EPI_SWIGLU, packed_shape=(2 * 18944, 512))
+    assert ops.launch_counts()["gemm_vh"] == before + 1
+    xd, wd, res = _rand((3088, 512), dev, 1.0, 3), _rand((3584, 512), dev, 0.05, 4), _rand((3088, 3584), dev, 1.0, 5)
+    ops.linear(xd, ops.pack_weight(wd), None, ops.EPI_RESIDUAL, res, packed_shape=(3584, 512))
+    assert ops.launch_counts()["gemm_vh"] == before + 1
+
+
 def test_gemm_auto_choice_at_the_7b_chunk_shape_is_the_tall_kernel_and_matches(dev):
     """LiveCC-7B gate/up of one streaming chunk (M = 386, N = 2 x 18944, K = 3584, SwiGLU): the default variant takes the tall kernel
     (237 blocks = one round); same result as the forced 128 x 256 tiles up to the summation order, and within the bound of the fp32
@@ -136,14 +176,11 @@ def test_gemm_auto_choice_at_the_7b_chunk_shape_is_the_tall_kernel_and_matches(d
     ops.set_gemm_variant(8)
     try:
         tall = ops.linear(x, wp, None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
-        ops.set_gemm_variant(9)
-        tall2 = ops.linear(x, wp, None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
         ops.set_gemm_variant(4)
         big = ops.linear(x, wp, None, ops.EPI_SWIGLU, packed_shape=(2 * I, K))
     finally:
         ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
     assert torch.equal(got, tall), "the default variant must be the tall kernel at this shape"
-    assert torch.equal(tall, tall2), "the half-tile ring (variant 9) keeps the accumulation order over k: bit-identical to the 2-stage ring"
     ref, atol = _ref_linear(x, w, None, 4, with_atol=True)
     assert_bf16_close(got, ref, "gemm_tall_7b_gate_up", max_ulp=1.0, max_frac=5e-3, atol=atol)
     assert_bf16_close(big, ref, "gemm_big128_7b_gate_up", max_ulp=1.0, max_frac=5e-3, atol=atol)
@@ -292,7 +329,7 @@ def test_gemv_17_to_64_rows_swiglu(dev, M, I, K):
 
 
 @pytest.mark.parametrize("M,N,K,S", [(100, 512, 1024, 2), (386, 3584, 3584, 4), (70, 256, 640, 3)])
-@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 5, 11, 13]))
+@pytest.mark.parametrize("packed,variant", _layout_variants([0, 1, 3, 4, 5, 13, 14]))
 def test_gemm_tiled_splitk_slabs(dev, M, N, K, S, packed, variant):
     """prefill split-K: fp32 slabs [S][M][N] whose sum is the product (reduced by add_rmsnorm in the engine)."""
     from livecc_amd import ops

@@ -183,6 +183,30 @@ print("configs3", json.dumps(d.get("configs3_oneshot480"))[:1200])
 print("configs4", json.dumps(d.get("configs4_72b_fp8"))[:1200])
 PY
   ;;
+r5c)         # round 5, call 3: variable-height GEMM tiles + raster default + attention cross-region prefetch: bit-identity, tests, A/B
+  OLD=$R/livecc_amd/_C_r4/liblivecc_amd.so
+  LCC_LIB_PATH=$OLD timeout 200 python tools/gemm_checksum.py > $O/sum_r4.txt 2>$O/sum_r4.err
+  for KV in "X=0" "LCC_GEMM_VH=0 LCC_GEMM_RASTER=0"; do
+    T=$(echo $KV | tr -d ' ='); env $KV timeout 200 python tools/gemm_checksum.py > $O/sum_$T.txt 2>$O/sum_$T.err
+    cmp -s $O/sum_r4.txt $O/sum_$T.txt && echo "checksums [$KV]: IDENTICAL to the round-4 build" || { echo "checksums [$KV] DIFFER"; paste $O/sum_r4.txt $O/sum_$T.txt; tail -n 3 $O/sum_$T.err; }
+  done
+  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_vit_fused.py -m gpu -q -x --timeout 800 > $O/ops_tests.log 2>&1; tail -n 5 $O/ops_tests.log
+  SH=gate_up_M3088,gate_up_M1131,gate_up_M24058,down_M3088,qkv_M3088,o_M3088,vit_fc1_P11648,vit_fc2_P11648,vit_qkv_P11648,vit_proj_P11648
+  LCC_LIB_PATH=$OLD timeout 300 python tools/r5_bench_gemm.py r4 $SH 2>$O/g_r4.err | tee -a $O/gemm_ab.jsonl | cut -c1-160
+  for KV in "X=0" "LCC_GEMM_VH=0" "LCC_GEMM_RASTER=0" "LCC_GEMM_RASTER=8" "X=1"; do
+    T=$(echo $KV | tr -d ' ='); env $KV timeout 300 python tools/r5_bench_gemm.py "$T" $SH 2>$O/g_$T.err | tee -a $O/gemm_ab.jsonl | cut -c1-160
+  done
+  for P in 0 1 0 1; do LCC_ATTN32_PIPE=$P timeout 300 python tools/bench_attn.py --quick 2>$O/attn_$P.err | grep '"variant": 3' | grep '"nsplit": 1,' | sed "s/^/pipe$P /" | tee -a $O/attn_ab.txt | cut -c1-200; done
+  for P in 0 1 0 1; do LCC_ATTN32_PIPE=$P timeout 300 python tools/r5_tower.py pipe$P 2>$O/tower_$P.err | tee -a $O/tower_ab.jsonl; done
+  for L in r4 new r4 new; do
+    if [ $L = r4 ]; then export LCC_LIB_PATH=$OLD; else unset LCC_LIB_PATH; fi
+    ( timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8s_$L.log 2>&1; echo "== 8 streams $L: $(val $O/bench_8s_$L.log value) tok/s"
+  done
+  for L in r4 new; do
+    if [ $L = r4 ]; then export LCC_LIB_PATH=$OLD; else unset LCC_LIB_PATH; fi
+    ( timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_$L.log 2>&1; echo "== 1 stream $L: $(val $O/bench_1s_$L.log value) tok/s"
+  done
+  unset LCC_LIB_PATH ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
