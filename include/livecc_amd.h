@@ -305,6 +305,14 @@ int lcc_engine_bind_kv(lcc_engine* e, int slot, void* kv_dev, size_t bytes);   /
 size_t lcc_engine_vit_workspace_bytes(const lcc_engine* e);
 size_t lcc_engine_vit_meta_bytes(const lcc_engine* e);
 int lcc_engine_bind_vit_buffers(lcc_engine* e, void* workspace_dev, size_t ws_bytes, void* meta_dev, void* meta_host_pinned, size_t meta_bytes);
+/* Workgroup budget of the NEXT lcc_vit_encode calls (round 5): cap > 0 = the tower's MFMA-bound kernels (GEMMs, attention) launch at most
+ * `cap` workgroups and walk their tiles persistently, i.e. they occupy `cap` of the 256 CUs; 0 = whole chip (default).  For a tower
+ * issued on the second stream UNDER another turn's decode steps: a resident 8-wave GEMM block leaves room for one weight-streaming
+ * decode wave per SIMD where five fit on a free CU, so a tower spread over every CU starves the HBM-bound decode kernels of their
+ * memory-level parallelism and simply adds its own duration to the decode steps; on half the CUs it takes twice as long under steps that
+ * keep their speed.  Same results (the tile -> output mapping does not change).  No reference counterpart: HF runs the tower and the
+ * decode loop strictly one after the other (Q2VL:1159-1176 inside forward). */
+int lcc_engine_set_vit_grid_cap(lcc_engine* e, int cap);
 /* weights by name, borrowed device pointers (bf16 unless stated):  see INTEGRATION.md for the name table */
 int lcc_engine_set_weight(lcc_engine* e, const char* name, const void* dev, int64_t numel);
 int lcc_engine_weights_ready(const lcc_engine* e, char* missing, int missing_len);

@@ -142,6 +142,7 @@ def load():
         "lcc_engine_vit_workspace_bytes": (sz, [vp]),
         "lcc_engine_vit_meta_bytes": (sz, [vp]),
         "lcc_engine_bind_vit_buffers": (i32, [vp, vp, sz, vp, vp, sz]),
+        "lcc_engine_set_vit_grid_cap": (i32, [vp, i32]),
         "lcc_engine_set_weight": (i32, [vp, C.c_char_p, vp, i64]),
         "lcc_engine_weights_ready": (i32, [vp, C.c_char_p, i32]),
         "lcc_engine_profile": (i32, [vp, i32, i32]),

@@ -379,18 +379,19 @@ LCC_DEVICE void wait_two_tiles_in_flight(int pw) {   // pw = DMA instructions pe
 __device__ unsigned int lcc_attn_zero_page[256];
 
 template <int D, int NQ, int MODE, int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
+LCC_DEVICE void attn_shared_body(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
     const int32_t* __restrict__ t0a, const int32_t* __restrict__ t1a, const int32_t* __restrict__ t2a,
     const int32_t* __restrict__ t3a, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_blk_start, bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer,
-    int heads, int total_blocks, float scale_log2e, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
+    int heads, int total_blocks, float scale_log2e, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml,
+    const int bx, const int by, const int bz) {       // the block's grid coordinates, or a virtual block of the persistent walk
   constexpr int KS = (D + 31) / 32, KP = 2 * KS, VP = D / 16, NP = KP + VP, NSTAGE = 4;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int nwave = NWAVE, pw = (NP + NWAVE - 1) / NWAVE;   // DMA instructions per wave per tile
   const int li = lane & 15, g = lane >> 4;
-  const int grp = blockIdx.x;
+  const int grp = bx;
 
   // ---- what this block streams (K rows, V^T blocks, number of keys) and what this wave computes
   const bf16_t* kbase; size_t kstride; const bf16_t* vbase; int nkeys;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
   int key_limit[NQ];
   int part_row0 = 0, part_head = 0;   // (row, head) of this wave's first query row, for split partials
   if (MODE == 0) {          // ViT: t0a = group segment, t1a = first query row of the group inside the segment
-    const int h = blockIdx.y, E = heads * D, ld = 3 * E;
+    const int h = by, E = heads * D, ld = 3 * E;
     const int sg = t0a[grp], q0 = t1a[grp] + wave * (NQ * 16);
     const int s0 = seg_start[sg], sl = seg_len[sg];
     kbase = q + (size_t)s0 * ld + E + h * D; kstride = ld;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
 #pragma unroll
     for (int n = 0; n < NQ; ++n) key_limit[n] = sl;
   } else {                  // prefill: t0a = stream slot, t1a = first row in q, t2a = valid rows, t3a = cache index of row 0
-    const int hk = blockIdx.y, G = heads / lay.n_kv_heads, h = hk * G + wave;
+    const int hk = by, G = heads / lay.n_kv_heads, h = hk * G + wave;
     const int strm = t0a[grp], q0 = t1a[grp], nq = t2a[grp], pos0 = t3a[grp];
     const bf16_t* base = kv_base[strm] + (size_t)layer * lay.layer_stride();
     kbase = base + (size_t)hk * lay.head_stride(); kstride = D;
@@ -427,9 +428,9 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
     for (int n = 0; n < NQ; ++n) key_limit[n] = pos0 + min(n * 16 + li, nq - 1) + 1;
   }
   const int ntile = (nkeys + 31) / 32;
-  // key split (blockIdx.z): this block handles key tiles [tb, te)
+  // key split (grid z): this block handles key tiles [tb, te)
   const int per = (ntile + nsplit - 1) / nsplit;
-  const int tb = (nsplit > 1) ? min(ntile, (int)blockIdx.z * per) : 0;
+  const int tb = (nsplit > 1) ? min(ntile, bz * per) : 0;
   const int te = (nsplit > 1) ? min(ntile, tb + per) : ntile;
 
   u32x4 qf[NQ][KS];
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
       l += __shfl_xor(l, 32, 64);
       const int r = n * 16 + li;
       if (r < nq_valid) {
-        const size_t slot = ((size_t)(part_row0 + r) * heads + part_head) * nsplit + blockIdx.z;
+        const size_t slot = ((size_t)(part_row0 + r) * heads + part_head) * nsplit + bz;
         float* op = ws_o + slot * D;
 #pragma unroll
         for (int dt = 0; dt < D / 16; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + g * 4) = acc.o[dt][n];
@@ -546,6 +547,28 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
         st8(op + dt * 16 + g * 4, (u32x2){pack2(o[0] * inv, o[1] * inv), pack2(o[2] * inv, o[3] * inv)});
       }
     }
+  }
+}
+
+// kernel: one block per (x, y, z) grid point, or -- vgx > 0 (the ViT launches under the grid cap, gemm.hip: g_grid_cap) -- a persistent walk over
+// the vgx x vgy virtual blocks
+template <int D, int NQ, int MODE, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+    const int32_t* __restrict__ t0a, const int32_t* __restrict__ t1a, const int32_t* __restrict__ t2a,
+    const int32_t* __restrict__ t3a, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
+    const int32_t* __restrict__ seg_blk_start, bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer,
+    int heads, int total_blocks, float scale_log2e, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml, int vgx, int vgy) {
+  if (vgx <= 0) {
+    attn_shared_body<D, NQ, MODE, NWAVE>(q, vt, out, t0a, t1a, t2a, t3a, seg_start, seg_len, seg_blk_start, kv_base, lay, layer, heads, total_blocks,
+                                         scale_log2e, nsplit, ws_o, ws_ml, blockIdx.x, blockIdx.y, blockIdx.z);
+    return;
+  }
+  const int nvb = vgx * vgy;
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    attn_shared_body<D, NQ, MODE, NWAVE>(q, vt, out, t0a, t1a, t2a, t3a, seg_start, seg_len, seg_blk_start, kv_base, lay, layer, heads, total_blocks,
+                                         scale_log2e, nsplit, ws_o, ws_ml, vb % vgx, vb / vgx, 0);
+    __syncthreads();     // the next virtual block's DMA ring reuses the stages (every wave returns from the body)
   }
 }
 
@@ -922,14 +945,18 @@ int attn_vit_bf16(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_
     // (neutral with it: the other stream's waves already fill the gaps).  LCC_VIT_ATTN_WAVES=4|8 forces one.
     static const int forced = [] { const char* v = getenv("LCC_VIT_ATTN_WAVES"); return v ? atoi(v) : 0; }();
     const int waves = forced ? forced : ((long)n_groups * heads <= 512 ? 8 : 4);
+    const int cap = get_grid_cap();
+    const bool capped = cap > 0 && (long)n_groups * heads > cap;
+    const int vgx = capped ? n_groups : 0, vgy = capped ? heads : 0;
+    const dim3 grid = capped ? dim3(cap) : dim3(n_groups, heads);
     if (waves == 8)
-      attn_shared_kernel<80, 1, 0, 8><<<dim3(n_groups, heads), dim3(512), lds, st>>>(
+      attn_shared_kernel<80, 1, 0, 8><<<grid, dim3(512), lds, st>>>(
           qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
-          heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
+          heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr, vgx, vgy);
     else
-      attn_shared_kernel<80, 2, 0, 4><<<dim3(n_groups, heads), dim3(256), lds, st>>>(
+      attn_shared_kernel<80, 2, 0, 4><<<grid, dim3(256), lds, st>>>(
           qkv, vt, out, grp_seg, grp_q0, nullptr, nullptr, seg_start, seg_len, seg_blk_start, nullptr, KvLayout{0, 1, 32, 80}, 0,
-          heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr);
+          heads, total_blocks, scale_l2e(80), 1, nullptr, nullptr, vgx, vgy);
     return 0;
   }
   attn_vit_kernel<80, 2><<<dim3((n_tiles + 3) / 4, heads), dim3(256), 0, st>>>(
@@ -969,10 +996,10 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
     if (once.first()) { set_lds_attr(attn_shared_kernel<128, 1, 1, GW>, lds); set_lds_attr(attn_shared_kernel<128, 2, 1, GW>, lds); } \
     if (tile_rows == 32)                                                                                                         \
       attn_shared_kernel<128, 2, 1, GW><<<grid, dim3(GW * 64), lds, st>>>(q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, \
-                                                                          nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml); \
+                                                                          nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml, 0, 0); \
     else                                                                                                                         \
       attn_shared_kernel<128, 1, 1, GW><<<grid, dim3(GW * 64), lds, st>>>(q, nullptr, out, tile_stream, tile_q0, tile_nq, tile_pos0, nullptr, \
-                                                                          nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml); \
+                                                                          nullptr, nullptr, kv_base, lay, layer, n_q_heads, 0, scale_l2e(128), S, ws_o, ws_ml, 0, 0); \
   } break;
     switch (G) {
       LCC_ATTN_SH(2) LCC_ATTN_SH(3) LCC_ATTN_SH(4) LCC_ATTN_SH(5) LCC_ATTN_SH(6) LCC_ATTN_SH(7) LCC_ATTN_SH(8)

@@ -57,11 +57,9 @@ __device__ unsigned int lcc_attn32_zero_page[256];
 // (32 d rows x 16 keys each), every piece 1 KB in MFMA fragment (lane) order.
 //   mlim: tiles reaching past it need the mask (causal diagonal / end of the key range); lim: this lane's effective key limit.
 //
-// PIPE 1 (round 5): the first three V^T fragments of a region are read at the END of the region before it (their stage has landed and
-// is not released before the next barrier), so the region's first MFMAs issue at once instead of behind an LDS round trip that nothing
-// in an in-order wave can cover (SQ counters, profiles/r05: 34-38 % of the wave cycles parked at s_waitcnt / s_barrier, 35 % issuing);
-// every MFMA then has exactly one fragment read behind it.  Same instructions on the same data: bit-identical.
-template <int D, int PW, int PIPE, class Issue>
+// (Round 5, measured null and removed: reading the next region's first three V^T fragments at the end of the region before it -- no LDS
+// round trip in front of a region's first MFMAs -- 377-382 us either way at 8 x 386 rows x 6.2k keys, profiles/r05/attn_pipe_ab.txt.)
+template <int D, int PW, class Issue>
 LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf)[D / 16], int tb, int te, int mlim, int lim, float scale_log2e,
                                 bool active, int lane, int hh, f32x16 (&o)[(D + 31) / 32], float& m_run, float& l_run) {
   constexpr int KP = D / 16, DT = (D + 31) / 32, VP = 2 * DT, NP = KP + VP, NSTAGE = 10;
@@ -71,8 +69,6 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
   p_prev[1] = p_prev[0];
   const u32x4* v_prev = alds;                           // V stage of that tile (while nothing is pending P = 0: any landed stage will do)
   f32x16 sc_a, sc_b;
-  constexpr int NPRE = 3;
-  u32x4 vpre[NPRE];                                     // PIPE 1: V^T fragments 0..2 of the next region's P.V
 
   auto region = [&](auto masked_tag, int t, f32x16& sc_cur, f32x16& sc_nxt) {
     constexpr bool MASKED = decltype(masked_tag)::value;
@@ -82,11 +78,7 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const int i = dt * 2 + ss;
-        const u32x4 vf = (PIPE == 1 && i < NPRE) ? vpre[i < NPRE ? i : 0] : vs[(KP + i) * 64 + lane];
-        o[dt] = mfma32(as_bf16x8(vf), p_prev[ss], o[dt]);
-      }
+      for (int ss = 0; ss < 2; ++ss) o[dt] = mfma32(as_bf16x8(vs[(KP + dt * 2 + ss) * 64 + lane]), p_prev[ss], o[dt]);
     // ... and K.Q^T of tile t+1
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc_nxt[r] = 0.f;
@@ -126,17 +118,12 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
       asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(l_run));
       pn[0] = as_bf16x8(w0); pn[1] = as_bf16x8(w1);
     }
-    if (PIPE == 1) {      // the next region's first V^T fragments: tile t's stage (landed; released only behind the next barrier)
-      const u32x4* vnext = stage_of(t);
-#pragma unroll
-      for (int i = 0; i < NPRE; ++i) vpre[i] = vnext[(KP + i) * 64 + lane];
-    }
-    // issue order: a few fragment reads ahead (PIPE 0), then per MFMA one more read and a handful of vector instructions
-    if (PIPE == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    // issue order: a few fragment reads ahead, then per MFMA one more read and a handful of vector instructions
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (PIPE == 1 || i < NP - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (i < NP - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, (MASKED ? 7 : 5) * 16 / NP, 0);
     }
     // region boundary: the accumulators now hold tiles <= t-1 at the OLD maximum; bring them to the new one before tile t's P.V.
@@ -162,10 +149,6 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
     issue(t + 6); issue(t + 7);
     if (!active) continue;
     if (t == tb) {
-      if (PIPE == 1) {
-#pragma unroll
-        for (int i = 0; i < NPRE; ++i) vpre[i] = alds[(KP + i) * 64 + lane];      // P = 0 for the first region: any landed stage will do
-      }
       const u32x4* k0 = stage_of(tb);
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc_a[r] = 0.f;
@@ -187,7 +170,7 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
 // ------------------------------------------------------------------------------------------------------------------------------
 // LLM prefill (causal, GQA): grid = (query tiles, KV heads, key splits); NWAVE waves: wave w < G computes query head hk * G + w, every
 // wave feeds the DMA ring.  Tile tables as attn_prefill_kernel: stream slot, first row in q, valid rows (<= 32), cache index of row 0.
-template <int NWAVE, int PIPE>
+template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
     const bf16_t* __restrict__ q, bf16_t* __restrict__ out, const int32_t* __restrict__ tile_stream,
     const int32_t* __restrict__ tile_q0, const int32_t* __restrict__ tile_nq, const int32_t* __restrict__ tile_pos0,
@@ -257,7 +240,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
   int min_limit = key_limit;                             // wave-wide minimum of the key limits: tiles entirely below it need no mask
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_limit = min(min_limit, __shfl_xor(min_limit, off, 64));
-  attn32_key_loop<D, PW, PIPE>(alds, issue, qf, tb, te, min(min_limit, te * 32), min(key_limit, te * 32), scale_log2e, active, lane, hh, o, m_run, l_run);
+  attn32_key_loop<D, PW>(alds, issue, qf, tb, te, min(min_limit, te * 32), min(key_limit, te * 32), scale_log2e, active, lane, hh, o, m_run, l_run);
   if (!active) return;
 
   float l = xor32_sum(l_run);
@@ -295,16 +278,19 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
 // and 3 d-tiles for O^T (the third half empty: its V^T rows 80..95 come from a zero page).  qkv = [P, 3E] with q, k rotated in place,
 // vt = V blocked-transposed [head][32-key block][80][32] (vit_rope_vt_kernel); keys past the segment end are masked, and the K rows of
 // the last (partial) tile are clamped into the segment (the next segment's rows are NOT part of this attention).
-template <int NWAVE, int PIPE>
+template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const int32_t* __restrict__ grp_seg,
     const int32_t* __restrict__ grp_q0, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
-    const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e) {
+    const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e, int n_groups) {
   constexpr int D = 80, KP = 5, DT = 3, VP = 6, NP = KP + VP, NSTAGE = 10, PW = (NP + NWAVE - 1) / NWAVE;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, hh = lane >> 5;
-  const int grp = blockIdx.x, h = blockIdx.y, E = heads * D, ld = 3 * E;
+  // one (group, head) per block, or a persistent walk under the grid cap (gemm.hip: g_grid_cap): virtual block vb = head * n_groups + group
+  const int nvb = n_groups * heads;
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  const int h = vb / n_groups, grp = vb - h * n_groups, E = heads * D, ld = 3 * E;
   const int sg = grp_seg[grp], q0 = grp_q0[grp] + wave * 32;
   const int s0 = seg_start[sg], sl = seg_len[sg];
   const bf16_t* kbase = qkv + (size_t)s0 * ld + E + h * D;
@@ -358,32 +344,34 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  attn32_key_loop<D, PW, PIPE>(alds, issue, qf, 0, ntile, sl, sl, scale_log2e, active, lane, hh, o, m_run, l_run);
+  attn32_key_loop<D, PW>(alds, issue, qf, 0, ntile, sl, sl, scale_log2e, active, lane, hh, o, m_run, l_run);
   const float l = xor32_sum(l_run);
-  if (!active || col >= nq) return;
-  const float inv = 1.f / l;
-  bf16_t* op = out + (size_t)(s0 + q0 + col) * E + h * D;
+  if (active && col < nq) {
+    const float inv = 1.f / l;
+    bf16_t* op = out + (size_t)(s0 + q0 + col) * E + h * D;
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int d = dt * 32 + 8 * r4 + 4 * hh;
-      if (d < D)
-        st8(op + d, (u32x2){pack2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv), pack2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv)});
-    }
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = dt * 32 + 8 * r4 + 4 * hh;
+        if (d < D)
+          st8(op + d, (u32x2){pack2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv), pack2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv)});
+      }
+  }
+  if (vb + (int)gridDim.x < nvb) __syncthreads();     // the next (group, head)'s DMA ring reuses the stages
+  }
 }
 
-// LCC_ATTN32_PIPE (A/B, read once): 1 = the cross-region prefetch of the first V^T fragments (attn32_key_loop PIPE 1), 0 = round-4 loop
-static int g_attn32_pipe = [] { const char* v = getenv("LCC_ATTN32_PIPE"); return v ? atoi(v) : 1; }();
-
-template <int NWAVE, int PIPE>
+template <int NWAVE>
 static void vit32_launch_t(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0, const int32_t* seg_start,
                            const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads, int total_blocks, float scale_log2e, hipStream_t st) {
   constexpr size_t lds = (size_t)10 * 11 * 1024;
   static DeviceOnce once;   // per instantiation
-  if (once.first()) (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<NWAVE, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  attn_vit32_kernel<NWAVE, PIPE><<<dim3(n_groups, heads), dim3(NWAVE * 64), lds, st>>>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads,
-                                                                                    total_blocks, scale_log2e);
+  if (once.first()) (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const long nvb = (long)n_groups * heads;
+  const int cap = get_grid_cap();
+  attn_vit32_kernel<NWAVE><<<dim3((unsigned)((cap > 0 && nvb > cap) ? cap : nvb)), dim3(NWAVE * 64), lds, st>>>(
+      qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads, total_blocks, scale_log2e, n_groups);
 }
 int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
                       const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
@@ -391,36 +379,31 @@ int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const in
   if (n_groups <= 0) return 0;
   if (group_rows != 256 && group_rows != 128) return LCC_ERR_ARG;
   // group_rows 256: 8 waves x 32 rows per block; 128: 4 waves (one per SIMD) -- twice the blocks for a grid that does not fill the chip
-#define LCC_VIT32(NW) (g_attn32_pipe ? vit32_launch_t<NW, 1>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st) \
-                                     : vit32_launch_t<NW, 0>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st))
-  if (group_rows == 256) LCC_VIT32(8); else LCC_VIT32(4);
-#undef LCC_VIT32
+  if (group_rows == 256) vit32_launch_t<8>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st);
+  else vit32_launch_t<4>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st);
   g_launch_counts[LC_ATTN_VIT32] += 1;
   return 0;
 }
 
-template <int NWAVE, int PIPE>
-static void gqa32_launch_t(dim3 grid, const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
-                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_q_heads, int nsplit, float* ws_o, float* ws_ml,
-                           float scale_log2e, hipStream_t st) {
-  constexpr size_t lds = (size_t)10 * 16 * 1024;
-  static DeviceOnce once;   // per instantiation
-  if (once.first()) (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<NWAVE, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  attn_gqa32_kernel<NWAVE, PIPE><<<grid, dim3(NWAVE * 64), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
-                                                                      scale_log2e, nsplit, ws_o, ws_ml);
-}
 // launcher: 32-row tiles only; the caller (attention.hip: attn_prefill_bf16) runs the split merge
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,
                           int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st) {
   const int G = n_q_heads / lay.n_kv_heads;
   if (G < 1 || G > 8 || lay.head_dim != 128) return LCC_ERR_SHAPE;
-  const int ns = nsplit > 1 ? nsplit : 1;
-  const dim3 grid(n_tiles, lay.n_kv_heads, ns);
-#define LCC_GQA32(NW) (g_attn32_pipe ? gqa32_launch_t<NW, 1>(grid, q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads, ns, ws_o, ws_ml, scale_log2e, st) \
-                                     : gqa32_launch_t<NW, 0>(grid, q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads, ns, ws_o, ws_ml, scale_log2e, st))
-  if (G <= 4) LCC_GQA32(4); else LCC_GQA32(8);
-#undef LCC_GQA32
+  constexpr size_t lds = (size_t)10 * 16 * 1024;
+  static DeviceOnce once;
+  if (once.first()) {
+    (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  const dim3 grid(n_tiles, lay.n_kv_heads, nsplit > 1 ? nsplit : 1);
+  if (G <= 4)
+    attn_gqa32_kernel<4><<<grid, dim3(256), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
+                                                       scale_log2e, nsplit > 1 ? nsplit : 1, ws_o, ws_ml);
+  else
+    attn_gqa32_kernel<8><<<grid, dim3(512), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
+                                                       scale_log2e, nsplit > 1 ? nsplit : 1, ws_o, ws_ml);
   return 0;
 }
 

@@ -119,6 +119,7 @@ struct lcc_engine {
   // parity instrumentation (lcc_debug_set_llm_taps / lcc_debug_set_vit_taps): residual-stream taps and per-layer input overrides
   bf16_t* llm_taps = nullptr; const bf16_t* llm_over = nullptr; int llm_tap_rows = 0;
   bf16_t* vit_taps = nullptr; const bf16_t* vit_over = nullptr; int vit_tap_rows = 0;
+  int vit_grid_cap = 0;                    // lcc_engine_set_vit_grid_cap: workgroup budget of the tower's tile kernels (0 = whole chip)
   const int32_t* forced = nullptr; int forced_steps = 0, forced_B = 0;   // teacher forcing (lcc_debug_set_forced_tokens)
   // host mirrors
   std::vector<int> h_kv_len, h_pos;

@@ -3,7 +3,6 @@
 // lcc_llm_decode (n steps without a host round trip; decode pipeline v2 for 1-2 streams, the weight-streaming GEMV sequence up to 64).
 #include "engine_internal.h"
 
-static int g_decode_skinny_rows = 64;     // decode batches up to this many streams take the weight-streaming path (run_layers `skinny`)
 // 1: decode pipeline v2 launches down_proj(l) + q/k/v(l+1) as ONE chained launch where both grids fit the chip at once (decode_v2.hip).
 // Measured on MI355X (LiveCC-7B, one stream, no ViT prefetch; profiles/r03/decode_chain_ab.jsonl): bit-identical, but SLOWER --
 // 3105-3229 us per decode step against 2989 us for the two launches (the chained kernel 43.6 us vs 25.5 + 10.7 us).  The consumer's
@@ -259,20 +258,28 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   const int use_thr = sp ? sp->use_thr : 0;
   const float thr = sp ? sp->thr_base + sp->thr_step * (float)step_index : 0.f;
   const int eos2 = sp ? sp->eos_token2 : -1;
+  // teacher forcing: the forced stream decides where a slot ends, so the model's own pick must not set `done` (a model EOS at
+  // a step where the forced stream goes on froze the slot and later forced tokens overwrote its last history column)
+  const bool forcing = e->forced != nullptr && B == e->forced_B && step_index < e->forced_steps;
+  const int sup_eos = forcing ? 1 : (sp ? sp->suppress_eos : 0);
   if (sp && sp->do_sample && sp->top_k != 1) {
     LCC_TRY(sample_topk_topp(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr, sp->eos_token,
-                             eos2, sp->suppress_eos, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col,
+                             eos2, sup_eos, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col,
                              sp->scores_out, sp->temperature, sp->top_k, sp->top_p, sp->seed, e->d_rng_ctr, st));
-    if (e->forced != nullptr && B == e->forced_B && step_index < e->forced_steps)
-      LCC_TRY(force_tokens(d_slots, e->forced + (size_t)step_index * B, B, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col, st));
+    if (forcing)
+      LCC_TRY(force_tokens(d_slots, e->forced + (size_t)step_index * B, B, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col, e->d_done,
+                           sp->suppress_eos ? -1 : sp->eos_token, sp->suppress_eos ? -1 : eos2, st));
     return 0;
   }
   // top_k == 1 (the released generation_config): the top-k warper leaves one finite score -> the draw IS the argmax
   LCC_TRY(sample_greedy(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr,
-                        sp ? sp->eos_token : -1, eos2, sp ? sp->suppress_eos : 0, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
+                        sp ? sp->eos_token : -1, eos2, sup_eos, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history,
                         e->d_hist_col, sp ? sp->scores_out : nullptr, b.ws_ml, st));
-  if (e->forced != nullptr && B == e->forced_B && step_index < e->forced_steps)
-    LCC_TRY(force_tokens(d_slots, e->forced + (size_t)step_index * B, B, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col, st));
+  if (forcing) {
+    const bool keep_going = sp && sp->suppress_eos;      // force_length: a forced EOS does not end the slot either
+    LCC_TRY(force_tokens(d_slots, e->forced + (size_t)step_index * B, B, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col, e->d_done,
+                         keep_going || !sp ? -1 : sp->eos_token, keep_going || !sp ? -1 : eos2, st));
+  }
   return 0;
 }
 }  // namespace
@@ -442,7 +449,11 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
   LayerCtx cx{};
   // weight-streaming ("skinny") layer sequence for up to 64 streams: fp32 split-K slabs consumed by rope / add+norm kernels.  fp8 weights
   // keep the round-3 routing above 16 rows (their GEMV multiplies one activation fragment per weight fragment)
-  cx.S = n_streams; cx.skinny = n_streams <= (e->c.llm_fp8 ? 16 : g_decode_skinny_rows); cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
+  cx.S = n_streams;
+  {
+    const bool f8 = e->c.llm_fp8 != 0;      // every Linear of a layer must take the same route (gemm.hip: gemm_routes_skinny)
+    cx.skinny = gemm_routes_skinny(n_streams, e->c.hidden_size, f8) && gemm_routes_skinny(n_streams, e->qd, f8) && gemm_routes_skinny(n_streams, e->c.intermediate_size, f8);
+  } cx.tok_stream = d_slots; cx.tok_pos = nullptr; cx.slots = d_slots; cx.B = n_streams;
   cx.nsplit_attn = nsplit;
   // fused kernel: 4 waves per block; about one block per CU, never less than one key tile per wave
   static const int fused_blocks = [] { const char* v = getenv("LCC_ATTN_FUSED_BLOCKS"); return v ? std::max(64, atoi(v)) : 256; }();
@@ -498,7 +509,7 @@ extern "C" int lcc_debug_set_forced_tokens(lcc_engine* e, const int32_t* dev_tok
 extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_decode_chain(int on) { g_decode_chain = on ? 1 : 0; return 0; }
 extern "C" int lcc_debug_set_resid_waves(int mode) { return set_resid_waves(mode); }
-extern "C" int lcc_debug_set_skinny_rows(int rows) { g_decode_skinny_rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows); return set_skinny_rows(rows); }
+extern "C" int lcc_debug_set_skinny_rows(int rows) { return set_skinny_rows(rows); }
 extern "C" int lcc_debug_set_decode_path(int path) {
   if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
   g_decode_path = path;

@@ -9,9 +9,22 @@
 static int g_vit_fused_qkv = [] { const char* v = getenv("LCC_VIT_FUSED_QKV"); return v ? atoi(v) : 1; }();
 extern "C" int lcc_debug_set_vit_fused_qkv(int on) { const int old = g_vit_fused_qkv; g_vit_fused_qkv = on ? 1 : 0; return old; }
 
+extern "C" int lcc_engine_set_vit_grid_cap(lcc_engine* e, int cap) {
+  if (!e || cap < 0) return fail(LCC_ERR_ARG, "bad engine / cap");
+  e->vit_grid_cap = cap;
+  return 0;
+}
+namespace {
+struct GridCapScope {      // the cap is host-side launch state: it holds for the launches made inside this call only
+  explicit GridCapScope(int cap) { set_grid_cap(cap); }
+  ~GridCapScope() { set_grid_cap(0); }
+};
+}  // namespace
+
 extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips, const float mean255[3], const float std255[3],
                               const float* rope_cos, const float* rope_sin, void* out_embeds, void* stream) {
   LCC_TRY(ensure_ready(e));
+  GridCapScope cap_scope(e->vit_grid_cap);
   if (n_clips <= 0 || !clips || !rope_cos || !rope_sin || !out_embeds) return fail(LCC_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   const int E = e->E, heads = e->c.vit_heads, MLP = e->c.vit_mlp, H = e->c.hidden_size, PD = e->c.patch_dim;
@@ -96,7 +109,8 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
   if (e->vit_taps) HIP_TRY(hipMemcpyAsync(e->vit_taps, x, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));   // tap 0 = PatchEmbed output
   // q|k|v projection with RoPE + V transpose in its epilogue: head_dim 80, shapes of the 8-wave GEMM (K % 64 == 0, > 64 patches); every
   // segment is a multiple of 4 patches (H, W multiples of 28).  lcc_debug_set_vit_fused_qkv(0) / LCC_VIT_FUSED_QKV=0: separate launches.
-  const bool fused_qkv = g_vit_fused_qkv != 0 && e->vit_hd == 80 && gemm_vit_qkv_eligible(P, E, E);
+  // (16-byte aligned cos / sin tables: the epilogue DMAs them into LDS; an offset view of the tables takes the separate launches -- ADVICE r4)
+  const bool fused_qkv = g_vit_fused_qkv != 0 && e->vit_hd == 80 && gemm_vit_qkv_eligible(P, E, E) && ((((uintptr_t)rope_cos | (uintptr_t)rope_sin) & 15) == 0);
   for (int l = 0; l < e->c.vit_depth; ++l) {
     const VitLayerW& L = e->vit[l];
     if (e->vit_over) HIP_TRY(hipMemcpyAsync(x, e->vit_over + (size_t)l * tap_stride, (size_t)P * E * 2, hipMemcpyDeviceToDevice, st));

@@ -27,6 +27,18 @@ namespace lcc {
 
 __device__ unsigned int lcc_zero_page[256];  // 1 KB of zeros: operand source of absent K chunks (address select, no branch)
 
+// Grid cap (round 5): while it is set (engine_vit.hip sets it around a vision-tower call that runs on the side stream UNDER another turn's
+// decode steps), the MFMA-bound tile kernels launch at most `cap` workgroups and walk their tiles persistently (tile = block, block +
+// grid, ...), so that they occupy `cap` of the 256 CUs instead of all of them.  Why: a resident 8-wave GEMM block (2 x 208-216 VGPRs per
+// SIMD, 128-140 KB of LDS) leaves room for ONE weight-streaming decode wave per SIMD where five fit on a free CU -- with the tower spread
+// over every CU the HBM-bound decode kernels lose their memory-level parallelism and the "overlapped" tower simply adds its own duration
+// to the decode steps (8 streams: 4.88 vs 3.68 ms per step while a 20-ms tower runs; 1 stream: 3.23 vs 2.95 ms).  Half the CUs stream the
+// weights at the full HBM rate.  A multiple of 8 (virtual block id and physical block id then agree on the XCD).
+static int g_grid_cap = 0;
+void set_grid_cap(int cap) { g_grid_cap = cap <= 0 ? 0 : std::max(8, cap & ~7); }
+int get_grid_cap() { return g_grid_cap; }
+static inline unsigned capped_grid(long nblk) { return (unsigned)((g_grid_cap > 0 && nblk > g_grid_cap) ? g_grid_cap : nblk); }
+
 // epilogue shared by the tiled kernels.  acc[i][j][r] = C[mbase + i*16 + li][nbase + j*16 + g*4 + r] (swapped operands).
 template <int EPI, int MT, int NT, int AM = MT, int AN = NT>   // the first MT x NT tiles of an AM x AN accumulator array
 LCC_DEVICE void tile_epilogue(const f32x4 (&acc)[AM][AN], int mbase, int nbase, int ocbase, int li, int g,
@@ -337,14 +349,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
   extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
 
   const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
+  for (int vb = blockIdx.x; vb < nblk; vb += gridDim.x) {     // one tile per block, or a persistent walk under the grid cap
+  int bid = vb;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, g = lane >> 4;
   const int K32 = (K + 31) >> 5;
@@ -422,6 +435,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(
     }
   }
   tile_epilogue<EPI, MT, NT>(acc, m0 + wm * WM, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, wscale);
+  if (vb + (int)gridDim.x < nblk) __syncthreads();     // the next tile's DMA reuses the stages
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,7 +643,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
     float* __restrict__ partial, int kt_per_split, const float* __restrict__ wscale, VitQkvEpi vq, int raster) {
   const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
+  for (int vb = blockIdx.x; vb < nblk; vb += gridDim.x) {     // one tile per block, or a persistent walk under the grid cap
+  int bid = vb;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -658,6 +674,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
       gemm_big_body<BM, EPI_VIT_QK, SCHED, W8>(A, lda, W, bias, nullptr, 0, C, ldc, M, 2 * vq.E, K, tm, tn, nullptr, 0, nullptr, vq);
   } else {
     gemm_big_body<BM, EPI, SCHED, W8>(A, lda, W, bias, residual, ldr, C, ldc, M, N, K, tm, tn, partial, kt_per_split, wscale, vq);
+  }
+  if (vb + (int)gridDim.x < nblk) __syncthreads();     // the next tile's DMA reuses the stages (and the rotation epilogue's tables)
   }
 }
 
@@ -694,7 +712,8 @@ __global__ __launch_bounds__(512) void gemm_vh_kernel(
   extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
 
   const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
+  for (int vb = blockIdx.x; vb < nblk; vb += gridDim.x) {     // one tile per block, or a persistent walk under the grid cap
+  int bid = vb;
   {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -813,6 +832,8 @@ __global__ __launch_bounds__(512) void gemm_vh_kernel(
   if (!wave_has_rows) run(I0{});
   else if (my_mt == MTX) run(I9{});
   else run(I8{});
+  if (vb + (int)gridDim.x < nblk) __syncthreads();     // the next tile's DMA reuses the stages
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -983,7 +1004,7 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
     if (attr_set.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_glds_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    gemm_glds_kernel<BM, EPI><<<dim3(tiles_m * tiles_n, S), dim3(256), lds, st>>>(
+    gemm_glds_kernel<BM, EPI><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(256), lds, st>>>(
         a.A, a.lda, a.W, a.ldw, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.w_packed, a.partial,
         (nkt + S - 1) / S, a.wscale);
     return;
@@ -1006,7 +1027,7 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, EPI, SCHED, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+  gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq,
       g_gemm_raster);
 }
@@ -1023,7 +1044,7 @@ static void launch_vh(const GemmArgs& a, hipStream_t st) {
   static DeviceOnce attr_set;   // per instantiation
   if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_vh_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   g_launch_counts[LC_GEMM_VH]++;
-  gemm_vh_kernel<EPI><<<dim3(tiles_m * tiles_n, S), dim3(512), lds, st>>>(
+  gemm_vh_kernel<EPI><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, g_gemm_raster);
 }
 template <int BM, int EPI>
@@ -1242,12 +1263,18 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
         xf[1][0] = xv[u][1][0];
       } else {
         // raw lines -> wave-private LDS image [row][8 x 16 B], chunk c of row r at r*8 + (c ^ (r & 7)) -> fragments (row mg*16 + li,
-        // k-block h, lane group g).  One wave, in-order LDS: no barrier.
+        // k-block h, lane group g).  One wave and in-order LDS: no s_barrier is needed, but the cross-LANE dependence (lane a's store, lane
+        // b's load of the same address) is invisible in per-thread alias analysis -- a wavefront-scope fence + wave barrier (no
+        // instructions on gfx950) keeps the compiler from reordering the two groups, here and in front of the next stage's stores.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 2 * MG; ++i) {
           const int row = i * 8 + (lane >> 3);
           xs[row * 8 + ((lane & 7) ^ (row & 7))] = xv[u][i / MG][i % MG];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1394,6 +1421,13 @@ __global__ __launch_bounds__(256) void gemv_skinny_kernel(
 }
 
 static int g_skinny_rows = 64;
+// THE predicate of the weight-streaming route (the engine used to decide it from its own copy of the row limit, so a forced tile
+// variant or a K that is not a multiple of 64 could leave it handing GEMV-derived split counts to the tiled kernels): M rows against a
+// [N, K] weight go through gemv_skinny_kernel / gemv_w8_kernel iff this holds (and the epilogue is one the GEMV kernels have).
+bool gemm_routes_skinny(int M, int K, bool w_fp8) {
+  if (w_fp8) return M <= 16;
+  return M <= (g_gemm_variant == 2 ? g_skinny_rows : 16) && (K % 32 == 0) && (M <= 16 || K % 64 == 0);
+}
 int set_skinny_rows(int rows) { const int old = g_skinny_rows; g_skinny_rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows); return old; }
 static int g_gemv_variant = 1;  // 0: UNR2 single stage; 1: UNR1 two-stage pipeline (default: best measured); 2: UNR2 two-stage
 void set_gemv_variant(int v) { g_gemv_variant = v; }
@@ -1690,8 +1724,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
   // weight-streaming path: up to g_skinny_rows rows (64: decode batches of 17-64 streams multiply every weight fragment with 2-4 activation
   // fragments; lcc_debug_set_skinny_rows(16) restores the round-3 routing of 17-64 rows through the 64-row GEMM tiles)
   // (a forced GEMM tile variant -- tests, A/B runs -- keeps 17-64 rows on the tiles it asks for)
-  const bool skinny = a.M <= (g_gemm_variant == 2 ? g_skinny_rows : 16) && (a.K % 32 == 0) && (a.M <= 16 || a.K % 64 == 0) && a.epilogue != EPI_QUICK_GELU &&
-                      a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
+  const bool skinny = gemm_routes_skinny(a.M, a.K, false) && a.epilogue != EPI_QUICK_GELU && a.epilogue != EPI_GELU_ERF && a.epilogue != EPI_RESIDUAL;
   if (skinny) {
     const int nchunk = (a.K + 63) / 64;
     if (a.epilogue == EPI_SWIGLU) {

@@ -84,8 +84,11 @@ bool gemm_vit_qkv_eligible(int M, int E, int K);   // shapes the EPI_VIT_QK / EP
 int gemv_num_splits(int N, int K);
 int gemm_tiled_num_splits(int M, int N, int K);
 void set_gemv_variant(int v);
+bool gemm_routes_skinny(int M, int K, bool w_fp8);   // M rows x [N, K] weights take the weight-streaming GEMV kernels (the one predicate: gemm.hip and the engine)
 int set_skinny_rows(int rows);     // 16..64: largest M served by the weight-streaming GEMV kernels (returns the previous value)
 void set_gemm_variant(int v);
+void set_grid_cap(int cap);        // > 0: the MFMA-bound tile kernels (8-wave / 4-wave LDS-DMA GEMMs, vision attention) launch at most `cap` workgroups
+int get_grid_cap();                //      and walk their tiles persistently (gemm.hip: g_grid_cap); 0 = one workgroup per tile
 int mfma_probe(const bf16_t* A, const bf16_t* B, float* D, hipStream_t st);
 
 // ---- elementwise / normalisation / layout (elementwise.hip) ----
@@ -170,9 +173,10 @@ struct DeviceOnce {
   }
 };
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st);
-// teacher forcing (tests): the token just sampled for stream b becomes forced[b] (current token + last history column)
+// teacher forcing (tests): the token just sampled for stream b becomes forced[b] (current token + last history column); the forced stream
+// also decides where a slot ends (`done`: flags from before this step, updated by a forced EOS)
 int force_tokens(const int32_t* slots, const int32_t* forced, int B, int32_t* cur_tok, int32_t* history, int hist_ld, const int32_t* hist_col,
-                 hipStream_t st);
+                 int32_t* done, int eos, int eos2, hipStream_t st);
 
 // ---- decode layer pipeline v2 (decode_v2.hip): elementwise stages fused into the weight-streaming GEMVs ----
 struct DgArgs {

@@ -536,18 +536,24 @@ __global__ void advance_kernel(const int32_t* slots, int32_t* kv_len, int32_t* p
   const int s = slots[i];
   if (done == nullptr || !done[s]) { kv_len[s] += 1; pos[s] += 1; }
 }
+// Teacher forcing (test instrument): the forced stream decides everything, including where it ends.  The sampler ran with EOS suppressed
+// (engine_llm.hip: head_and_sample), so `done` still holds the flags from BEFORE this step: a slot whose forced stream has ended stays
+// frozen (its last history column is not overwritten by later forced tokens), the others take the forced token and end if it is an EOS.
 __global__ void force_tokens_kernel(const int32_t* __restrict__ slots, const int32_t* __restrict__ forced, int B, int32_t* __restrict__ cur_tok,
-                                    int32_t* __restrict__ history, int hist_ld, const int32_t* __restrict__ hist_col) {
+                                    int32_t* __restrict__ history, int hist_ld, const int32_t* __restrict__ hist_col, int32_t* __restrict__ done,
+                                    int eos, int eos2) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int slot = slots[b], tok = forced[b];
+  if (done != nullptr && done[slot]) return;
   cur_tok[slot] = tok;
   const int col = hist_col[slot] - 1;          // the sampler has just written column hist_col - 1
   if (col >= 0 && col < hist_ld) history[(size_t)slot * hist_ld + col] = tok;
+  if (done != nullptr && (tok == eos || (eos2 >= 0 && tok == eos2))) done[slot] = 1;
 }
 int force_tokens(const int32_t* slots, const int32_t* forced, int B, int32_t* cur_tok, int32_t* history, int hist_ld, const int32_t* hist_col,
-                 hipStream_t st) {
-  force_tokens_kernel<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(slots, forced, B, cur_tok, history, hist_ld, hist_col);
+                 int32_t* done, int eos, int eos2, hipStream_t st) {
+  force_tokens_kernel<<<dim3((B + 63) / 64), dim3(64), 0, st>>>(slots, forced, B, cur_tok, history, hist_ld, hist_col, done, eos, eos2);
   return 0;
 }
 int advance_lengths(const int32_t* slots, int32_t* kv_len, int32_t* pos, int B, const int32_t* done, hipStream_t st) {

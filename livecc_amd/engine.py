@@ -164,6 +164,10 @@ class Engine:
             self._rope_cache[key] = (c.to(self.device), s.to(self.device))
         return self._rope_cache[key]
 
+    def set_vit_grid_cap(self, cap: int) -> None:
+        """Workgroup budget of the next vit_encode calls (lcc_engine_set_vit_grid_cap): > 0 = the tower occupies `cap` of the 256 CUs, 0 = all."""
+        _lib.check(self.lib.lcc_engine_set_vit_grid_cap(self.h, int(cap)), "lcc_engine_set_vit_grid_cap")
+
     def vit_encode(self, clips: Sequence[dict], stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
         """clips: dicts with either {'frames': uint8 device tensor, 'layout': 'THWC'|'TCHW'} or
         {'pixel_values': fp32 device [P,1176], 'grid': (t,h,w)}.  Returns bf16 [sum P/4, hidden].  `stream`: launch on that stream

@@ -20,6 +20,8 @@ No CPU path: everything below needs the HIP library and a GPU, and raises otherw
 """
 from __future__ import annotations
 
+import os
+
 import dataclasses
 from typing import List, Optional, Sequence
 
@@ -132,6 +134,8 @@ class LiveCCForConditionalGeneration:
         self._vit_cache: dict = {}
         self._vit_last_event: Optional[torch.cuda.Event] = None
         self._sample_calls = 0                      # generate calls that drew their Philox seed from torch's default generator
+        # CUs a prefetched vision tower may occupy while it runs under another turn's decode steps (0 = all; LCC_VIT_PREFETCH_CAP overrides)
+        self.prefetch_grid_cap = int(os.environ.get("LCC_VIT_PREFETCH_CAP", "0"))
 
     # ---- constructors ----
     @classmethod
@@ -403,7 +407,16 @@ class LiveCCForConditionalGeneration:
         side.wait_stream(main)      # the ViT workspace is free and this turn's prefill is enqueued: start under the decode steps
         cfg = self.cfg
         with torch.cuda.stream(side):
-            emb = self._vit_encode([c for _, c in todo], stream=side)     # ONE batched launch sequence (large-M GEMMs), sliced per clip
+            # under the decode steps the tower keeps to `prefetch_grid_cap` CUs (engine.set_vit_grid_cap): spread over all of them it takes
+            # the decode kernels' occupancy away and adds its whole duration to the steps it was meant to hide under
+            eng_cap = self.prefetch_grid_cap
+            if eng_cap:
+                self.engine.set_vit_grid_cap(eng_cap)
+            try:
+                emb = self._vit_encode([c for _, c in todo], stream=side)     # ONE batched launch sequence (large-M GEMMs), sliced per clip
+            finally:
+                if eng_cap:
+                    self.engine.set_vit_grid_cap(0)
             ev = self._vit_last_event                                     # recorded by _vit_encode after the last ViT kernel
             off = 0
             for k, clip in todo:

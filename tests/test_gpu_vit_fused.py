@@ -81,3 +81,34 @@ def test_fused_qkv_epilogue_is_bit_identical_at_7b_shapes(dev, streams):
         ms.setdefault("fused" if on else "separate", []).append(t0.elapsed_time(t1) / 5)
         ops.set_vit_fused_qkv(bool(old))
     record(f"vit_tower_fused_qkv[{streams} streams]", dict(tower_ms_separate=ms["separate"], tower_ms_fused=ms["fused"]))
+
+
+@pytest.mark.parametrize("streams,cap", [(1, 32), (1, 96), (8, 64), (8, 128)])
+def test_tower_under_a_grid_cap_is_bit_identical(dev, streams, cap):
+    """lcc_engine_set_vit_grid_cap (round 5): the tower's tile kernels launch at most `cap` workgroups and walk their tiles persistently (what a
+    prefetched tower does under another turn's decode steps) -- the tile -> output mapping does not change, so the embeddings are the bits of
+    the whole-chip launch.  LiveCC-7B tower on 1 and 8 chunks: the 4-wave LDS-DMA GEMM + 128-row 8-wave tiles + the LDS-shared vision
+    attention (one chunk), the 256-row 8-wave tiles + the 32x32x16 vision attention (eight)."""
+    from livecc_amd.config import get_config
+    cfg = get_config("livecc-7b")
+    native = _model(cfg, dev, max_patches=16384)
+    clips = _clips([(2, 392, 728)] * streams, dev, seed=33)
+    ref = native.engine.vit_encode(clips).clone()
+    native.engine.set_vit_grid_cap(cap)
+    try:
+        got = native.engine.vit_encode(clips).clone()
+        ms = []
+        for _ in range(3):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            native.engine.vit_encode(clips)
+            t1.record()
+            torch.cuda.synchronize()
+            ms.append(t0.elapsed_time(t1))
+    finally:
+        native.engine.set_vit_grid_cap(0)
+    again = native.engine.vit_encode(clips)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, got), f"{int((ref != got).sum())} of {ref.numel()} embedding values differ under a cap of {cap} workgroups"
+    assert torch.equal(ref, again)
+    record(f"vit_tower_grid_cap[{streams} streams, {cap} CUs]", dict(tower_ms=min(ms)))

@@ -207,6 +207,17 @@ r5c)         # round 5, call 3: variable-height GEMM tiles + raster default + at
     ( timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_$L.log 2>&1; echo "== 1 stream $L: $(val $O/bench_1s_$L.log value) tok/s"
   done
   unset LCC_LIB_PATH ;;
+r5d)         # round 5, call 4: the prefetched vision tower under a CU budget (persistent walks): bit-identity, then the bench at 1 / 8 streams per cap
+  timeout 600 python -m pytest tests/test_gpu_vit_fused.py -m gpu -q -x --timeout 500 > $O/cap_tests.log 2>&1; tail -n 4 $O/cap_tests.log
+  grep -A3 "vit_tower_grid_cap" gpurun_out/parity_report.json | grep -E "grid_cap|tower_ms" | paste - - | cut -c1-160
+  for CAP in 0 64 96 128 160 0; do
+    ( LCC_VIT_PREFETCH_CAP=$CAP timeout 500 $B --steps 2 --warmup 1 --streams-per-gpu 8 --share8 off ) > $O/bench_8s_cap$CAP.log 2>&1
+    echo "== 8 streams, prefetch cap $CAP: $(val $O/bench_8s_cap$CAP.log value) tok/s  step $(grep -o '"avg_step_us": [0-9.]*' $O/bench_8s_cap$CAP.log | head -1)"
+  done
+  for CAP in 0 32 48 64 96 0; do
+    ( LCC_VIT_PREFETCH_CAP=$CAP timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_cap$CAP.log 2>&1
+    echo "== 1 stream, prefetch cap $CAP: $(val $O/bench_1s_cap$CAP.log value) tok/s  step $(grep -o '"avg_step_us": [0-9.]*' $O/bench_1s_cap$CAP.log | head -1)"
+  done ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
