@@ -516,8 +516,7 @@ def more_configs(args):
                                     standalone_replay_without_prefetch=ds.get("standalone_replay_without_prefetch")))
         out["configs4_72b_fp8"] = blk
         try:
-            blk["parity"] = _fixture_test("test_gpu_layer_parity.py", "72b", ["qwen2vl72b_fp8_layer_stages_vs_hf", "qwen2vl72b_fp8_one_layer_stream_vs_hf",
-                                                                              "qwen2vl72b_fp8_full_depth_first_token"], 900)
+            blk["parity"] = _fixture_test("test_gpu_layer_parity.py", "72b", ["stream_72b_1layer_fp8", "qwen2vl72b_fp8_full_depth_vs_committed_golden"], 900)
         except Exception as e:
             blk["parity"] = dict(error=repr(e))
     except Exception as e:

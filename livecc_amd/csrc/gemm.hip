@@ -1014,9 +1014,12 @@ static void launch_tiled(const GemmArgs& a, hipStream_t st) {
       (nkt + S - 1) / S, a.wscale);
 }
 
-// LCC_GEMM_RASTER (A/B, read once): band width of the tile order of the 8-wave kernels; default 4 (bands of 4 column tiles walked row-major:
-// the ~32 tiles an XCD runs at a time form an 8 x 4 super-tile), 0 = column-major (rounds 2-4)
-static int g_gemm_raster = [] { const char* v = getenv("LCC_GEMM_RASTER"); return v ? atoi(v) : 4; }();
+// LCC_GEMM_RASTER (A/B, read once): band width of the tile order of the 8-wave kernels (bands of G column tiles walked row-major: the ~32
+// tiles an XCD runs at a time form a (32 / G) x G super-tile), 0 = column-major (rounds 2-4)
+static int g_gemm_raster = [] { const char* v = getenv("LCC_GEMM_RASTER"); return v ? atoi(v) : -1; }();
+// -1 (default): bands of 4 column tiles once there are more than 6 row tiles; with few row tiles column-major already puts every row
+// tile of a W panel side by side (M = 1131: 335 us column-major vs 342-355 us in bands, profiles/r05/gemm_vh_raster_ab.jsonl)
+static inline int raster_for(int tiles_m) { return g_gemm_raster >= 0 ? g_gemm_raster : (tiles_m > 6 ? 4 : 0); }
 template <int BM, int EPI, int SCHED, bool W8>
 static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + 255) / 256;
@@ -1029,7 +1032,7 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
   }
   gemm_big_kernel<BM, EPI, SCHED, W8><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq,
-      g_gemm_raster);
+      raster_for(tiles_m));
 }
 // variable-height row tiles (gemm_vh_kernel): tiles_m = floor(F / 16) row tiles for F = ceil(M / 16) row fragments
 static bool vh_legal(const GemmArgs& a) {
@@ -1045,7 +1048,7 @@ static void launch_vh(const GemmArgs& a, hipStream_t st) {
   if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_vh_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   g_launch_counts[LC_GEMM_VH]++;
   gemm_vh_kernel<EPI><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(512), lds, st>>>(
-      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, g_gemm_raster);
+      a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, raster_for(tiles_m));
 }
 template <int BM, int EPI>
 static void launch_big(const GemmArgs& a, hipStream_t st) {

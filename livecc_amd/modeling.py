@@ -134,8 +134,10 @@ class LiveCCForConditionalGeneration:
         self._vit_cache: dict = {}
         self._vit_last_event: Optional[torch.cuda.Event] = None
         self._sample_calls = 0                      # generate calls that drew their Philox seed from torch's default generator
-        # CUs a prefetched vision tower may occupy while it runs under another turn's decode steps (0 = all; LCC_VIT_PREFETCH_CAP overrides)
-        self.prefetch_grid_cap = int(os.environ.get("LCC_VIT_PREFETCH_CAP", "0"))
+        # CUs a prefetched vision tower may occupy while it runs under another turn's decode steps: -1 (default) = 128 for >= 4 clips (measured
+        # +1.5 % tokens/s at 8 streams, profiles/r05/prefetch_grid_cap_ab.txt; one stream's tower is too small to share: 276 -> 256-269 tokens/s
+        # under any cap), 0 = whole chip, n = n workgroups.  LCC_VIT_PREFETCH_CAP overrides.
+        self.prefetch_grid_cap = int(os.environ.get("LCC_VIT_PREFETCH_CAP", "-1"))
 
     # ---- constructors ----
     @classmethod
@@ -409,7 +411,7 @@ class LiveCCForConditionalGeneration:
         with torch.cuda.stream(side):
             # under the decode steps the tower keeps to `prefetch_grid_cap` CUs (engine.set_vit_grid_cap): spread over all of them it takes
             # the decode kernels' occupancy away and adds its whole duration to the steps it was meant to hide under
-            eng_cap = self.prefetch_grid_cap
+            eng_cap = self.prefetch_grid_cap if self.prefetch_grid_cap >= 0 else (128 if len(todo) >= 4 else 0)
             if eng_cap:
                 self.engine.set_vit_grid_cap(eng_cap)
             try:

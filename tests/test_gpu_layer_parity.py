@@ -203,3 +203,57 @@ def test_qwen2vl_72b_shaped_layer_with_fp8_weights_matches_hf_on_the_dequantised
     state.release()
     record("stream_72b_1layer_fp8", worst)
     print("72B-shaped fp8 stream:", worst)
+
+
+def test_qwen2vl_72b_fp8_full_depth_against_the_committed_hf_logits(dev):
+    """BASELINE.json configs[4] through ALL 80 decoder layers (VERDICT r4 missing #4): Qwen2-VL-72B shapes, LLM Linear weights as OCP e4m3 +
+    fp32 row scales (the 73-GB single-GPU arena), the 6-frame first turn of the benchmark protocol (4,368 patches, a 1,131-row prefill) + 3
+    decode steps, teacher-forced along the fixture's tokens -- against tests/golden/qwen2vl72b_fp8_full_depth.npz: HF's own modules executed
+    layer-streamed in the build container on the same seeded synthetic weights after the same per-row e4m3 quantisation (oracle/
+    make_golden_72b.py: fp32 = exact q x scale = the truth, bf16 = what the reference's dtype makes of the dequantised checkpoint).
+    After 80 layers the reference's OWN bf16 run is 4.4 % of the logit scale (rms 0.37-0.39, scale 7.8-9.4) away from the fp32 truth, so
+    the gross-error guard is stated in units of that committed error.  Per step: |native - HF_bf16| at HF's top-64 ids <= max(6e-2 x scale,
+    6 x rms(HF_bf16 - fp32)); rms over the 4,096 sample ids of (native - fp32) <= 1.25 x rms(HF_bf16 - fp32) -- the sensitive bound; the
+    native argmax equals HF fp32's wherever the fp32 top-1 / top-2 margin exceeds 8 x that rms."""
+    from livecc_amd import protocol
+    from livecc_amd.config import get_config
+    from livecc_amd.modeling import LiveCCForConditionalGeneration
+    from livecc_amd.weights import WeightArena
+    from oracle import make_golden_72b as G
+    g = dict(np.load(G.PATH))
+    seed_in, T, H, W, n_forced, seed_w, L = (int(x) for x in g["meta"])
+    cfg = get_config("qwen2vl-72b")
+    assert L == cfg.num_hidden_layers == 80 and (seed_in, T, H, W, n_forced) == (G.SEED_IN, G.T, G.H, G.W, G.N_FORCED)
+    grid = protocol.grid_of(T, H, W, cfg)
+    ids = np.asarray(protocol.TurnBuilder(cfg, seed=seed_in).turn_ids(0, protocol.num_video_tokens(grid, cfg)), dtype=np.int64)
+    forced = G.teacher_tokens(cfg)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(forced, g["tokens"]) and np.array_equal(g["sample_ids"], G.sample_ids(cfg.vocab_size))
+    arena = WeightArena(cfg, dev, llm_fp8=True).fill_tiled(seed=seed_w)
+    native = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=1, max_kv_len=2048, max_new_rows=1280, max_patches=4608, max_history=8)
+    frames = torch.from_numpy(protocol.synth_frames(T, H, W, seed=seed_in, layout="TCHW")).to(dev)
+    r = native.generate(input_ids=torch.from_numpy(ids).view(1, -1), frames=frames, frames_layout="TCHW", repetition_penalty=1.0,
+                        max_new_tokens=n_forced, min_new_tokens=n_forced, output_logits=True, do_sample=False, teacher_tokens=[int(t) for t in forced])
+    assert r.sequences[0, len(ids):].tolist() == [int(t) for t in forced]
+    lg = r.logits.float().cpu().numpy()
+    r.past_key_values.release()
+    sid = g["sample_ids"]
+    rec = dict(layers=L, prompt_rows=len(ids), steps=n_forced, rel_dlogit_top=[], rms_ratio=[], decided=0, decided_equal=0, argmax_equal_fp32=0,
+               ref_bf16_rms_err_over_scale=[float(a / b) for a, b in zip(g["t0_rms_err_bf16_full_vocab"], g["t0_scale"])])
+    for k in range(n_forced):
+        scale = float(g["t0_scale"][k])
+        d = float(np.abs(lg[k][g["t0_top_ids"][k]] - g["t0_top_vals_bf16"][k].astype(np.float64)).max()) / max(scale, 100.0 * float(g["t0_rms_err_bf16_full_vocab"][k]))
+        n, b16, t32 = lg[k][sid].astype(np.float64), g["t0_sample_vals_bf16"][k].astype(np.float64), g["t0_sample_vals_fp32"][k].astype(np.float64)
+        ratio = float(np.sqrt(((n - t32) ** 2).mean()) / np.sqrt(((b16 - t32) ** 2).mean()))
+        rec["rel_dlogit_top"].append(d)
+        rec["rms_ratio"].append(ratio)
+        top2 = g["t0_fp32_top2_vals"][k]
+        own, want = int(lg[k].argmax()), int(g["t0_fp32_top2_ids"][k][0])
+        rec["argmax_equal_fp32"] += int(own == want)
+        if float(top2[0] - top2[1]) > 8.0 * float(g["t0_rms_err_bf16_full_vocab"][k]):
+            rec["decided"] += 1
+            rec["decided_equal"] += int(own == want)
+    record("qwen2vl72b_fp8_full_depth_vs_committed_golden", rec)
+    print("72B fp8, 80 layers, vs the committed HF logits:", rec)
+    assert max(rec["rel_dlogit_top"]) <= 6e-2, rec
+    assert max(rec["rms_ratio"]) <= 1.25, rec
+    assert rec["decided_equal"] == rec["decided"], rec

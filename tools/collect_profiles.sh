@@ -2,7 +2,7 @@
 # Copies the small summaries of a GPU call (gpurun_out/ is scratch) into the tracked profiles/<TAG>/ directory.
 #   tools/collect_profiles.sh r02 [bench-log-dir]      (bench-log-dir default gpurun_out/<TAG>)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 SRC=gpurun_out/profiles_$TAG
 LOGS=${2:-gpurun_out/$TAG}
 DST=profiles/$TAG

@@ -3,12 +3,12 @@
 # dominant kernel.  Only the small summary CSVs are kept under gpurun_out/ (the kernel traces are tens of MB).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 cd /tmp
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 1 --warmup 1 --cpu-baseline off > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 1 --warmup 1 --cpu-baseline off --parity off --live2fps off --more-configs off > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 find $OUT/stats -name '*kernel_trace.csv' -delete
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o gemv -- python $R/tools/pmc_target.py > $OUT/pmc_$C.log 2>&1

@@ -34,9 +34,11 @@ gemm = {}
 for f in glob.glob(os.path.join(out, "pmc_gemm_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r.get("Kernel_Name", "")
-        if "gemm_big_kernel" not in kn and "gemm_tall_kernel" not in kn:
+        if "gemm_big_kernel" not in kn and "gemm_tall_kernel" not in kn and "gemm_vh_kernel" not in kn:
             continue
-        key = "M386_gemm_tall_kernel" if "gemm_tall_kernel" in kn else ("M3088_gemm_big_kernel_256" if "<256" in kn else "M386_gemm_big_kernel_128")
+        # round 5: the gate/up GEMM at M = 3088 runs on the variable-height tiles (gemm_vh_kernel: 12 x 148 tiles of 256 / 272 rows)
+        key = ("M386_gemm_tall_kernel" if "gemm_tall_kernel" in kn else "M3088_gemm_vh_kernel" if "gemm_vh_kernel" in kn else
+               "M3088_gemm_big_kernel_256" if "<256" in kn else "M386_gemm_big_kernel_128")
         if "<128, 5" in kn:      # split-K slabs at M = 386: grid (tiles, splits) x 512 threads tells q/k/v (72 x 3) from o / down (56 x 4);
             grid = int(r.get("Grid_Size", 0)) // 512      # o and down share a grid: told apart by the duration of the dispatch
             dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
