@@ -385,9 +385,10 @@ int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slots, const in
                     const int32_t* vit_index, const void* vit_embeds, const int32_t* pos3, const lcc_sampling* sp,
                     void* stream);
 /* n_steps further decode steps for the same streams without any host round trip.  n_streams <= LCC_MAX_DECODE_BATCH (and
- * <= max_new_rows): up to 16 streams are one MFMA column tile of the weight-streaming GEMVs; 17..64 go through the 64-row GEMM
- * tiles (the weights are still streamed once per step for the whole batch).  Larger batches: call once per group.
- * Round 4: 17..64 streams take the weight-streaming GEMVs too (lcc_debug_set_skinny_rows). */
+ * <= max_new_rows): up to 16 streams are one activation fragment per weight fragment of the weight-streaming GEMVs; 17..64 streams run the
+ * same kernels with 2-4 activation fragments per weight fragment (bf16 weights; lcc_debug_set_skinny_rows lowers the limit) or, with fp8
+ * weights, the 64-row GEMM tiles -- either way the weights are streamed once per step for the whole batch.  Larger batches: call once
+ * per group. */
 #define LCC_MAX_DECODE_BATCH 64
 int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots, int n_steps, int first_step_index,
                    const lcc_sampling* sp, void* stream);

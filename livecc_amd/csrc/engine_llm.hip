@@ -420,8 +420,9 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
                               const lcc_sampling* sp, void* stream) {
   LCC_TRY(ensure_ready(e));
   if (n_streams <= 0 || !slots || n_steps < 0) return fail(LCC_ERR_ARG, "bad argument");
-  // <= 16 streams: one MFMA column tile of the weight-streaming GEMVs.  17..64: the rows go through the 64-row GEMM tiles of the
-  // prefill path (every weight byte is still read once per step) with the decode attention; beyond that the caller splits.
+  // <= 16 streams: one activation fragment per weight fragment of the weight-streaming GEMVs.  17..64 (bf16 weights): the same kernels with
+  // 2-4 activation fragments per weight fragment (gemv_skinny_kernel<..., MG>, round 4); fp8 weights above 16 rows: the 64-row GEMM tiles
+  // of the prefill path.  One predicate decides (gemm.hip: gemm_routes_skinny).  Beyond 64 the caller splits.
   if (n_streams > LCC_MAX_DECODE_BATCH)
     return fail(LCC_ERR_SHAPE, "decode batches of more than %d streams are not supported", LCC_MAX_DECODE_BATCH);
   if (n_streams > e->lim.max_new_rows) return fail(LCC_ERR_STATE, "%d streams > max_new_rows %d", n_streams, e->lim.max_new_rows);

@@ -4,10 +4,12 @@
 // bf16 (16 bytes) per lane.  fp32 accumulation, one rounding to bf16 at the points where HF rounds.
 //
 //  * gemm_big_kernel     : M >= 17, packed W, K % 64 == 0 (LLM prefill, ViT).  MFMA-bound.  8 waves, BM x 256 x 64 tile
-//                          (BM 256 / 128), LDS-DMA for both operands, optional fp8-e4m3 W converted after the LDS read.
+//                          (BM 256 / 192 / 128), LDS-DMA for both operands, optional fp8-e4m3 W converted after the LDS read.
+//  * gemm_vh_kernel      : the same pipeline over row tiles of 256 / 272 / 288 rows (no ragged last row tile; round 5).
+//  * gemm_tall_kernel    : one block row covers all of M (256 < M <= 448: one streaming chunk's gate/up).
 //  * gemm_glds_kernel /   : shapes with few 256-column tiles, row-major W, K % 64 != 0.  64x128x64 (128x128x64) tile, 4 waves,
 //    gemm_tiled_kernel     LDS-DMA 3-stage ring / register-staged double buffer with an XOR swizzle, XCD-aware block remap.
-//  * gemv_skinny_kernel  : M <= 16 (decode, lm_head).  HBM-bound weight streaming.  4 waves per block share 16 (or 32) W rows,
+//  * gemv_skinny_kernel  : M <= 64 (decode, lm_head; MG = ceil(M / 16) activation fragments per weight fragment).  HBM-bound weight streaming.  4 waves per block share 16 (or 32) W rows,
 //                          each wave a slice of K; W fragments go straight from HBM into the MFMA operand registers (no LDS
 //                          round trip - the operand is used once), split-K partial sums as fp32 slabs that the consumer reduces.
 //  * gemv_w8_kernel      : the same for fp8-e4m3 weights + fp32 row scales (PACKED8 order), e4m3 -> bf16 exactly in registers.
@@ -1173,7 +1175,7 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMV-like kernel (M <= 16): HBM-bound weight streaming
+// skinny GEMV-like kernel (M <= 16; 17..64 rows with MG = 2..4 activation fragments per weight fragment): HBM-bound weight streaming
 // ------------------------------------------------------------------------------------------------
 // Block = 4 waves.  The block owns NTILE*16 consecutive W rows and the 64-element K chunks [c_begin, c_end) of split
 // blockIdx.y; wave w takes chunks c_begin + w, + 4, ...  W fragments go HBM -> VGPR -> MFMA (no LDS: each byte is used

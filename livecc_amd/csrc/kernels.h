@@ -27,7 +27,7 @@ enum LaunchCounter {
   LC_GEMM_TALL = 12,
   LC_ATTN_VIT32 = 13,          // attn_vit32_kernel (vision attention on 32x32x16 MFMAs)
   LC_GEMM_VH = 14,             // gemm_vh_kernel (row tiles of 256 / 272 / 288 rows; round 5 -- the slot of the retired gemm_pp_kernel)
-  LC_GEMM_VIT_QKV = 15,        // gemm_big_kernel with the EPI_VIT_QK / EPI_VIT_V epilogues (RoPE / V transpose fused into the q|k|v projection; 2 per tower block)
+  LC_GEMM_VIT_QKV = 15,        // gemm_big_kernel with the EPI_VIT_QK / EPI_VIT_V epilogues (RoPE / V transpose fused into the q|k|v projection; one EPI_VIT_QKV launch per tower block when E % 128 == 0, else a q|k launch + a V launch)
   LC_COUNT = 16
 };
 extern long long g_launch_counts[LC_COUNT];

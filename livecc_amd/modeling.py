@@ -133,7 +133,6 @@ class LiveCCForConditionalGeneration:
         self._side: Optional[torch.cuda.Stream] = None
         self._vit_cache: dict = {}
         self._vit_last_event: Optional[torch.cuda.Event] = None
-        self._sample_calls = 0                      # generate calls that drew their Philox seed from torch's default generator
         # CUs a prefetched vision tower may occupy while it runs under another turn's decode steps: -1 (default) = 128 for >= 4 clips (measured
         # +1.5 % tokens/s at 8 streams, profiles/r05/prefetch_grid_cap_ab.txt; one stream's tower is too small to share: 276 -> 256-269 tokens/s
         # under any cap), 0 = whole chip, n = n workgroups.  LCC_VIT_PREFETCH_CAP overrides.
@@ -282,7 +281,6 @@ class LiveCCForConditionalGeneration:
             # greedy calls leave the generator untouched like HF's.  Explicit `seed=` keeps a call reproducible by itself.
             if do_sample and top_k != 1:
                 seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
-                self._sample_calls += 1
             else:
                 seed = 0
         n = len(requests)

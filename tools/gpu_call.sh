@@ -37,7 +37,7 @@ mid)         # weight-streaming GEMV for 17-64 rows: kernel tests, then the 32-s
   ( timeout 500 $B --steps 1 --warmup 1 --streams-per-gpu 32 --share8 off ) > $O/bench_32s_mid.log 2>&1; tail -n 1 $O/bench_32s_mid.log | cut -c1-1600 ;;
 trace)       # kernel-trace breakdown of a multi-stream replay: bash tools/gpu_call.sh trace <streams>
   N=${1:-8}; shift || true; X="$*"; cd /tmp      # extra bench flags after the stream count, e.g. trace 32 --skinny-rows 16
-  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t$N -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-prefetch --streams-per-gpu $N --cpu-baseline off --parity off --share8 off $X > $O/bench_${N}s_under_rocprof.json 2> $O/trace_$N.err
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t$N -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-prefetch --streams-per-gpu $N --cpu-baseline off --parity off --share8 off --live2fps off --more-configs off $X > $O/bench_${N}s_under_rocprof.json 2> $O/trace_$N.err
   T=$(find $O/t$N -name '*kernel_trace.csv' | head -1); python $R/tools/trace_breakdown.py $T 28 > $O/step_breakdown_${N}streams_noprefetch.json 2>> $O/trace_$N.err; rm -rf $O/t$N
   [ -n "$X" ] && cp $O/step_breakdown_${N}streams_noprefetch.json "$O/step_breakdown_${N}streams_noprefetch_$(echo $X | tr -d ' -').json"
   python - <<PY
