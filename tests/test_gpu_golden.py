@@ -446,14 +446,23 @@ def test_livecc7b_long480_stream_against_the_committed_hf_stream(dev):
     tests/golden/livecc7b_long480_stream.npz (HF bf16 free-running on the tiled:0 weights, oracle/make_golden_7b_long_stream.py).  The native
     engine follows HF's tokens through ALL 238 turns (teacher forcing: both caches hold the same history); at the probe turns (60, 120, 180
     and the last three: 8k / 16k / 24k / 31.5k cached keys) every step's raw logits at HF's top-64 ids stay within 6e-2 x scale and the
-    native path's own choice equals HF's wherever HF's processed-score margin exceeds 8 % of the scale (no fp32 leg for this fixture:
-    238 fp32 turns at 7B are hours of host time; the error-ratio statistics of configs[3] come from the one-shot fixture)."""
+    native path's own choice equals HF's wherever HF's processed-score margin exceeds 8 % of the scale.  Round 5: at the
+    probe turns 60 and 120 (8.3k / 16.3k cached keys) tests/golden/livecc7b_long480_stream_fp32.npz holds the fp32 TRUTH of the same
+    teacher-forced stream (HF fp32 with its own fp32 cache built over all 121 turns, oracle/make_golden_7b_long_stream_fp32.py) and HF
+    bf16 at 4,096 sample ids: rms(native - fp32) <= 1.25 x rms(HF_bf16 - fp32) on each of those 24 steps -- the incremental path over a
+    deep cache now has the sensitive bound, not only the gross-error guard."""
     from livecc_amd import protocol
     from livecc_amd.config import get_config
     from livecc_amd.modeling import LiveCCForConditionalGeneration
     from livecc_amd.weights import WeightArena
     from oracle import make_golden_7b_long_stream as L
+    from oracle import make_golden_7b_long_stream_fp32 as L32
     g = dict(np.load(L.PATH))
+    g32 = dict(np.load(L32.PATH))
+    probes32 = set(int(x) for x in g32["probe_turns"])
+    assert all(f"t{ti}_sample_vals_fp32" in g32 for ti in probes32), "the fp32 leg of the fixture generator was interrupted"
+    sid32 = g32["sample_ids"]
+    ratios32 = []
     seed, n_frames, H, W, n_new, seed_w, n_turns = (int(x) for x in g["meta"])
     assert "final_kv" in g, "the fixture generator was interrupted"
     cfg = get_config("livecc-7b")
@@ -490,11 +499,19 @@ def test_livecc7b_long480_stream_against_the_committed_hf_stream(dev):
                 if margin > 0.08 * scale and winner == gold[k]:
                     st["decided"] += 1
                     st["decided_equal"] += int(own == gold[k])
+                if ti in probes32:
+                    n_, b16, t32 = (lg[k][sid32].astype(np.float64), g32[f"t{ti}_sample_vals_bf16"][k].astype(np.float64),
+                                    g32[f"t{ti}_sample_vals_fp32"][k].astype(np.float64))
+                    ratios32.append(float(np.sqrt(((n_ - t32) ** 2).mean()) / np.sqrt(((b16 - t32) ** 2).mean())))
                 seen.add(gold[k])
         past = np.concatenate([ids, np.asarray(gold[:-1], dtype=np.int64)])
     assert state.get_seq_length() == int(g["final_kv"]) == len(past)
     state.release()
+    ratios32 = np.asarray(ratios32)
+    st.update(fp32_probe_turns=sorted(probes32), fp32_steps=int(ratios32.size), worst_rms_ratio_vs_fp32=float(ratios32.max()),
+              rms_ratio_vs_fp32_all_steps=float(np.sqrt((ratios32 ** 2).mean())))
     record("livecc7b_long480_stream_vs_committed_golden", st)
+    assert ratios32.size == len(probes32) * n_new and ratios32.max() <= 1.25, ratios32
     assert st["steps"] == len(probes) * n_new
     assert st["worst_rel_dlogit_top"] <= 6e-2, st
     assert st["decided_equal"] == st["decided"], st

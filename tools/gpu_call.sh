@@ -218,6 +218,10 @@ r5d)         # round 5, call 4: the prefetched vision tower under a CU budget (p
     ( LCC_VIT_PREFETCH_CAP=$CAP timeout 500 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_1s_cap$CAP.log 2>&1
     echo "== 1 stream, prefetch cap $CAP: $(val $O/bench_1s_cap$CAP.log value) tok/s  step $(grep -o '"avg_step_us": [0-9.]*' $O/bench_1s_cap$CAP.log | head -1)"
   done ;;
+r5e)         # round 5, call 5: the long-stream fixture with its new fp32 leg + the 72B full-depth test again; GEMV-under-GEMM overlap probe
+  timeout 600 python -m pytest tests/test_gpu_golden.py tests/test_gpu_layer_parity.py -m gpu -q --timeout 500 -k "long480_stream or full_depth" > $O/fixtures.log 2>&1; tail -n 3 $O/fixtures.log
+  grep -A12 '"livecc7b_long480_stream_vs_committed_golden"' gpurun_out/parity_report.json | tr -d '\n' | cut -c1-700; echo
+  timeout 300 python tools/r5_overlap_probe.py 2>$O/overlap.err | tee $O/overlap_probe.jsonl ;;
 tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
