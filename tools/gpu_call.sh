@@ -15,17 +15,8 @@ val() { grep -o "\"$2\": [0-9.]*" $1 | head -1 | cut -d' ' -f2; }
 case $RECIPE in
 golden)      # the fixture-based 7B / 2B tests (no HF forward on the box)
   timeout 900 python -m pytest tests/test_gpu_golden.py -m gpu -q --timeout 600 "$@" > $O/golden.log 2>&1; tail -n 15 $O/golden.log ;;
-ring4)       # gemm_big4_kernel (LCC_GEMM_RING=4) vs the default: bit-identity, micro-benchmark, and (only if faster) the 8-stream bench A/B
-  timeout 200 python tools/gemm_checksum.py > $O/sum_ring2.txt 2>$O/sum_ring2.err
-  LCC_GEMM_RING=4 timeout 200 python tools/gemm_checksum.py > $O/sum_ring4.txt 2>$O/sum_ring4.err
-  cmp $O/sum_ring2.txt $O/sum_ring4.txt && echo "CHECKSUMS IDENTICAL (ring 2 vs ring 4)" || paste $O/sum_ring2.txt $O/sum_ring4.txt
-  for RING in 2 4 2 4; do LCC_GEMM_RING=$RING timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/ring$RING /" | tee -a $O/gemm_ring.txt; done ;;
 pmc_l2)      # L2 / TCP / TA counters of the 8-wave GEMM's DMA ring
   bash tools/pmc_gemm_l2.sh $O > $O/pmc_l2.log 2>&1; tail -n 70 $O/pmc_l2.log ;;
-pp)          # gemm_pp_kernel (ping-pong wave groups) vs gemm_big_kernel<256>: bit-identity (3 runs = race screen), GEMM tests, micro-benchmark
-  for V in 3 11 11 11 12; do timeout 200 python tools/gemm_checksum.py $V > $O/sum_v$V.txt 2>$O/sum_v$V.err; cmp $O/sum_v3.txt $O/sum_v$V.txt && echo "variant $V: CHECKSUMS IDENTICAL to variant 3" || { echo "variant $V DIFFERS"; paste $O/sum_v3.txt $O/sum_v$V.txt; tail -n 3 $O/sum_v$V.err; }; done
-  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --timeout 500 -k "gemm_tiled and (11 or 12)" > $O/gemm_tests.log 2>&1; tail -n 6 $O/gemm_tests.log
-  for V in 3 11 12 3 11 12; do timeout 120 python tools/bench_gemm_diag.py $V 2>/dev/null | grep '^{' | tee -a $O/gemm_pp_bench.txt; done ;;
 t192)        # the 192-row tile of the 8-wave GEMM: bit-identity with the 256-row tile, kernel tests, micro-benchmark (gate/up + down_proj)
   for V in 3 13; do timeout 200 python tools/gemm_checksum.py $V > $O/sum_v$V.txt 2>$O/sum_v$V.err; done
   cmp $O/sum_v3.txt $O/sum_v13.txt && echo "variant 13: CHECKSUMS IDENTICAL to variant 3" || { echo "variant 13 DIFFERS"; paste $O/sum_v3.txt $O/sum_v13.txt; tail -n 3 $O/sum_v13.err; }
@@ -226,5 +217,14 @@ tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
   timeout 1700 python bench.py "$@" > $O/bench.log 2>$O/bench.err; tail -n 3 $O/bench.log | cut -c1-3000; tail -n 5 $O/bench.err ;;
-*) echo "recipes: golden ring4 pmc_l2 tests bench (see the case statement)";;
+r5f)         # round 5, call 6: the k-tile barrier 3 steps before the end of the tile (LCC_GEMM_EARLY_BARRIER=1): bit-identity (3 runs), A/B
+  for E in 0 1 1 1; do LCC_GEMM_EARLY_BARRIER=$E timeout 200 python tools/gemm_checksum.py "$@" > $O/sum_e$E.txt 2>$O/sum_e$E.err; cmp $O/sum_e0.txt $O/sum_e$E.txt && echo "early barrier $E: CHECKSUMS IDENTICAL" || { echo "early barrier $E DIFFERS"; paste $O/sum_e0.txt $O/sum_e$E.txt; tail -n 3 $O/sum_e$E.err; }; done
+  for E in 0 1 0 1; do LCC_GEMM_EARLY_BARRIER=$E timeout 300 python tools/r5_bench_gemm.py early$E gate_up_M3088,gate_up_M1131,down_M3088,vit_fc1_P11648,vit_fc2_P11648,vit_qkv_P11648 2>/dev/null | grep '^{' | tee -a $O/gemm_early_barrier_ab.jsonl | cut -c1-200; done ;;
+r5g)         # round 5, call 7: what bounds the 8-wave GEMM now?  no-DMA / no-MFMA diagnostics of gemm_big_kernel<256> + the row-stride probe
+  for D in 0 2 3 0 2 3; do LCC_GEMM_VH=0 LCC_GEMM_DIAG=$D timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | tee -a $O/gemm_diag.jsonl; done
+  timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed 's/^/vh /' | tee -a $O/gemm_diag.jsonl
+  timeout 300 python tools/r5_lda_probe.py "$@" 2>$O/lda.err | tee -a $O/lda_probe.jsonl; tail -n 3 $O/lda.err ;;
+r5h)         # round 5, call 8: the row-stride probe again, A/B/A/B order: bash tools/gpu_call.sh r5h <pads> <shapes>
+  timeout 600 python tools/r5_lda_probe.py "$@" 2>$O/lda.err | tee -a $O/lda_probe_abab.jsonl; tail -n 2 $O/lda.err ;;
+*) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
