@@ -33,7 +33,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "down":      # the down projection (N = 
         print(json.dumps(dict(shape="down_proj", variant=sys.argv[1], M=M, us=round(us, 1), pflops=round(2.0 * M * H * I / us / 1e9, 3))))
     sys.exit(0)
 ws = [ops.pack_weight((torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(2)]
-for M in (3088, 1131):
+for M in (1131, 3088, 1131, 3088, 9048):      # the first shape of a process carries a ~10 % first-run penalty: read the repeats
     x = torch.randn(M, H, device=dev).to(torch.bfloat16)
     for i in range(4):
         ops.linear(x, ws[i % 2], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
