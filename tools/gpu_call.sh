@@ -229,5 +229,7 @@ r5h)         # round 5, call 8: the row-stride probe again, A/B/A/B order: bash 
 r5i)         # round 5, call 9: the 4-stage half-tile ring (gemm_big4_kernel) on the asm LDS-DMA vs gemm_big_kernel<256>: bit-identity, sustained A/B
   for RING in 2 4 4; do LCC_GEMM_VH=0 LCC_GEMM_RING=$RING timeout 200 python tools/gemm_checksum.py > $O/sum_ring$RING.txt 2>$O/sum_ring$RING.err; cmp $O/sum_ring2.txt $O/sum_ring$RING.txt && echo "ring $RING: CHECKSUMS IDENTICAL" || { echo "ring $RING DIFFERS"; paste $O/sum_ring2.txt $O/sum_ring$RING.txt; tail -n 3 $O/sum_ring$RING.err; }; done
   for RING in 2 4 2 4; do LCC_GEMM_VH=0 LCC_GEMM_RING=$RING timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/ring$RING /" | tee -a $O/gemm_ring4_asm_dma.txt; done ;;
+r5j)         # round 5, call 10: random vs zero-filled operands through the same GEMM launches (is the kernel clock / power bound?)
+  timeout 300 python tools/r5_power_probe.py 2>$O/power.err | tee $O/gemm_operand_toggling.jsonl; tail -n 2 $O/power.err ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
