@@ -95,11 +95,20 @@ FP8_MAX = 448.0   # largest finite OCP e4m3 value
 
 def quantize_fp8_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[N,K] float -> (q uint8 [N,K] = OCP e4m3 bit patterns, scale fp32 [N]) with w ~= q * scale[:, None]; per-output-row
-    absmax scaling (the row's largest weight maps to +-448), round-to-nearest-even (torch.float8_e4m3fn)."""
+    absmax scaling (the row's largest weight maps to +-448), round-to-nearest-even.
+
+    The rule is spelled out in operations that are exact, or correctly rounded, on every device, so a CPU process (the oracle) and the
+    GPU arena quantise the same checkpoint to the SAME bytes: scale = fp32(fp64(absmax) / 448) (`tensor / 448.0` in fp32 is a multiply by
+    the reciprocal on the GPU and a division on the CPU), x = fp32(fp64(w) / fp64(scale)), then x rounded to its e4m3 grid
+    by frexp / ldexp / round-half-even (the devices' own float -> float8 casts disagree on ~0.15 % of the elements: measured,
+    tools/probes/fp8_quantiser_cpu_vs_gpu.py) and only then cast, which is exact for a value already on the grid."""
     wf = w.float()
-    scale = (wf.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-12)
-    q = (wf / scale[:, None]).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
-    return q.view(torch.uint8), scale
+    scale = (wf.abs().amax(dim=1).double() / FP8_MAX).float().clamp_min(1e-12)
+    x = (wf.double() / scale.double()[:, None]).float().clamp_(-FP8_MAX, FP8_MAX)
+    _, e = torch.frexp(x)                                   # |x| = m * 2^e, m in [0.5, 1): the leading bit is 2^(e-1)
+    ulp_exp = (e - 4).clamp_(min=-9)                        # 3 mantissa bits below the leading one; subnormal step 2^-9 below 2^-6
+    q = torch.ldexp(torch.round(torch.ldexp(x, -ulp_exp)), ulp_exp).clamp_(-FP8_MAX, FP8_MAX)
+    return q.to(torch.float8_e4m3fn).view(torch.uint8), scale
 
 
 def dequantize_fp8_rows(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:

@@ -1,7 +1,9 @@
 """ORACLE / TEST INFRASTRUCTURE: tests/golden/qwen2vl72b_fp8_full_depth.npz -- the executed HF reference through ALL 80 decoder layers of
 BASELINE.json configs[4] (Qwen2-VL-72B shapes, LLM Linear weights as OCP e4m3 + fp32 row scales).
 
-    python oracle/make_golden_72b.py [--layers N] [--frames T]      (build container: 62 GB of host RAM, 8 cores: ~40 min)
+    python oracle/make_golden_72b.py [--layers N] [--frames T] [--out PATH] [--profile]      (build container: 62 GB of host RAM, 8 cores: ~40 min)
+    (--profile also writes tests/golden/qwen2vl72b_fp8_depth_profile.npz: the residual stream of both dtypes after every 4th layer at 4 prompt
+    rows x 512 hidden dims + the all-dims rms(bf16 - fp32) of every layer -- the depth profile of the reference's own error)
 
 A 72B model does not fit the build container (288 GB in fp32), and the GPU tier has no time for an HF forward at this size.  So HF's own
 modules run LAYER-STREAMED: one `Qwen2VLForConditionalGeneration` with ONE decoder layer is built per dtype (vision tower, embeddings,
@@ -38,6 +40,14 @@ from oracle.make_golden_7b_long import pack, sample_ids  # noqa: E402
 SEED_IN, T, H, W = 1234, 6, 392, 728
 N_FORCED, SEED_W = 4, 0
 PATH = os.path.join(ROOT, "tests", "golden", "qwen2vl72b_fp8_full_depth.npz")
+# depth profile (--profile): the residual stream after every PROFILE_EVERY-th decoder layer, both dtypes, at the last PROFILE_ROWS prompt rows x
+# PROFILE_DIMS seeded hidden dims -- where along the 80 layers does an implementation's error against the fp32 truth build up?
+PROFILE_PATH = os.path.join(ROOT, "tests", "golden", "qwen2vl72b_fp8_depth_profile.npz")
+PROFILE_EVERY, PROFILE_ROWS, PROFILE_DIMS = 4, 4, 512
+
+
+def profile_dims(hidden: int) -> np.ndarray:
+    return np.sort(np.random.default_rng(SEED_IN + 7272).choice(hidden, size=PROFILE_DIMS, replace=False)).astype(np.int64)
 FP8_LINEARS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj", "lm_head")
 
 
@@ -119,7 +129,7 @@ def capture_layer_inputs(m, cfg1, ids_all, pv, grid):
     return got["h"], got["kwargs"]
 
 
-def generate(n_layers=None, frames_t=T, path=PATH):
+def generate(n_layers=None, frames_t=T, path=PATH, profile_path=None):
     torch.set_num_threads(os.cpu_count() or 1)
     cfg = get_config("qwen2vl-72b")
     L = cfg.num_hidden_layers if n_layers is None else int(n_layers)
@@ -136,6 +146,20 @@ def generate(n_layers=None, frames_t=T, path=PATH):
         state[dt] = capture_layer_inputs(m, cfg1, ids_all, pv, grid)
         print(f"{dt}: vision tower + embeddings in {time.time() - t0:.0f} s, hidden {tuple(state[dt][0].shape)}", flush=True)
     layers = [shells[dt].model.language_model.layers[0] for dt in shells]
+    S = len(ids)
+    pdims = torch.from_numpy(profile_dims(cfg.hidden_size))
+    prows = slice(S - PROFILE_ROWS, S)      # prompt rows only: the native prefill (S rows) sees exactly these (causal)
+    prof = dict(layers=[], h32=[], h16=[], rms_err_bf16_all_dims=[], rms_fp32_all_dims=[])
+
+    def take(l):
+        a, t = state[torch.bfloat16][0][0, prows].float(), state[torch.float32][0][0, prows].float()
+        prof["rms_err_bf16_all_dims"].append(float((a - t).double().pow(2).mean().sqrt()))
+        prof["rms_fp32_all_dims"].append(float(t.double().pow(2).mean().sqrt()))
+        if l < 0 or l % PROFILE_EVERY == PROFILE_EVERY - 1 or l == L - 1:
+            prof["layers"].append(l)
+            prof["h32"].append(t[:, pdims].numpy().astype(np.float32))
+            prof["h16"].append(a[:, pdims].numpy().astype(np.float32))
+    take(-1)                                 # the embeddings handed to layer 0 (video rows: vision tower + merger output)
     with torch.inference_mode():
         for l in range(L):
             t0 = time.time()
@@ -145,7 +169,9 @@ def generate(n_layers=None, frames_t=T, path=PATH):
                 h, kw = state[dt]
                 out = m.model.language_model.layers[0](h, **kw)
                 state[dt] = ((out[0] if isinstance(out, tuple) else out), kw)
-            print(f"layer {l}: weights {t1 - t0:.0f} s, forward {time.time() - t1:.0f} s, |h|_rms fp32 {float(state[torch.float32][0].float().pow(2).mean().sqrt()):.4f}", flush=True)
+            take(l)
+            print(f"layer {l}: weights {t1 - t0:.0f} s, forward {time.time() - t1:.0f} s, |h|_rms fp32 {float(state[torch.float32][0].float().pow(2).mean().sqrt()):.4f}"
+                  f" rms(bf16 - fp32) at the probe rows {prof['rms_err_bf16_all_dims'][-1]:.5f}", flush=True)
         logits = {}
         for dt, m in shells.items():
             h = state[dt][0][:, -N_FORCED:]
@@ -155,6 +181,12 @@ def generate(n_layers=None, frames_t=T, path=PATH):
                grid=np.asarray(grid, dtype=np.int64), hf_bf16_argmax=l16.argmax(-1).numpy().astype(np.int64), hf_fp32_argmax=l32.argmax(-1).numpy().astype(np.int64))
     pack(out, "t0", l16, l32, sid)
     np.savez_compressed(path, **out)
+    if profile_path:
+        np.savez_compressed(profile_path, meta=out["meta"], rows=np.arange(S - PROFILE_ROWS, S, dtype=np.int64), dims=pdims.numpy(),
+                            layers=np.asarray(prof["layers"], dtype=np.int64), h_fp32=np.stack(prof["h32"]), h_bf16=np.stack(prof["h16"]),
+                            rms_err_bf16_all_dims=np.asarray(prof["rms_err_bf16_all_dims"], dtype=np.float32),
+                            rms_fp32_all_dims=np.asarray(prof["rms_fp32_all_dims"], dtype=np.float32))
+        print("wrote", profile_path, os.path.getsize(profile_path), "bytes", flush=True)
     print("wrote", path, os.path.getsize(path), "bytes; rms(bf16 - fp32) per step", out["t0_rms_err_bf16_full_vocab"].round(4).tolist(), "scale",
           out["t0_scale"].round(2).tolist(), flush=True)
     return out
@@ -165,4 +197,4 @@ if __name__ == "__main__":
     nl = int(a[a.index("--layers") + 1]) if "--layers" in a else None
     ft = int(a[a.index("--frames") + 1]) if "--frames" in a else T
     p = a[a.index("--out") + 1] if "--out" in a else PATH
-    generate(nl, ft, p)
+    generate(nl, ft, p, PROFILE_PATH if "--profile" in a else None)

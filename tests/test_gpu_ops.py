@@ -187,6 +187,19 @@ def test_gemm_auto_choice_at_the_7b_chunk_shape_is_the_tall_kernel_and_matches(d
 
 
 @pytest.mark.parametrize("M", [1, 2, 8, 16])
+def test_fp8_quantiser_gives_the_same_bytes_on_the_gpu_as_on_the_cpu(dev):
+    """The arena quantises on the GPU, the oracle on the CPU: same e4m3 bytes and same row scales for the same bf16 matrix (the devices'
+    own float -> float8 casts and `tensor / 448.0` do NOT agree: 0.15 % of the elements of a 72B matrix, tools/probes/fp8_quantiser_cpu_vs_gpu.py)."""
+    from livecc_amd.weights import quantize_fp8_rows
+    g = torch.Generator().manual_seed(11)
+    for shape, std in (((1024, 4096), 0.02), ((256, 8192), 1.0), ((64, 512), 1e-4)):
+        w = (torch.randn(*shape, generator=g) * std).to(torch.bfloat16)
+        qc, sc = quantize_fp8_rows(w)
+        qg, sg = quantize_fp8_rows(w.to(dev))
+        assert torch.equal(sc, sg.cpu()), shape
+        assert torch.equal(qc, qg.cpu()), (shape, int((qc != qg.cpu()).sum()))
+
+
 @pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1024, 192)])
 def test_gemv_w8_fp8_weights(dev, M, N, K):
     """fp8 (OCP e4m3 + fp32 row scale) weight-streaming GEMV: plain (+bias), split-K slabs, and the reference is the bf16 linear

@@ -161,6 +161,38 @@ def test_fp8_quantise_pack_roundtrip_and_arena_layout():
     assert arena.nbytes() < bf16.nbytes() and all(o[0] % 128 == 0 for o in arena.offsets.values())
 
 
+def test_fp8_quantiser_is_the_ieee_rule_spelled_out():
+    """`quantize_fp8_rows` is written in device-independent operations (fp64 division, frexp / ldexp / round-half-even) so that the CPU
+    oracle and the GPU arena hold the same bytes (round 5: the devices' own float -> float8 casts disagreed on 0.15 % of a 72B matrix, which
+    put the 80-layer 72B parity at 1.12-1.18 x the reference's error instead of 1.0).  On the CPU the spelled-out rule must equal the plain
+    one (fp32 division + torch's e4m3 cast: round-to-nearest-even, saturating): every e4m3 value, every midpoint between neighbours, values
+    just beside both, subnormals, +-448; and a seeded matrix byte for byte."""
+    from livecc_amd.weights import FP8_MAX, dequantize_fp8_rows, quantize_fp8_rows
+    vals = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float()
+    vals = vals[~vals.isnan()].sort().values
+    mids = (vals[:-1] + vals[1:]) / 2
+    probe = torch.cat([vals, mids, mids * (1 + 2.0 ** -20), mids * (1 - 2.0 ** -20), vals * 1.03, torch.tensor([0.0, 2.0 ** -10, 2.0 ** -11, 3 * 2.0 ** -11])]).clamp(-FP8_MAX, FP8_MAX)
+    # one row per probe value next to a +-448 entry, so the row scale is exactly 1 and x = the probe value itself
+    w = torch.zeros(probe.numel(), 64)
+    w[:, 0] = FP8_MAX
+    w[:, 1] = probe
+    q, sc = quantize_fp8_rows(w)
+    assert torch.equal(sc, torch.ones_like(sc))
+    want = probe.clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q[:, 1], want), (probe[q[:, 1] != want][:8], q[:, 1][q[:, 1] != want][:8], want[q[:, 1] != want][:8])
+    g = torch.Generator().manual_seed(5)
+    wm = (torch.randn(512, 2048, generator=g) * 0.02).to(torch.bfloat16)
+    q1, s1 = quantize_fp8_rows(wm)
+    wf = wm.float()
+    s0 = (wf.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-12)
+    q0 = (wf / s0[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(s1, s0) and torch.equal(q1, q0)
+    q2, s2 = quantize_fp8_rows(dequantize_fp8_rows(q1, s1))                  # a dequantised checkpoint re-quantises to itself
+    assert torch.equal(q2, q1) and torch.equal(s2, s1)
+    qz, sz = quantize_fp8_rows(torch.zeros(16, 64))                          # all-zero rows: scale floor, zero bytes
+    assert int(qz.sum()) == 0 and bool((sz > 0).all())
+
+
 def test_vit_rope_copy_is_the_row_permuted_qkv_weight_in_rotation_pair_order():
     """`vit.{i}.qkv_w_rope` / `qkv_b_rope` (the q|k|v projection whose GEMM epilogue applies the 2-D RoPE, csrc/gemm.hip vit_qkv_epilogue):
     a permutation; inside q and k every 32 stored rows are 16 first-half channels followed by their partners 40 channels later IN THE SAME
