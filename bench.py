@@ -368,7 +368,7 @@ def configs2_share(cfg, make_model, dev, args, protocol, streams=8, steps=2, ran
     return out
 
 
-def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64, 96, 128), video_s=12.0, deadline_s=1.0):
+def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64, 96, 112, 128), video_s=12.0, deadline_s=1.0):
     """SURVEY 8f-2 under LIVE pacing (north_star: "concurrent 2 fps streams"; ref demo/infer.py:105-129, 165-175: one blocking generate per
     due chunk): N streams whose frames ARRIVE at 2 fps on the server's wall clock, `livecc_amd.server.StreamServer` batching whatever is
     due at each step, `max_new_tokens` forced greedy tokens per chunk, NO look-ahead (prefetch off: a chunk's vision tower starts only
