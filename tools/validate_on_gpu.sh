@@ -26,11 +26,6 @@ timeout 300 python tools/r5_bench_gemm.py final > $O/gemm_shapes_final.jsonl 2>$
 timeout 300 python tools/r5_tower.py final > $O/tower_final.jsonl 2>$O/tower_final.err
 bash tools/gpu_call.sh trace 8 > $O/trace8.log 2>&1; cp gpurun_out/trace/step_breakdown_8streams_noprefetch.json $O/ 2>/dev/null
 bash tools/gpu_call.sh trace 1 > $O/trace1.log 2>&1; cp gpurun_out/trace/step_breakdown_1streams_noprefetch.json $O/ 2>/dev/null
-# decode attention key-split knobs (one stream): tiles per split 4 (default) / 3 / 2
-for KV in "X=0" "LCC_ATTN_TPS=3 LCC_ATTN_MAXSPLIT=96" "LCC_ATTN_TPS=2 LCC_ATTN_MAXSPLIT=128" "X=1"; do
-  T=$(echo $KV | tr -d ' ='); ( env $KV $B --steps 2 --warmup 1 --share8 off ) > $O/tps_$T.log 2>&1
-  echo "== decode attention [$KV]: $(grep -o '"value": [0-9.]*' $O/tps_$T.log | head -1) $(grep -o '"avg_step_us": [0-9.]*' $O/tps_$T.log | head -2 | tr '\n' ' ')" | tee -a $O/attn_tps_ab.txt
-done
 tail -n 40 $O/test_full.log; tail -n 2 $O/smoke.log
 for f in bench_default bench_noprefetch bench_8streams bench_32streams bench_oneshot480 bench_2b bench_7b_fp8; do echo "== $f $(grep -o '"value": [0-9.]*' $O/$f.log | head -1) $(grep -o '"us_per_layer": [0-9.]*' $O/$f.log | tr '\n' ' ')"; done
 grep -o '"parity": {.*' $O/bench_default.log | cut -c1-1500
