@@ -477,6 +477,11 @@ def _fixture_test(test_file, expr, keys, timeout_s):
         if os.path.exists(rp):
             allrec = json.load(open(rp))
             rec = {k: allrec[k] for k in keys if k in allrec}
+            for v in rec.values():      # per-depth tables stay in the test's own report: the line carries their range
+                dp = v.get("depth_profile") if isinstance(v, dict) else None
+                if isinstance(dp, dict) and dp.get("rms_ratio"):
+                    rr = [x for x, l in zip(dp["rms_ratio"], dp["layers"]) if l >= 0]
+                    v["depth_profile"] = dict(layers_probed=len(rr), rms_ratio_min=min(rr), rms_ratio_max=max(rr))
         return dict(test=f"tests/{test_file} -k '{expr}'", passed=r.returncode == 0, seconds=round(time.perf_counter() - t0, 1),
                     tail=r.stdout.strip().splitlines()[-1][:160] if r.stdout.strip() else "", **rec)
     finally:
