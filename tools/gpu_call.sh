@@ -231,5 +231,11 @@ r5i)         # round 5, call 9: the 4-stage half-tile ring (gemm_big4_kernel) on
   for RING in 2 4 2 4; do LCC_GEMM_VH=0 LCC_GEMM_RING=$RING timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/ring$RING /" | tee -a $O/gemm_ring4_asm_dma.txt; done ;;
 r5j)         # round 5, call 10: random vs zero-filled operands through the same GEMM launches (is the kernel clock / power bound?)
   timeout 300 python tools/r5_power_probe.py 2>$O/power.err | tee $O/gemm_operand_toggling.jsonl; tail -n 2 $O/power.err ;;
+r5k)         # round 5, call 11: shader clock + socket power under the GEMM on random vs zero-filled operands (and under the HBM-bound GEMV)
+  ls /sys/class/drm/card*/device/hwmon/hwmon*/ 2>/dev/null | head -40 > $O/hwmon_files.txt
+  timeout 200 python tools/r5_clock_probe.py 2>$O/clock.err | tee $O/gemm_clock_power.jsonl; tail -n 2 $O/clock.err ;;
+r5l)         # round 5, call 12: effective clock of the GEMM dispatches on random vs zero-filled operands: GRBM_GUI_ACTIVE cycles / duration
+  cd /tmp; timeout 500 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_clock -o clk -- python $R/tools/r5_power_probe.py > $O/power_under_pmc.jsonl 2>$O/pmc.err
+  cd $R; python tools/r5_clock_from_pmc.py $O/pmc_clock | tee $O/gemm_effective_clock.jsonl; tail -n 2 $O/pmc.err; rm -rf $O/pmc_clock ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
