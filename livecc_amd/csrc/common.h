@@ -41,6 +41,9 @@ LCC_DEVICE void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 LCC_DEVICE u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
 LCC_DEVICE void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 
+#ifndef LCC_GLDS_POLICY      // cache-policy suffix of the LDS-DMA instruction (build-time experiment knob: " nt", " sc0", ...)
+#define LCC_GLDS_POLICY ""
+#endif
 // LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes at `gsrc` land at LDS byte address `lds_dst` + l * 16
 // (`lds_dst` wave-uniform).  INLINE ASM ON PURPOSE (round 5): the builtin is a FLAT-encoded instruction with an LDS memory operand, so
 // hipcc's waitcnt pass books it as "may access LDS through flat" -- from then on EVERY s_waitcnt it inserts in front of a ds_read
@@ -51,7 +54,7 @@ LCC_DEVICE void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 // M0 is saved and restored around the statement (cdna_hip_programming.md section 5.7); the s_nop covers the M0 write -> LDS-DMA hazard.
 LCC_DEVICE void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" LCC_GLDS_POLICY "\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");   // readfirstlane: free when provably uniform
 }
 // Make the compiler wait HERE for a plain global load it is tracking (it must insert its own s_waitcnt in front of a statement that reads

@@ -237,5 +237,14 @@ r5k)         # round 5, call 11: shader clock + socket power under the GEMM on r
 r5l)         # round 5, call 12: effective clock of the GEMM dispatches on random vs zero-filled operands: GRBM_GUI_ACTIVE cycles / duration
   cd /tmp; timeout 500 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_clock -o clk -- python $R/tools/r5_power_probe.py > $O/power_under_pmc.jsonl 2>$O/pmc.err
   cd $R; python tools/r5_clock_from_pmc.py $O/pmc_clock | tee $O/gemm_effective_clock.jsonl; tail -n 2 $O/pmc.err; rm -rf $O/pmc_clock ;;
+r5m)         # round 5, call 13: cache policy of the LDS-DMA instruction (builds livecc_amd/_C_{nt,sc0,sc1}: -DLCC_GLDS_POLICY): bit-identity + A/B
+  for P in "" _nt _sc0 _sc1; do
+    L=$R/livecc_amd/_C$P/liblivecc_amd.so; [ -f $L ] || continue
+    LCC_LIB_PATH=$L timeout 200 python tools/gemm_checksum.py > $O/sum$P.txt 2>$O/sum$P.err; cmp $O/sum.txt $O/sum$P.txt > /dev/null && echo "policy[$P]: CHECKSUMS IDENTICAL" || echo "policy[$P] DIFFERS"
+    LCC_LIB_PATH=$L timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/policy[$P] /" | tee -a $O/glds_policy_ab.txt
+    LCC_LIB_PATH=$L LCC_GEMM_VH=0 LCC_GEMM_DIAG=3 timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/policy[$P] dma-only /" | tee -a $O/glds_policy_ab.txt
+    LCC_LIB_PATH=$L timeout 200 python tools/r5_bench_gemm.py "policy$P" gate_up_M386_tall,vit_fc2_P1456,vit_fc1_P1456,down_M3088 2>/dev/null | grep '^{' | tee -a $O/glds_policy_ab.txt | cut -c1-180
+    LCC_LIB_PATH=$L timeout 200 python tools/r5_tower.py "policy$P" 2>/dev/null | grep '^{' | tee -a $O/glds_policy_ab.txt
+  done ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
