@@ -15,6 +15,7 @@ import torch  # noqa: E402
 from livecc_amd import _lib, ops  # noqa: E402
 
 lib = _lib.load()
+ZEROS = "--zeros" in sys.argv
 dev = torch.device("cuda:0")
 Hq, Hkv = 28, 4
 
@@ -32,6 +33,8 @@ def tables(segs, tile_rows):
 def run(kv, segs, variant, tile_rows, nsplit, iters=20):
     (a, b, c, d), rows = tables(segs, tile_rows)
     q = (torch.randn(rows, Hq * 128, device=dev) * 0.7).to(torch.bfloat16)
+    if ZEROS:
+        q.zero_()
     out = torch.empty_like(q)
     ws_o = torch.empty(rows * Hq * max(nsplit, 1) * 128, dtype=torch.float32, device=dev)
     ws_ml = torch.empty(rows * Hq * max(nsplit, 1) * 2, dtype=torch.float32, device=dev)
@@ -64,10 +67,14 @@ cases = [("chunk_1stream", [(0, 386, 6200)]), ("chunk_8streams", [(s, 386, 6200)
 quick = "--quick" in sys.argv
 kv = ops.KvArena(8, 1, Hkv, 24576 + 8192, dev)
 kv.buf.copy_((torch.randn(kv.buf.shape, device=dev) * 0.7).to(torch.bfloat16))
+if ZEROS:      # --zeros: the same launches on zero-filled q / K / V (is the kernel clock-throttled on real data like the GEMMs are?)
+    kv.buf.zero_()
+if "--only32" in sys.argv:
+    cases = [c for c in cases if c[0] in ("chunk_8streams", "first_turn_8streams", "oneshot_piece_4096_at_8k")]
 for name, segs in cases:
     rows = sum(n for _, n, _ in segs)
     ref = None
-    for variant, tr, nss in ((2, 16, (1, 4, 8)), (2, 32, (1, 4)), (3, 32, (1, 2, 3, 4, 6, 8))):
+    for variant, tr, nss in (((3, 32, (1, 4)),) if "--only32" in sys.argv else ((2, 16, (1, 4, 8)), (2, 32, (1, 4)), (3, 32, (1, 2, 3, 4, 6, 8)))):
         for ns in nss:
             if ns > 1 and rows > 1024 * 8:
                 continue
@@ -77,5 +84,5 @@ for name, segs in cases:
             if ref is None:
                 ref = out.float()
             err = float((out.float() - ref).abs().max())
-            print(json.dumps(dict(case=name, rows=rows, variant=variant, tile_rows=tr, nsplit=ns, us=round(us, 1), pflops=round(pf, 3),
+            print(json.dumps(dict(operands="zeros" if ZEROS else "random", case=name, rows=rows, variant=variant, tile_rows=tr, nsplit=ns, us=round(us, 1), pflops=round(pf, 3),
                                   max_abs_diff_vs_first=round(err, 5))), flush=True)

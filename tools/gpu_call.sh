@@ -246,5 +246,7 @@ r5m)         # round 5, call 13: cache policy of the LDS-DMA instruction (builds
     LCC_LIB_PATH=$L timeout 200 python tools/r5_bench_gemm.py "policy$P" gate_up_M386_tall,vit_fc2_P1456,vit_fc1_P1456,down_M3088 2>/dev/null | grep '^{' | tee -a $O/glds_policy_ab.txt | cut -c1-180
     LCC_LIB_PATH=$L timeout 200 python tools/r5_tower.py "policy$P" 2>/dev/null | grep '^{' | tee -a $O/glds_policy_ab.txt
   done ;;
+r5n)         # round 5, call 14: the prefill attention kernel on random vs zero-filled q / K / V (clock-throttled like the GEMMs?)
+  for Z in "" --zeros "" --zeros; do timeout 200 python tools/bench_attn.py --only32 $Z 2>/dev/null | grep '^{' | tee -a $O/attn_operand_toggling.jsonl | cut -c1-200; done ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
