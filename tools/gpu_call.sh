@@ -248,5 +248,9 @@ r5m)         # round 5, call 13: cache policy of the LDS-DMA instruction (builds
   done ;;
 r5n)         # round 5, call 14: the prefill attention kernel on random vs zero-filled q / K / V (clock-throttled like the GEMMs?)
   for Z in "" --zeros "" --zeros; do timeout 200 python tools/bench_attn.py --only32 $Z 2>/dev/null | grep '^{' | tee -a $O/attn_operand_toggling.jsonl | cut -c1-200; done ;;
+r5o)         # round 5, call 15: a full-size (16.6 GB, sharded, HF 4.5x keys) safetensors checkpoint through weights.from_pretrained, bf16 and fp8 arenas
+  df -h /tmp | tail -n 1 > $O/disk.txt
+  timeout 900 python tools/full_size_loader_check.py 2>$O/loader.err | tee $O/full_size_loader_check.jsonl
+  timeout 900 python tools/full_size_loader_check.py --fp8 2>>$O/loader.err | tee -a $O/full_size_loader_check.jsonl; tail -n 3 $O/loader.err ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
