@@ -402,7 +402,7 @@ def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64, 96, 112
             f = base_frames[i % 8] if i < 8 else base_frames[i % 8].roll(i // 8, dims=0).contiguous()     # distinct content per stream
             t_live[i] = i / N
             srv.add_stream(i, f, pts, t_start=t_live[i] + fti, max_pixels=args.height * args.width)
-        lat, first, steps = [], [], []
+        lat, lat_t, first, steps = [], [], [], []
         base = time.monotonic()
         inner = srv.step
 
@@ -420,6 +420,7 @@ def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64, 96, 112
                 first.append(t - (t_live[sid] + fti))      # (the reference's rule, ref demo/infer.py:107-110): join -> text
             else:
                 lat.append(t - (t_live[sid] + span[1] - fti))      # arrival of the chunk's last frame on the stream's live clock -> text
+                lat_t.append(t)
         torch.cuda.synchronize(dev)
         srv.run(until=video_s + 8.0, realtime=True, on_result=on_result, t0=base)
         wall = time.monotonic() - base
@@ -436,6 +437,10 @@ def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64, 96, 112
                    initial_chunk_s_mean=round(float(np.mean(first)), 3) if first else None,
                    scheduler_steps=len(steps), mean_chunks_per_step=round(served / max(1, len(steps)), 2),
                    gpu_busy_frac=round(busy / wall, 3), tokens_per_s=round(served * args.max_new_tokens / wall, 1), wall_s=round(wall, 2))
+        if video_s > 20.0 and lat:      # a soak run (tools/r5_live_soak.py): does the latency drift as the KV history grows?
+            la, lt = np.asarray(lat), np.asarray(lat_t)
+            row["p99_s_by_10s_window"] = [round(float(np.percentile(la[(lt >= w) & (lt < w + 10.0)], 99)), 3) if ((lt >= w) & (lt < w + 10.0)).any() else None
+                                          for w in np.arange(0.0, video_s + 10.0, 10.0)]
         row["meets_deadline"] = bool(served == expected and row["p99_s"] <= deadline_s)
         rows.append(row)
         if row["meets_deadline"]:

@@ -252,5 +252,7 @@ r5o)         # round 5, call 15: a full-size (16.6 GB, sharded, HF 4.5x keys) sa
   df -h /tmp | tail -n 1 > $O/disk.txt
   timeout 900 python tools/full_size_loader_check.py 2>$O/loader.err | tee $O/full_size_loader_check.jsonl
   timeout 900 python tools/full_size_loader_check.py --fp8 2>>$O/loader.err | tee -a $O/full_size_loader_check.jsonl; tail -n 3 $O/loader.err ;;
+r5p)         # round 5, call 16: soak of the live-paced server leg: N streams x 60 s of video (KV history to ~26k keys per stream), p99 per 10-s window
+  timeout 400 python tools/r5_live_soak.py ${1:-48} ${2:-60} 2>$O/soak.err | tee -a $O/live2fps_soak.jsonl | cut -c1-900; tail -n 2 $O/soak.err ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
