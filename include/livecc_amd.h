@@ -64,7 +64,10 @@ int lcc_debug_set_gemv_variant(int variant);
  * takes it when 256 < M <= 448 and ceil(N/160) fills 75-100 % of one round of the chip (LiveCC-7B gate/up of a streaming chunk);
  * 13 = the 192-row 8-wave tile wherever eligible; 14 = row tiles of variable height (256 / 272 / 288 rows: ceil(M/16) row fragments dealt
  * out over floor(ceil(M/16)/16) tiles, no ragged last tile; round 5) wherever legal, else as 3 -- the default picks them by score (e.g. the
- * gate/up GEMM of 8 co-scheduled chunks: 12 x 148 tiles instead of 13 x 148).  Every tile shape produces the same bits. */
+ * gate/up GEMM of 8 co-scheduled chunks: 12 x 148 tiles instead of 13 x 148); 15 = the SMALL variable-height class (row tiles of 128 / 144
+ * rows) for split-K slabs of 64 < M <= 448 wherever legal, else as 4 -- the default picks it by score for the o / down / q|k|v projections
+ * of one streaming chunk (M = 386: 3 row tiles instead of 4, 6 / 6 / 4 splits; LCC_GEMM_VH_SMALL=0 restores the 128-row tiles and their
+ * 4 / 4 / 3 splits).  Every tile shape produces the same bits for the same split count. */
 int lcc_debug_set_gemm_variant(int variant);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
  * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs

@@ -52,7 +52,7 @@ size_t lcc_engine::llm_ws_bytes() const {
   t += align_up(S * qd * 2) * 2;             // q, attn
   t += align_up(S * I * 2);                  // act
   t += align_up(S * 64 * 2) * 2;             // cos, sin
-  t += align_up(std::max((size_t)MAX_SPLIT * 64 * std::max<size_t>(qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H) * 4);  // split-K slabs
+  t += align_up(std::max((size_t)MAX_SPLIT * 64 * std::max<size_t>(qkvd, H), (size_t)6 * std::min<size_t>(S, 4096) * H) * 4);  // split-K slabs (up to 6 of S x H floats)
   t += align_up(B * H * 2) * 2;              // last_h, last_xn
   t += align_up(16 * (H / 16 + 4) * 4);      // decode v2: per-tile sums of squares of the residual rows
   t += align_up(B * V * 2);                  // logits

@@ -30,7 +30,7 @@ int carve_llm(lcc_engine* e, LlmBuffers* b) {
   b->h = cv.take<bf16_t>(S * H); b->xn = cv.take<bf16_t>(S * H); b->qkv = cv.take<bf16_t>(S * e->qkvd);
   b->q = cv.take<bf16_t>(S * e->qd); b->attn = cv.take<bf16_t>(S * e->qd); b->act = cv.take<bf16_t>(S * I);
   b->cos = cv.take<bf16_t>(S * 64); b->sin = cv.take<bf16_t>(S * 64);
-  b->partial = cv.take<float>(std::max((size_t)MAX_SPLIT * 64 * std::max<size_t>(e->qkvd, H), (size_t)4 * std::min<size_t>(S, 4096) * H));
+  b->partial = cv.take<float>(std::max((size_t)MAX_SPLIT * 64 * std::max<size_t>(e->qkvd, H), (size_t)6 * std::min<size_t>(S, 4096) * H));
   b->last_h = cv.take<bf16_t>(B * H); b->last_xn = cv.take<bf16_t>(B * H);
   b->stats = cv.take<float>(16 * (H / 16 + 4));
   b->logits = cv.take<bf16_t>(B * V);
@@ -56,13 +56,15 @@ int run_layers(lcc_engine* e, const LlmBuffers& b, const LayerCtx& cx, hipStream
   const int sp_o = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(H, e->qd)) : 0;
   const int sp_dn = cx.skinny ? std::min(MAX_SPLIT, gemv_num_splits(H, I)) : 0;
   // prefill with few output tiles (N = hidden): split-K slabs, reduced by the fused residual-add + RMSNorm kernel
-  const int tp_o = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, e->qd);
-  const int tp_dn = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, I);
+  // (up to 6 slabs of S x H floats: the slab buffer holds 6 x min(max_new_rows, 4096) x H -- carve_llm -- and S <= max_new_rows)
+  const bool w16 = !e->c.llm_fp8;
+  const int tp_o = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, e->qd, w16);
+  const int tp_dn = cx.skinny ? 1 : gemm_tiled_num_splits(S, H, I, w16);
   // q/k/v of a short prefill (one streaming chunk): split-K slabs consumed by the rope / KV-append kernel (267.5 -> 269.1 tok/s single
   // stream; LCC_PREFILL_QKV_SPLIT=0 restores the bf16 GEMM output)
   static const int qkv_split_on = [] { const char* v = getenv("LCC_PREFILL_QKV_SPLIT"); return v ? atoi(v) : 1; }();
-  const int tp_qkv = (cx.skinny || !qkv_split_on || e->c.llm_fp8 || (size_t)4 * std::min<size_t>(e->lim.max_new_rows, 4096) * H <
-                      (size_t)8 * S * e->qkvd) ? 1 : gemm_tiled_num_splits(S, e->qkvd, H);
+  const int tp_qkv = (cx.skinny || !qkv_split_on || e->c.llm_fp8 || (size_t)6 * std::min<size_t>(e->lim.max_new_rows, 4096) * H <
+                      (size_t)8 * S * e->qkvd) ? 1 : gemm_tiled_num_splits(S, e->qkvd, H, true);
   // fp8 weights: the same GemmArgs with the byte pointer, the row scales and the dequantisation scratch of the tiled path
   auto set_w = [&](GemmArgs& g, const bf16_t* w, const float* scale) {
     g.w_packed = 1; g.W = w;

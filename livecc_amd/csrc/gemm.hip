@@ -701,16 +701,26 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(
 //     spread one per row-tile step behind the barrier (gemm_big_kernel's SCHED 6).
 // Accumulation order per output element = gemm_big_kernel's (k-step 0, then 1, tile after tile): bit-identical outputs.
 // Requires packed bf16 W, K % 64 == 0, F >= 16, F <= 18 * floor(F / 16).
-template <int EPI>
+// SMALL = 1 (round 5): the same kernel over row tiles of 8 or 9 fragments (128 / 144 rows) for the split-K projections of ONE streaming
+// chunk (M = 386 = 25 fragments: 3 row tiles of 9 + 8 + 8 instead of gemm_big_kernel<128>'s 4, whose fourth holds 2 rows): an M-wave
+// multiplies 4 or 5 row fragments, 2 activation pieces per wave + the extra slot (rows 128-143, waves 0-1), a ring of THREE 51,200-B stages
+// (one more tile in flight: at 32-40 MFMAs per wave and k-tile a single stage of look-ahead left the DMA round trip exposed: 104 vs 72 us).
+template <int EPI, int SMALL>
 __global__ __launch_bounds__(512) void gemm_vh_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
     const bf16_t* __restrict__ bias, const bf16_t* __restrict__ residual, int ldr,
     bf16_t* __restrict__ C, int ldc, int M, int N, int K, int tiles_m, int tiles_n,
     float* __restrict__ partial, int kt_per_split, int raster) {
-  constexpr int BN = 256, BK = 64, NT = 4, MTX = 9, NSLOT = 9;
-  constexpr int A_UNITS = 288 * 8;                // 16-byte units of the activation image
-  constexpr int STAGE = A_UNITS + 32 * 64;        // + 32 W sub-tiles of 1 KB: 4352 units = 69,632 B
-  constexpr unsigned SCRATCH = 2u * STAGE * 16u;  // byte offset of the 1-KB scratch behind the two stages
+  constexpr int BN = 256, BK = 64, NT = 4;
+  constexpr int MTX = SMALL ? 5 : 9, MTL = MTX - 1;          // row fragments of an M-wave: MTL or MTX
+  constexpr int APW = SMALL ? 2 : 4;                         // 8-row activation pieces per wave below XBASE
+  constexpr int XBASE = APW * 64;                            // 128 / 256: the rows above ride on the extra slot
+  constexpr int AROWS = XBASE + (SMALL ? 16 : 32);           // 144 / 288
+  constexpr int NSLOT = APW + 5;
+  constexpr int A_UNITS = AROWS * 8;              // 16-byte units of the activation image
+  constexpr int STAGE = A_UNITS + 32 * 64;        // + 32 W sub-tiles of 1 KB: 4352 units = 69,632 B (SMALL: 3200 units = 51,200 B)
+  constexpr int NST = SMALL ? 3 : 2;              // ring depth: the small tile's k-step is too short to hide a DMA round trip behind one stage
+  constexpr unsigned SCRATCH = (unsigned)NST * STAGE * 16u;  // byte offset of the 1-KB scratch behind the stages
   extern __shared__ __attribute__((aligned(16))) u32x4 dsmem[];
 
   const int nblk = tiles_m * tiles_n;
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(512) void gemm_vh_kernel(
     tm = bid - tn * tiles_m;
   }
   const int F = (M + 15) >> 4, fbase = F / tiles_m, frem = F - fbase * tiles_m;
-  const int f = fbase + (tm < frem ? 1 : 0);                       // row fragments of this tile: 16..18
+  const int f = fbase + (tm < frem ? 1 : 0);                       // row fragments of this tile: 16..18 (SMALL: 8..9)
   const int m0 = (tm * fbase + min(tm, frem)) << 4, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -747,34 +757,36 @@ __global__ __launch_bounds__(512) void gemm_vh_kernel(
   unsigned pdst[NSLOT];
   const int swz = ((lane & 7) ^ (lane >> 3)) << 3;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = (wave * 4 + q) * 8 + (lane >> 3);
+  for (int q = 0; q < APW; ++q) {
+    const int row = (wave * APW + q) * 8 + (lane >> 3);
     psrc[q] = A + (size_t)min(m0 + row, M - 1) * lda + swz;
-    pdst[q] = (unsigned)(wave * 4 + q) * 1024u;
+    pdst[q] = (unsigned)(wave * APW + q) * 1024u;
   }
   {
-    const bool have = wave < 4 && 256 + wave * 8 < f * 16;         // wave-uniform
-    const int row = 256 + (wave & 3) * 8 + (lane >> 3);
-    psrc[4] = have ? A + (size_t)min(m0 + row, M - 1) * lda + swz : A;
-    pdst[4] = have ? (unsigned)(32 + wave) * 1024u : SCRATCH;
+    const bool have = wave < 4 && XBASE + wave * 8 < f * 16;       // wave-uniform
+    const int row = XBASE + (wave & 3) * 8 + (lane >> 3);
+    psrc[APW] = have ? A + (size_t)min(m0 + row, M - 1) * lda + swz : A;
+    pdst[APW] = have ? (unsigned)(XBASE / 8 + wave) * 1024u : SCRATCH;
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int st = wave * 4 + q, fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
-    psrc[5 + q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
-    pdst[5 + q] = (unsigned)(A_UNITS + st * 64) * 16u;
+    psrc[APW + 1 + q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
+    pdst[APW + 1 + q] = (unsigned)(A_UNITS + st * 64) * 16u;
   }
   const unsigned lds0 = lds_addr(dsmem);
-  auto piece = [&](int q, int kt, unsigned stage_lds) {             // q < 5: activations advance 64 elements per k-tile, W 1024
-    glds16(psrc[q] + (size_t)kt * (q < 5 ? BK : 1024), pdst[q] == SCRATCH ? lds0 + SCRATCH : stage_lds + pdst[q]);
+  auto piece = [&](int q, int kt, unsigned stage_lds) {             // q <= APW: activations advance 64 elements per k-tile, W 1024
+    glds16(psrc[q] + (size_t)kt * (q <= APW ? BK : 1024), pdst[q] == SCRATCH ? lds0 + SCRATCH : stage_lds + pdst[q]);
   };
 
   const int nkt_all = K / BK;
   const int kt0 = (EPI == EPI_PARTIAL) ? blockIdx.y * kt_per_split : 0;
   const int nkt = (EPI == EPI_PARTIAL) ? min(nkt_all, kt0 + kt_per_split) : nkt_all;
-  if (kt0 < nkt) {
+  if (kt0 < nkt) {      // tiles kt0 .. kt0 + NST - 2 (clamped) into stages 0 .. NST - 2
 #pragma unroll
-    for (int q = 0; q < NSLOT; ++q) piece(q, kt0, lds0);
+    for (int p = 0; p < NST - 1; ++p)
+#pragma unroll
+      for (int q = 0; q < NSLOT; ++q) piece(q, min(kt0 + p, nkt - 1), lds0 + (unsigned)(p * STAGE) * 16u);
   }
   int aoff[2];
 #pragma unroll
@@ -788,14 +800,20 @@ __global__ __launch_bounds__(512) void gemm_vh_kernel(
     for (int i = 0; i < (MTW > 0 ? MTW : 1); ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int st_cur = 0;                   // stage of tile kt = (kt - kt0) % NST
     for (int kt = kt0; kt < nkt; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // every wave issues exactly NSLOT pieces per tile, so with NST = 3 the newest tile's pieces may stay in flight across the barrier
+      static_assert(NST == 2 || NSLOT == 7, "the counted wait below is written for 7 pieces per tile");
+      if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // tile kt complete in LDS; every wave is done reading tile kt-1
-      const u32x4* s = dsmem + ((kt - kt0) & 1) * STAGE;
-      // the pieces of tile kt+1 go out unconditionally (a branch would cut the scheduling region): past the last tile the source is clamped
-      // and the copy lands in the stage nobody reads any more
-      const int kt_dma = min(kt + 1, nkt - 1);
-      const unsigned dma_lds = lds0 + (unsigned)(((kt + 1 - kt0) & 1) * STAGE) * 16u;
+      const u32x4* s = dsmem + st_cur * STAGE;
+      // the pieces of tile kt+NST-1 go out unconditionally (a branch would cut the scheduling region): past the last tile the source is
+      // clamped and the copy lands in a stage nobody reads any more (the stage of tile kt-1)
+      const int kt_dma = min(kt + NST - 1, nkt - 1);
+      const int st_dma = st_cur == 0 ? NST - 1 : st_cur - 1;
+      const unsigned dma_lds = lds0 + (unsigned)(st_dma * STAGE) * 16u;
+      st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
       if constexpr (MTW == 0) {
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) piece(q, kt_dma, dma_lds);
@@ -829,11 +847,12 @@ __global__ __launch_bounds__(512) void gemm_vh_kernel(
       tile_epilogue<EPI, MTW, NT>(acc, m0 + my_row0, n0 + wn * 64, (n0 + wn * 64) / 2, li, g, bias, residual, ldr, C, ldc, M, N, partial, nullptr);
   };
   using I0 = std::integral_constant<int, 0>;
-  using I8 = std::integral_constant<int, 8>;
-  using I9 = std::integral_constant<int, MTX>;
+  using IL = std::integral_constant<int, MTL>;
+  using IX = std::integral_constant<int, MTX>;
+  static_assert(2 * MTL >= NSLOT, "one DMA piece per row-tile step");
   if (!wave_has_rows) run(I0{});
-  else if (my_mt == MTX) run(I9{});
-  else run(I8{});
+  else if (my_mt == MTX) run(IX{});
+  else run(IL{});
   if (vb + (int)gridDim.x < nblk) __syncthreads();     // the next tile's DMA reuses the stages
   }
 }
@@ -1036,20 +1055,20 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, a.wscale, a.vq,
       raster_for(tiles_m));
 }
-// variable-height row tiles (gemm_vh_kernel): tiles_m = floor(F / 16) row tiles for F = ceil(M / 16) row fragments
-static bool vh_legal(const GemmArgs& a) {
-  const int F = (a.M + 15) >> 4, t = F >> 4;
-  return a.w_packed && !a.w_fp8 && (a.K % 64) == 0 && t >= 1 && F <= 18 * t && (a.N & 15) == 0;
+// variable-height row tiles (gemm_vh_kernel): tiles_m = floor(F / 16) row tiles for F = ceil(M / 16) row fragments (small class: F / 8)
+static bool vh_legal(const GemmArgs& a, bool small = false) {
+  const int F = (a.M + 15) >> 4, t = F >> (small ? 3 : 4);
+  return a.w_packed && !a.w_fp8 && (a.K % 64) == 0 && t >= 1 && F <= (small ? 9 : 18) * t && (a.N & 15) == 0;
 }
-template <int EPI>
+template <int EPI, int SMALL = 0>
 static void launch_vh(const GemmArgs& a, hipStream_t st) {
-  const int F = (a.M + 15) >> 4, tiles_m = F >> 4, tiles_n = (a.N + 255) / 256;
+  const int F = (a.M + 15) >> 4, tiles_m = F >> (SMALL ? 3 : 4), tiles_n = (a.N + 255) / 256;
   const int nkt = a.K / 64, S = (EPI == EPI_PARTIAL) ? a.nsplit : 1;
-  constexpr size_t lds = (size_t)2 * (288 * 8 + 2048) * 16 + 1024;      // two 69,632-B stages + the scratch
+  constexpr size_t lds = (size_t)(SMALL ? 3 : 2) * ((SMALL ? 144 : 288) * 8 + 2048) * 16 + 1024;      // 2 x 69,632 B / 3 x 51,200 B + the scratch
   static DeviceOnce attr_set;   // per instantiation
-  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_vh_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_vh_kernel<EPI, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   g_launch_counts[LC_GEMM_VH]++;
-  gemm_vh_kernel<EPI><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(512), lds, st>>>(
+  gemm_vh_kernel<EPI, SMALL><<<dim3(capped_grid((long)tiles_m * tiles_n), S), dim3(512), lds, st>>>(
       a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K, tiles_m, tiles_n, a.partial, (nkt + S - 1) / S, raster_for(tiles_m));
 }
 template <int BM, int EPI>
@@ -1071,7 +1090,8 @@ static void launch_big(const GemmArgs& a, hipStream_t st) {
   else if (g_gemm_sched) launch_big_s<BM, EPI, 1, false>(a, st);
   else launch_big_s<BM, EPI, 0, false>(a, st);
 }
-// 13: the 192-row tile wherever eligible (bf16 weights); 14: variable-height row tiles (gemm_vh_kernel) wherever legal, else as 3
+// 13: the 192-row tile wherever eligible (bf16 weights); 14: variable-height row tiles (gemm_vh_kernel) wherever legal, else as 3;
+// 15: the small variable-height class (8 / 9 fragments) for split-K slabs wherever legal, else as 4
 void set_gemm_variant(int v) {
   g_gemm_variant = v;
   g_gemm_sched = (v == 5 || v == 6) ? 0 : 1;
@@ -1087,6 +1107,13 @@ bool gemm_vit_qkv_eligible(int M, int E, int K) { return K > 0 && (K % 64) == 0 
 // kernels run one block per CU (256 slots), the 4-wave 64-row kernel two (512 slots).  Measured on MI355X (7B shapes):
 // 256x256 tiles ~1.05-1.1 PF, 128x256 ~0.9 PF, 64x128 ~0.55 PF when the grid fills the chip; with few blocks (qkv at
 // M = 386: 72 blocks of 128x256) the small tile wins.
+// small variable-height class: on unless LCC_GEMM_VH_SMALL=0; shapes = one block-row class of a streaming chunk (fragment count not a
+// multiple of 8, at most 448 rows) -- the engine asks gemm_tiled_num_splits with the same predicate, so split count and tile agree
+static bool vh_small_on() { static const int on = [] { const char* v = getenv("LCC_GEMM_VH_SMALL"); return v ? atoi(v) : 1; }(); return on != 0; }
+static bool vh_small_shape(int M, int K) {
+  const int F = (M + 15) >> 4, t = F >> 3;
+  return M > 64 && M <= 448 && (K % 64) == 0 && t >= 1 && F <= 9 * t && (F & 7) != 0;
+}
 static float tile_score(int M, int N, int S, int BM, int BN, int slots, float eff, bool ragged_skip) {
   const long tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN, blocks = tm * tn * S;
   const int half = BM / 2, mh = (M + half - 1) / half * half;   // the 8-wave kernel skips an all-padding half tile (~25 % cost)
@@ -1107,6 +1134,7 @@ static int big_tile_rows(const GemmArgs& a, int S) {
   if (g_gemm_variant == 3 || g_gemm_variant == 5) return 256;
   if (g_gemm_variant == 4 || g_gemm_variant == 6) return 128;
   if (g_gemm_variant == 13) return a.w_fp8 ? 256 : 192;
+  if (g_gemm_variant == 15) return (a.partial != nullptr && vh_small_shape(a.M, a.K) && vh_legal(a, true)) ? 144 : 128;
   if (g_gemm_variant != 2) return 0;
   const float s256 = tile_score(a.M, a.N, S, 256, 256, 256, 1.0f, true);
   static const int allow192 = [] { const char* v = getenv("LCC_GEMM_192"); return v ? atoi(v) : 1; }();     // A/B: 0 = round-3 tile choice
@@ -1119,6 +1147,13 @@ static int big_tile_rows(const GemmArgs& a, int S) {
     const long blocks = (long)t * ((a.N + 255) / 256) * S;
     const float svh = (float)a.M / (float)(t * maxf * 16) * (float)blocks / (float)((blocks + 255) / 256 * 256);
     if (svh > s256 && svh > s192 && svh > s128 && svh > s64) return 272;
+  }
+  // small class (returned as 144): split-K slabs of one streaming chunk's projections, where the 128-row tiles leave a nearly empty last row tile
+  if (vh_small_on() && a.partial != nullptr && vh_small_shape(a.M, a.K) && vh_legal(a, true)) {
+    const int F = (a.M + 15) >> 4, t = F >> 3, maxf = (F + t - 1) / t;
+    const long blocks = (long)t * ((a.N + 255) / 256) * S;
+    const float svs = 0.85f * (float)a.M / (float)(t * maxf * 16) * (float)blocks / (float)((blocks + 255) / 256 * 256);
+    if (svs > s256 && svs > s192 && svs > s128 && svs > s64) return 144;
   }
   if (s256 >= s192 && s256 >= s128 && s256 >= s64) return 256;
   if (s192 >= s128 && s192 >= s64) return 192;
@@ -1633,12 +1668,21 @@ int gemv_num_splits(int N, int K) {
 }
 
 // split-K factor for a tiled GEMM whose output grid alone cannot fill 256 CUs (e.g. M = 386, N = 3584: 196 tiles)
-int gemm_tiled_num_splits(int M, int N, int K) {
+int gemm_tiled_num_splits(int M, int N, int K, bool packed_bf16) {
   const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
   if (tiles >= 400 || M > 4096) return 1;
   int s = (int)((640 + tiles - 1) / tiles);
   s = std::min(s, std::max(1, ((K + 63) / 64) / 8));
-  return std::max(1, std::min(4, s));
+  s = std::max(1, std::min(4, s));
+  // small variable-height tiles (bf16 weights): floor(F / 8) row tiles x 256-column tiles -> as many splits as fill one round of the chip
+  // (7B chunk, M = 386: o / down 3 x 14 tiles x 6 = 252 blocks, q|k|v 3 x 18 x 4 = 216), never fewer than the 128-row rule gives
+  if (packed_bf16 && vh_small_on() && vh_small_shape(M, K) && (N & 15) == 0) {
+    const long vt = (long)(((M + 15) >> 4) >> 3) * ((N + 255) / 256);
+    int sv = (int)std::min<long>(6, 256 / std::max<long>(1, vt));
+    sv = std::min(sv, std::max(1, ((K + 63) / 64) / 8));
+    s = std::max(s, sv);
+  }
+  return s;
 }
 
 static int gemm_w8(const GemmArgs& a, hipStream_t st) {
@@ -1754,6 +1798,7 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) {
     if (a.epilogue != EPI_NONE || a.nsplit < 1 || a.nsplit > 8 || a.nsplit > (a.K + 63) / 64) return LCC_ERR_ARG;
     const int big = big_tile_rows(a, a.nsplit);
     if (big == 272) launch_vh<EPI_PARTIAL>(a, st);
+    else if (big == 144) launch_vh<EPI_PARTIAL, 1>(a, st);
     else if (big == 256) launch_big<256, EPI_PARTIAL>(a, st);
     else if (big == 192) launch_big<192, EPI_PARTIAL>(a, st);
     else if (big == 128) launch_big<128, EPI_PARTIAL>(a, st);

@@ -26,7 +26,7 @@ enum LaunchCounter {
   LC_LAST_PREFILL_NSPLIT = 11, // key splits of the most recent prefill attention launch
   LC_GEMM_TALL = 12,
   LC_ATTN_VIT32 = 13,          // attn_vit32_kernel (vision attention on 32x32x16 MFMAs)
-  LC_GEMM_VH = 14,             // gemm_vh_kernel (row tiles of 256 / 272 / 288 rows; round 5 -- the slot of the retired gemm_pp_kernel)
+  LC_GEMM_VH = 14,             // gemm_vh_kernel (row tiles of 256 / 272 / 288 rows, small class 128 / 144; round 5 -- the slot of the retired gemm_pp_kernel)
   LC_GEMM_VIT_QKV = 15,        // gemm_big_kernel with the EPI_VIT_QK / EPI_VIT_V epilogues (RoPE / V transpose fused into the q|k|v projection; one EPI_VIT_QKV launch per tower block when E % 128 == 0, else a q|k launch + a V launch)
   LC_COUNT = 16
 };
@@ -82,7 +82,7 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
 bool gemm_vit_qkv_eligible(int M, int E, int K);   // shapes the EPI_VIT_QK / EPI_VIT_V epilogues serve (8-wave kernel: K % 64 == 0; M > 64, M % 4 == 0, E % 32 == 0)
 int gemv_num_splits(int N, int K);
-int gemm_tiled_num_splits(int M, int N, int K);
+int gemm_tiled_num_splits(int M, int N, int K, bool packed_bf16 = false);      // packed_bf16: the small variable-height tiles may serve it (more splits)
 void set_gemv_variant(int v);
 bool gemm_routes_skinny(int M, int K, bool w_fp8);   // M rows x [N, K] weights take the weight-streaming GEMV kernels (the one predicate: gemm.hip and the engine)
 int set_skinny_rows(int rows);     // 16..64: largest M served by the weight-streaming GEMV kernels (returns the previous value)

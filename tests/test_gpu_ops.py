@@ -151,6 +151,44 @@ def test_gemm_variable_height_tiles_are_bit_identical_to_the_256_row_tiles(dev, 
     assert_bf16_close(got, exp, f"gemm_vh[{M}x{N}x{K},epi{epi}]", max_ulp=1.0, max_frac=5e-3, atol=atol)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(386, 3584, 18944, 6), (386, 4608, 3584, 4), (386, 3584, 3584, 6), (400, 3600, 1024, 2), (130, 512, 512, 2),
+                                     (272, 1024, 1024, 4), (144, 256, 4096, 8), (391, 1536, 8960, 5)])
+def test_gemm_small_variable_height_tiles_give_the_slabs_of_the_128_row_tiles(dev, M, N, K, S):
+    """gemm_vh_kernel, small class (round 5): split-K slabs on row tiles of 8 / 9 fragments (M = 386: 9 + 8 + 8 instead of four 128-row
+    tiles whose last holds 2 rows).  Same k ranges per split and the same accumulation order per element as gemm_big_kernel<128>: every fp32
+    slab is bit-identical to variant 4's; one tile of 9 (M = 130, 144), two tiles of 9 + 8 (M = 272), a ragged column tile (N = 3600),
+    uneven k-tile counts per split (56 / 6, 140 / 5), the 2B shapes (1536 x 8960); and the kernel really ran (launch counter)."""
+    from livecc_amd import ops
+    x, w = _rand((M, K), dev, 1.0, 1), _rand((N, K), dev, 0.05, 2)
+    wp = ops.pack_weight(w)
+    try:
+        ops.set_gemm_variant(4)
+        ref = ops.linear_partial(x, wp, S, packed_shape=(N, K))
+        ops.set_gemm_variant(15)
+        before = ops.launch_counts()["gemm_vh"]
+        got = ops.linear_partial(x, wp, S, packed_shape=(N, K))
+        assert ops.launch_counts()["gemm_vh"] == before + 1
+    finally:
+        ops.set_gemm_variant(ops.GEMM_DEFAULT_VARIANT)
+    assert torch.equal(got, ref), f"{int((got != ref).sum())} of {got.numel()} slab entries differ from the 128-row tiles"
+    full = got.sum(dim=0)
+    exp = x.float() @ w.float().t()
+    assert float((full - exp).abs().max()) <= 2e-5 * float(exp.abs().max()) * math.sqrt(K / 256) + 1e-4
+
+
+def test_gemm_auto_choice_takes_the_small_variable_height_tiles_for_one_chunk_with_six_splits(dev):
+    """The 7B down projection of one streaming chunk as the engine asks for it (M = 386, N = 3584, 6 slabs): the default tile choice is the
+    small variable-height class (3 x 14 x 6 = 252 blocks); with 4 slabs the 128-row tiles keep the call (224 blocks beat 168)."""
+    from livecc_amd import ops
+    x, w = _rand((386, 1024), dev, 1.0, 1), _rand((3584, 1024), dev, 0.05, 2)
+    wp = ops.pack_weight(w)
+    before = ops.launch_counts()["gemm_vh"]
+    ops.linear_partial(x, wp, 6, packed_shape=(3584, 1024))
+    assert ops.launch_counts()["gemm_vh"] == before + 1
+    ops.linear_partial(x, wp, 4, packed_shape=(3584, 1024))
+    assert ops.launch_counts()["gemm_vh"] == before + 1
+
+
 def test_gemm_auto_choice_picks_the_variable_height_tiles_for_eight_chunks(dev):
     """M = 3088 (8 x 386 rows), 7B gate/up: the default tile choice takes gemm_vh_kernel (12 x 148 blocks = 6.9 rounds instead of 13 x 148 =
     7.5 -> 8); the o / down shapes (14 column tiles) keep the 192-row tile."""

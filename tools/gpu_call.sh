@@ -254,5 +254,9 @@ r5o)         # round 5, call 15: a full-size (16.6 GB, sharded, HF 4.5x keys) sa
   timeout 900 python tools/full_size_loader_check.py --fp8 2>>$O/loader.err | tee -a $O/full_size_loader_check.jsonl; tail -n 3 $O/loader.err ;;
 r5p)         # round 5, call 16: soak of the live-paced server leg: N streams x 60 s of video (KV history to ~26k keys per stream), p99 per 10-s window
   timeout 400 python tools/r5_live_soak.py ${1:-48} ${2:-60} 2>$O/soak.err | tee -a $O/live2fps_soak.jsonl | cut -c1-900; tail -n 2 $O/soak.err ;;
+r5q)         # round 5, call 17: the small variable-height tile class (128 / 144-row tiles, 6 / 6 / 4 splits at M = 386): tests, micro-benchmark, 1-stream A/B
+  timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x --timeout 500 -k "small_variable or auto_choice or variable_height" > $O/ops_tests.log 2>&1; tail -n 4 $O/ops_tests.log
+  timeout 200 python tools/r5_bench_splitk.py 2>$O/splitk.err | tee $O/gemm_splitk_small_vh.jsonl | cut -c1-160; tail -n 2 $O/splitk.err
+  for V in 0 1 0 1; do ( LCC_GEMM_VH_SMALL=$V timeout 300 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_small$V.log 2>&1; echo "LCC_GEMM_VH_SMALL=$V: $(val $O/bench_small$V.log value) tok/s" | tee -a $O/bench_small_vh_ab.txt; done ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac
