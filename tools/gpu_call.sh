@@ -258,5 +258,10 @@ r5q)         # round 5, call 17: the small variable-height tile class (128 / 144
   timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x --timeout 500 -k "small_variable or auto_choice or variable_height" > $O/ops_tests.log 2>&1; tail -n 4 $O/ops_tests.log
   timeout 200 python tools/r5_bench_splitk.py 2>$O/splitk.err | tee $O/gemm_splitk_small_vh.jsonl | cut -c1-160; tail -n 2 $O/splitk.err
   for V in 0 1 0 1; do ( LCC_GEMM_VH_SMALL=$V timeout 300 $B --steps 2 --warmup 1 --share8 off ) > $O/bench_small$V.log 2>&1; echo "LCC_GEMM_VH_SMALL=$V: $(val $O/bench_small$V.log value) tok/s" | tee -a $O/bench_small_vh_ab.txt; done ;;
+r5r)         # round 5, call 18: MfmaUtil of the M = 386 split-K projections on the small variable-height class (one PMC pass, reduced by summarize_pmc.py)
+  mkdir -p $O/p; cd /tmp
+  timeout 150 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/p/pmc_gemm_MfmaUtil -o gemm -- python $R/tools/pmc_target.py --gemm > $O/pmc.log 2>&1
+  find $O/p -name '*kernel_trace.csv' -delete; cd $R
+  python tools/summarize_pmc.py $O/p 2>/dev/null | python -c "import sys, json; d = json.load(sys.stdin); print(json.dumps(d['gemm_counters_mean_per_dispatch'], indent=1))" | tee $O/mfma_util_small_vh.json; rm -rf $O/p ;;
 *) echo "recipes: golden pmc_l2 tests bench r5a..r5f (see the case statement)";;
 esac

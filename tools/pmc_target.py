@@ -20,17 +20,20 @@ if "--gemm" in sys.argv:
         x = torch.randn(M, H, device=dev).to(torch.bfloat16)
         for i in range(6):
             ops.linear(x, ws[i % 2], None, ops.EPI_SWIGLU, packed_shape=(2 * I, H))
-    # the other LLM prefill GEMMs of ONE streaming chunk (M = 386) as the engine launches them: split-K slabs on the 128 x 256 tiles --
-    # q/k/v (N = 4608, 3 splits), o_proj (N = K = 3584, 4 splits), down_proj (N = 3584, K = 18944, 4 splits)
+    # the other LLM prefill GEMMs of ONE streaming chunk (M = 386) as the engine launches them: split-K slabs -- until round 5's small
+    # variable-height class on the 128 x 256 tiles (q/k/v 3 splits, o / down 4), since then on 3 row tiles of 128 / 144 rows with
+    # q/k/v (N = 4608) 4 splits, o_proj (N = K = 3584) 6, down_proj (N = 3584, K = 18944) 6 (LCC_GEMM_VH_SMALL=0: the old counts)
+    small = os.environ.get("LCC_GEMM_VH_SMALL", "1") != "0"
+    sq, so = (4, 6) if small else (3, 4)
     x = torch.randn(386, H, device=dev).to(torch.bfloat16)
     xi = torch.randn(386, I, device=dev).to(torch.bfloat16)
     wq = ops.pack_weight((torch.randn(4608, H, device=dev) * 0.02).to(torch.bfloat16))
     wo = ops.pack_weight((torch.randn(H, H, device=dev) * 0.02).to(torch.bfloat16))
     wd = ops.pack_weight((torch.randn(H, I, device=dev) * 0.02).to(torch.bfloat16))
     for i in range(6):
-        ops.linear_partial(x, wq, 3, packed_shape=(4608, H))
-        ops.linear_partial(x, wo, 4, packed_shape=(H, H))
-        ops.linear_partial(xi, wd, 4, packed_shape=(H, I))
+        ops.linear_partial(x, wq, sq, packed_shape=(4608, H))
+        ops.linear_partial(x, wo, so, packed_shape=(H, H))
+        ops.linear_partial(xi, wd, so, packed_shape=(H, I))
     torch.cuda.synchronize()
     print("ok")
     sys.exit(0)

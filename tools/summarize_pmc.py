@@ -39,6 +39,11 @@ for f in glob.glob(os.path.join(out, "pmc_gemm_*", "**", "*counter_collection.cs
         # round 5: the gate/up GEMM at M = 3088 runs on the variable-height tiles (gemm_vh_kernel: 12 x 148 tiles of 256 / 272 rows)
         key = ("M386_gemm_tall_kernel" if "gemm_tall_kernel" in kn else "M3088_gemm_vh_kernel" if "gemm_vh_kernel" in kn else
                "M3088_gemm_big_kernel_256" if "<256" in kn else "M386_gemm_big_kernel_128")
+        if "gemm_vh_kernel<5, 1>" in kn:      # the small variable-height class (split-K slabs of one chunk): 54 tiles x 4 splits = q/k/v, 42 x 6 = o / down
+            grid = int(r.get("Grid_Size", 0)) // 512
+            dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+            key = "M386_qkv_splitk4_vh_small" if grid == 216 else ("M386_down_splitk6_vh_small" if dur > 35.0 else "M386_o_splitk6_vh_small")
+            gemm.setdefault(key, {}).setdefault("duration_us_under_pmc", []).append(dur)
         if "<128, 5" in kn:      # split-K slabs at M = 386: grid (tiles, splits) x 512 threads tells q/k/v (72 x 3) from o / down (56 x 4);
             grid = int(r.get("Grid_Size", 0)) // 512      # o and down share a grid: told apart by the duration of the dispatch
             dur = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
