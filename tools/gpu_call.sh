@@ -217,7 +217,7 @@ tests)       # the whole GPU tier, serially, as the driver runs it
   timeout ${1:-1500} python -m pytest tests/ -x -q -m gpu > $O/tests.log 2>&1; tail -n 25 $O/tests.log ;;
 bench)       # the driver's default line
   timeout 1700 python bench.py "$@" > $O/bench.log 2>$O/bench.err; tail -n 3 $O/bench.log | cut -c1-3000; tail -n 5 $O/bench.err ;;
-r5f)         # round 5, call 6: the k-tile barrier 3 steps before the end of the tile (LCC_GEMM_EARLY_BARRIER=1): bit-identity (3 runs), A/B
+r5f)         # round 5, call 6 (RECORD ONLY: the variant measured null and was removed, the switch no longer exists): the k-tile barrier 3 steps before the end of the tile (LCC_GEMM_EARLY_BARRIER=1): bit-identity (3 runs), A/B
   for E in 0 1 1 1; do LCC_GEMM_EARLY_BARRIER=$E timeout 200 python tools/gemm_checksum.py "$@" > $O/sum_e$E.txt 2>$O/sum_e$E.err; cmp $O/sum_e0.txt $O/sum_e$E.txt && echo "early barrier $E: CHECKSUMS IDENTICAL" || { echo "early barrier $E DIFFERS"; paste $O/sum_e0.txt $O/sum_e$E.txt; tail -n 3 $O/sum_e$E.err; }; done
   for E in 0 1 0 1; do LCC_GEMM_EARLY_BARRIER=$E timeout 300 python tools/r5_bench_gemm.py early$E gate_up_M3088,gate_up_M1131,down_M3088,vit_fc1_P11648,vit_fc2_P11648,vit_qkv_P11648 2>/dev/null | grep '^{' | tee -a $O/gemm_early_barrier_ab.jsonl | cut -c1-200; done ;;
 r5g)         # round 5, call 7: what bounds the 8-wave GEMM now?  no-DMA / no-MFMA diagnostics of gemm_big_kernel<256> + the row-stride probe
@@ -226,7 +226,7 @@ r5g)         # round 5, call 7: what bounds the 8-wave GEMM now?  no-DMA / no-MF
   timeout 300 python tools/r5_lda_probe.py "$@" 2>$O/lda.err | tee -a $O/lda_probe.jsonl; tail -n 3 $O/lda.err ;;
 r5h)         # round 5, call 8: the row-stride probe again, A/B/A/B order: bash tools/gpu_call.sh r5h <pads> <shapes>
   timeout 600 python tools/r5_lda_probe.py "$@" 2>$O/lda.err | tee -a $O/lda_probe_abab.jsonl; tail -n 2 $O/lda.err ;;
-r5i)         # round 5, call 9: the 4-stage half-tile ring (gemm_big4_kernel) on the asm LDS-DMA vs gemm_big_kernel<256>: bit-identity, sustained A/B
+r5i)         # round 5, call 9 (RECORD ONLY: 5-7 % slower, kernel removed again, LCC_GEMM_RING no longer exists): the 4-stage half-tile ring (gemm_big4_kernel) on the asm LDS-DMA vs gemm_big_kernel<256>: bit-identity, sustained A/B
   for RING in 2 4 4; do LCC_GEMM_VH=0 LCC_GEMM_RING=$RING timeout 200 python tools/gemm_checksum.py > $O/sum_ring$RING.txt 2>$O/sum_ring$RING.err; cmp $O/sum_ring2.txt $O/sum_ring$RING.txt && echo "ring $RING: CHECKSUMS IDENTICAL" || { echo "ring $RING DIFFERS"; paste $O/sum_ring2.txt $O/sum_ring$RING.txt; tail -n 3 $O/sum_ring$RING.err; }; done
   for RING in 2 4 2 4; do LCC_GEMM_VH=0 LCC_GEMM_RING=$RING timeout 120 python tools/bench_gemm_diag.py 2>/dev/null | grep '^{' | sed "s/^/ring$RING /" | tee -a $O/gemm_ring4_asm_dma.txt; done ;;
 r5j)         # round 5, call 10: random vs zero-filled operands through the same GEMM launches (is the kernel clock / power bound?)
@@ -237,7 +237,7 @@ r5k)         # round 5, call 11: shader clock + socket power under the GEMM on r
 r5l)         # round 5, call 12: effective clock of the GEMM dispatches on random vs zero-filled operands: GRBM_GUI_ACTIVE cycles / duration
   cd /tmp; timeout 500 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_clock -o clk -- python $R/tools/r5_power_probe.py > $O/power_under_pmc.jsonl 2>$O/pmc.err
   cd $R; python tools/r5_clock_from_pmc.py $O/pmc_clock | tee $O/gemm_effective_clock.jsonl; tail -n 2 $O/pmc.err; rm -rf $O/pmc_clock ;;
-r5m)         # round 5, call 13: cache policy of the LDS-DMA instruction (builds livecc_amd/_C_{nt,sc0,sc1}: -DLCC_GLDS_POLICY): bit-identity + A/B
+r5m)         # round 5, call 13: cache policy of the LDS-DMA instruction (needs the extra builds livecc_amd/_C_{nt,sc0,sc1}: make OUT=../_C_nt CXXFLAGS="... -DLCC_GLDS_POLICY='\" nt\"'"; skipped when absent): bit-identity + A/B
   for P in "" _nt _sc0 _sc1; do
     L=$R/livecc_amd/_C$P/liblivecc_amd.so; [ -f $L ] || continue
     LCC_LIB_PATH=$L timeout 200 python tools/gemm_checksum.py > $O/sum$P.txt 2>$O/sum$P.err; cmp $O/sum.txt $O/sum$P.txt > /dev/null && echo "policy[$P]: CHECKSUMS IDENTICAL" || echo "policy[$P] DIFFERS"
