@@ -69,6 +69,12 @@ int lcc_debug_set_gemv_variant(int variant);
  * of one streaming chunk (M = 386: 3 row tiles instead of 4, 6 / 6 / 4 splits; LCC_GEMM_VH_SMALL=0 restores the 128-row tiles and their
  * 4 / 4 / 3 splits).  Every tile shape produces the same bits for the same split count. */
 int lcc_debug_set_gemm_variant(int variant);
+/* Host logic only (no launch; works without a GPU): which kernel family serves a packed-weight GEMM of this shape under the current
+ * variant -- *tile_rows = 16 weight-streaming GEMV, 448 tall, 272 / 144 variable-height tiles (big / small class), 256 / 192 / 128 the
+ * 8-wave tile of that height, 64 a 4-wave tile kernel; nsplit > 0 asks for the split-K slab form -- and *engine_splits = the split count
+ * the engine's prefill asks for at this shape (what csrc/engine_llm.hip passes as nsplit for the o / down / q|k|v projections).
+ * w_fp8 != 0: *tile_rows = 0 (fp8 weights route inside their own entry point), *engine_splits as for fp8 weights. */
+int lcc_debug_gemm_plan(int M, int N, int K, int epilogue, int nsplit, int w_fp8, int32_t* tile_rows, int32_t* engine_splits);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
  * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs
  * (csrc/attn32.hip; applies to calls with tile_rows = 32, the engine then always builds 32-row tiles) */

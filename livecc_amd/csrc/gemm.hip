@@ -1209,6 +1209,20 @@ static void launch_tiled_bm(const GemmArgs& a, hipStream_t st) {
   else launch_tiled<64, EPI>(a, st);
 }
 
+// Which kernel family serves a packed-weight GEMM of this shape under the current variant (host logic only: no launch, no GPU needed):
+// 16 = weight-streaming GEMV, 448 = tall, 272 / 144 = variable-height tiles (big / small class), 256 / 192 / 128 = the 8-wave tile of
+// that height, 64 = a 4-wave tile kernel.  `nsplit` > 0: the split-K slab form with that many splits (as the engine asks: gemm_tiled_num_splits).
+int gemm_plan(int M, int N, int K, int epilogue, int nsplit, bool w_fp8) {
+  GemmArgs a; a.M = M; a.N = N; a.K = K; a.w_packed = 1; a.w_fp8 = w_fp8 ? 1 : 0; a.epilogue = epilogue; a.nsplit = nsplit;
+  static float dummy;
+  if (nsplit > 0) a.partial = &dummy;      // never dereferenced here: only "is this the slab form?"
+  const bool skinny = gemm_routes_skinny(M, K, w_fp8) && epilogue != EPI_QUICK_GELU && epilogue != EPI_GELU_ERF && epilogue != EPI_RESIDUAL;
+  if (skinny) return 16;
+  if (nsplit <= 0 && !w_fp8 && tall_wanted(a)) return 448;
+  const int big = big_tile_rows(a, nsplit > 0 ? nsplit : 1);
+  return big != 0 ? big : 64;
+}
+
 // ------------------------------------------------------------------------------------------------
 // skinny GEMV-like kernel (M <= 16; 17..64 rows with MG = 2..4 activation fragments per weight fragment): HBM-bound weight streaming
 // ------------------------------------------------------------------------------------------------

@@ -82,6 +82,7 @@ struct GemmArgs {
 int gemm_bf16(const GemmArgs& a, hipStream_t st);
 bool gemm_vit_qkv_eligible(int M, int E, int K);   // shapes the EPI_VIT_QK / EPI_VIT_V epilogues serve (8-wave kernel: K % 64 == 0; M > 64, M % 4 == 0, E % 32 == 0)
 int gemv_num_splits(int N, int K);
+int gemm_plan(int M, int N, int K, int epilogue, int nsplit, bool w_fp8);     // host logic: which kernel family would serve this GEMM
 int gemm_tiled_num_splits(int M, int N, int K, bool packed_bf16 = false);      // packed_bf16: the small variable-height tiles may serve it (more splits)
 void set_gemv_variant(int v);
 bool gemm_routes_skinny(int M, int K, bool w_fp8);   // M rows x [N, K] weights take the weight-streaming GEMV kernels (the one predicate: gemm.hip and the engine)

@@ -23,6 +23,12 @@ static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_hea
 extern "C" int lcc_debug_set_gemv_variant(int variant) { set_gemv_variant(variant); return 0; }
 extern "C" int lcc_debug_set_gemm_variant(int variant) { set_gemm_variant(variant); return 0; }
 extern "C" int lcc_debug_set_attn_variant(int variant) { set_attn_variant(variant); return 0; }
+extern "C" int lcc_debug_gemm_plan(int M, int N, int K, int epilogue, int nsplit, int w_fp8, int32_t* tile_rows, int32_t* engine_splits) {
+  if (M <= 0 || N <= 0 || K <= 0 || !tile_rows || !engine_splits) return fail(LCC_ERR_ARG, "lcc_debug_gemm_plan: invalid arguments");
+  *engine_splits = gemm_tiled_num_splits(M, N, K, w_fp8 == 0);
+  *tile_rows = w_fp8 ? 0 : gemm_plan(M, N, K, epilogue, nsplit, false);      // fp8 weights route inside gemm_w8 (not modelled here)
+  return 0;
+}
 extern "C" int lcc_debug_set_fused_tails(int on);
 extern "C" int lcc_gemm_bf16(const void* A, int lda, const void* W, int ldw, int w_layout, const void* bias, const void* residual,
                              int ldr, void* C, int ldc, int M, int N, int K, int epilogue, float* partial, int nsplit, void* stream) {

@@ -112,6 +112,16 @@ LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "a
                    "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_vh", "gemm_vit_qkv")
 
 
+def gemm_plan(M: int, N: int, K: int, epilogue: int = EPI_NONE, nsplit: int = 0, w_fp8: bool = False) -> Tuple[int, int]:
+    """(tile_rows, engine_splits) of lcc_debug_gemm_plan: the kernel family that serves this packed-weight GEMM and the split count the
+    engine's prefill asks for at this shape.  Host logic only: needs the library, not a GPU."""
+    import numpy as np
+    out = np.zeros(2, dtype=np.int32)
+    _lib.check(_lib.load().lcc_debug_gemm_plan(int(M), int(N), int(K), int(epilogue), int(nsplit), 1 if w_fp8 else 0, out[0:].ctypes.data,
+                                               out[1:].ctypes.data), "lcc_debug_gemm_plan")
+    return int(out[0]), int(out[1])
+
+
 def launch_counts(reset: bool = False) -> dict:
     """Host-side launch counters of the library (which kernel served the calls since the last reset): lcc_debug_launch_counts."""
     import numpy as np
