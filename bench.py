@@ -292,15 +292,30 @@ def configs2_share(cfg, make_model, dev, args, protocol, streams=8, steps=2, ran
     streams, weights broadcast once over RCCL (`bcast`: seconds per rank + the xGMI bound), no collective in prefill / decode (ref
     evaluation/livesports3kcc/distributed_generate_livecc.py:46-50, 105-122: N processes, strided shards, nothing shared)."""
     n_tok_turn = (args.height // 28) * (args.width // 28)
-    model = make_model(streams)
-    frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + rank * streams + i)).to(dev) for i in range(streams)]
-    seeds = [1234 + rank * streams + i for i in range(streams)]
     sync = (lambda: torch.cuda.synchronize(dev)) if torch.device(dev).type == "cuda" else (lambda: None)
     allmax = (lambda v: D.max_over_ranks(v, dev)) if D is not None else (lambda v: v)
     allsum = (lambda v: D.sum_over_ranks(v, dev)) if D is not None else (lambda v: v)
     gather = (lambda v: D.gather_floats(v, dev)) if D is not None else (lambda v: [float(v)])
     barrier = (lambda: D.barrier(dev)) if D is not None else (lambda: None)
-    replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, True)          # warm-up
+    # Everything that can fail on ONE rank only (building the 8-stream model: HBM, its first replay) runs before the first collective, and
+    # the ranks then agree on a success flag: if any rank failed, EVERY rank leaves with an error block instead of the healthy ranks blocking
+    # in the next barrier for ever (ADVICE r5).
+    err, model, frames, seeds = None, None, None, None
+    # stream s of the 8 x world streams runs on rank s % world (ref distributed_generate_livecc.py:49-50: idxs[i::N]; distributed.shard_streams)
+    from livecc_amd.distributed import shard_streams
+    my_ids = shard_streams(range(streams * world), rank, world)
+    assert len(my_ids) == streams
+    try:
+        model = make_model(streams)
+        frames = [torch.from_numpy(protocol.synth_frames(args.frames, args.height, args.width, seed=1234 + sid)).to(dev) for sid in my_ids]
+        seeds = [1234 + sid for sid in my_ids]
+        replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, True)          # warm-up
+        sync()
+    except Exception as e:          # noqa: BLE001
+        err = repr(e)
+    n_bad = allsum(1.0 if err else 0.0)
+    if n_bad > 0:
+        return dict(error=err or f"{int(n_bad)} other rank(s) failed to build / warm up their share; skipped on every rank", ranks_failed=int(n_bad))
     if model.engine is not None:
         model.engine.profile(True, 16384)
     barrier()
@@ -337,6 +352,7 @@ def configs2_share(cfg, make_model, dev, args, protocol, streams=8, steps=2, ran
     tf = flops / dt1 / 1e12
     total_toks, total_fr = allsum(float(toks)), allsum(float(nfr))
     per_rank = gather(toks / my_dt)
+    ids_sum_per_rank = [int(round(x)) for x in gather(float(sum(my_ids)))]
     per_stream_min = min(per_rank) / streams
     del model, frames
     if torch.device(dev).type == "cuda":
@@ -350,13 +366,16 @@ def configs2_share(cfg, make_model, dev, args, protocol, streams=8, steps=2, ran
         streams=n_all, streams_per_gpu=streams, n_gpus=world, steps=steps, value=round(total_toks / dt, 2), unit="tokens/s",
         tokens_per_s_per_stream=round(per_stream_min, 2), tokens_per_s_per_stream_is="minimum over ranks",
         tokens_per_s_per_rank=[round(x, 2) for x in per_rank],
+        stream_to_rank="stream s -> rank s % n_gpus (strided shards, as the reference's idxs[i::N])", stream_ids_rank0=list(my_ids),
+        stream_id_sum_per_rank=ids_sum_per_rank,
         frames_per_s=round(total_fr / dt, 2), ms_per_replay=round(dt / steps * 1e3, 1),
         north_star_target_tokens_per_s_per_stream=30.0, meets_target=bool(per_stream_min >= 30.0),
         roofline=dict(bound="mfma", kernel=f"vision tower + LLM prefill of every turn (every GEMM / attention launch), {streams} streams batched per GPU; replay "
                                            "stopped after each turn's first token, no prefetch overlap",
                       achieved=round(tf, 1), peak=2500.0 * world, unit="TFLOP/s", frac=round(tf / (2500.0 * world), 4), traffic=None,
                       algorithmic_flops_per_replay=flops, vit_flops_per_stream=fl["vit_flops"], llm_prefill_flops_per_stream=fl["llm_prefill_flops"],
-                      prefill_rows_per_stream=fl["prefill_rows"], seconds_per_replay=round(dt1, 4)),
+                      prefill_rows_per_stream=fl["prefill_rows"], seconds_per_replay=round(dt1, 4),
+                      llm_gemm_mfma_util=llm_gemm_mfma_util_if_current(os.path.join(ROOT, "profiles", "roofline_traffic.json"))),
         decode_step=step_roof)
     if world == 1:
         out["meets_target_on_this_gpu"] = out["meets_target"]
@@ -668,6 +687,24 @@ def pmc_traffic_if_current(path):
     return d.get("gemv_gate_up_hbm_bytes_per_launch")
 
 
+def llm_gemm_mfma_util_if_current(path):
+    """T2 evidence: MfmaUtil of all four LLM GEMMs at M = 3088 / 386 + the FLOP-weighted figure per layer, from the committed
+    rocprofv3 PMC pass (tools/r6_pmc_llm_gemms.py -> profiles/roofline_traffic.json) -- or None when csrc/gemm.hip has changed since."""
+    import hashlib
+    try:
+        blk = json.load(open(path)).get("llm_gemm_mfma_util")
+        if not blk:
+            return None
+        with open(os.path.join(ROOT, blk["gemm_source"]), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest()[:16] != blk["gemm_source_sha16"]:
+                return None
+        return dict(per_gemm={k: dict(mfma_util_pct=v["mfma_util_pct"], duration_us_under_pmc=v["duration_us_under_pmc"], kernel=v["kernel"], splits=v["splits"])
+                              for k, v in blk["per_gemm"].items()},
+                    flop_weighted=blk["per_layer"], source="profiles/roofline_traffic.json (rocprofv3 --pmc MfmaUtil; stale-source check passed)")
+    except Exception:
+        return None
+
+
 def parity_report(native_tokens, native_logits, ref, ref32=None):
     """ref / ref32: npz of oracle/cpu_baseline.py (`logits` [turns, N, V], `own_argmax` [turns, N]).  Only complete turns count."""
     lg, own = ref["logits"], ref["own_argmax"]
@@ -842,6 +879,18 @@ def main():
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     if model.engine is not None:
         model.engine.profile(False)
+    # the same replay WITHOUT the next turn's vision tower prefetched under this turn's decode steps (what a live 2-fps stream gets): reported
+    # beside `value`, same barrier + max-over-ranks clock, one pass
+    value_no_prefetch = None
+    if pf and not oneshot:
+        D.barrier(dev)
+        sync()
+        t_np = time.perf_counter()
+        a_np, _ = replay(model, cfg, frames, seeds, args.max_new_tokens, protocol, torch, False)
+        sync()
+        D.barrier(dev)
+        dt_np = D.max_over_ranks(time.perf_counter() - t_np, dev)
+        value_no_prefetch = D.sum_over_ranks(float(a_np), dev) / dt_np
     total_tokens = D.sum_over_ranks(float(toks), dev)
     total_frames = D.sum_over_ranks(float(nfr), dev)
     per_rank = D.gather_floats(toks / my_dt, dev)
@@ -875,6 +924,8 @@ def main():
             share = configs2_share(cfg, make_model, dev, args, protocol, rank=rank, world=world, D=D if world > 1 else None, bcast=bc)
         except Exception as e:       # never takes the main line down (every rank fails or none: the collectives inside are symmetric)
             share = dict(error=repr(e))
+    if world > 1:
+        D.shutdown(dev)          # all collectives are done: leave together (rank 0 goes on alone with the report)
     if rank != 0:
         return
     I, H = cfg.intermediate_size, cfg.hidden_size
@@ -1018,11 +1069,15 @@ def main():
         "metric": f"commentary tokens/s (all streams) + frames/s ingested, {'LiveCC-7B' if cfg.name == 'livecc-7b' else cfg.name} streaming", "value": round(total_tokens / dt, 3),
         "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value_no_prefetch": round(value_no_prefetch, 3) if value_no_prefetch is not None else None,
         "dtype": "bf16 (LLM Linear weights stored as fp8 e4m3 + fp32 row scales and expanded to bf16 in registers: every MFMA instruction is a bf16 one, "
                  "activations are never quantised)" if fp8 else "bf16",
         "data": "standin (launcher self-test, no GPU work)" if args.standin else "synthetic frames + synthetic prompt ids, seeded synthetic weights of the real architecture",
         "config": {"workload": f"{cfg.name} {spg} stream(s) per GPU, 2 fps, {args.frames} frames {args.height}x{args.width}, "
-                               f"{args.max_new_tokens} tokens/{'call' if oneshot else 'turn'}, greedy, repetition_penalty 1.05" + tag,
+                               f"{args.max_new_tokens} tokens/{'call' if oneshot else 'turn'}, greedy, repetition_penalty 1.05" + tag +
+                               (", weights stored as fp8 e4m3 + fp32 row scales and EXPANDED TO bf16 IN REGISTERS: every MFMA is a bf16 one (not an fp8-MFMA path)" if fp8 else "") +
+                               (", M-RoPE text offset after the vision block: transformers-4.5x rule (`hf4`, the product default) -- restated from memory, UNPINNED: no 4.5x "
+                                "wheel exists offline to execute it against" if (oneshot and getattr(model, "text_offset_rule", "") == "hf4") else ""),
                    "streams": n_streams, "streams_per_gpu": spg, "parallelism": f"dp{world} (streams sharded, weights broadcast)",
                    "mfma": "bf16 x bf16 -> fp32" + (" (fp8 weights expanded in registers; no fp8 MFMA instruction is issued: on gfx950 only the MX block-scaled "
                                                     "forms run faster than bf16 and they need activation scales the reference arithmetic does not have)" if fp8 else "")},

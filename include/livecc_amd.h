@@ -254,7 +254,8 @@ int lcc_embed_gather_bf16(const int32_t* ids, const int32_t* indirect, const int
 int lcc_seen_set(uint32_t* seen, int words_per_stream, const int32_t* ids, const int32_t* slot_of_id, int n, void* stream);
 /* RepetitionPenalty -> ThresholdLogitsProcessor -> argmax  (HF:generation/logits_process.py, ref:demo/infer.py:10-23).
  * eos_token / eos_token2: the (up to two) EOS ids of generation_config.json (<|im_end|>, <|endoftext|>; -1 = unused): both are
- * masked while suppress_eos (MinNewTokensLength) and either one sets the slot's done flag. */
+ * masked while suppress_eos bit 0 is set (MinNewTokensLength) and either one sets the slot's done flag -- unless suppress_eos bit 1 is
+ * set (the engine's teacher forcing: the forced stream decides where a slot ends; scores stay HF's, EOS unmasked). */
 int lcc_sample_greedy(const void* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                       const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
                       int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,

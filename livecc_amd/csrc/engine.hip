@@ -26,6 +26,13 @@ int lcc_check_launch(const char* what) {
   return 0;
 }
 
+std::atomic<int> g_calls_in_flight{0};
+int lcc_knob_guard(const char* name) {
+  const int n = g_calls_in_flight.load(std::memory_order_acquire);
+  if (n > 0) return lcc_fail(LCC_ERR_STATE, "%s refused: %d model-level call(s) in flight (the knob is process-global launch-routing state)", name, n);
+  return 0;
+}
+
 extern "C" const char* lcc_last_error(void) { return g_err; }
 extern "C" const char* lcc_version(void) { return "livecc_amd 0.1.0 (gfx950)"; }
 extern "C" int lcc_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
@@ -296,6 +303,7 @@ int meta_commit(MetaWriter* mw, hipStream_t st) {
 extern "C" int lcc_slot_reset(lcc_engine* e, int slot, void* stream) {
   if (!e || slot < 0 || slot >= e->lim.max_slots) return fail(LCC_ERR_ARG, "bad slot");
   if (!e->state) return fail(LCC_ERR_STATE, "buffers not bound");
+  std::lock_guard<std::mutex> lk(e->mu_llm);
   hipStream_t st = (hipStream_t)stream;
   e->h_kv_len[slot] = 0; e->h_pos[slot] = 0;
   HIP_TRY(hipMemsetAsync(e->d_kv_len + slot, 0, 4, st));
@@ -309,6 +317,7 @@ extern "C" int lcc_slot_reset(lcc_engine* e, int slot, void* stream) {
 extern "C" int lcc_slot_set_length(lcc_engine* e, int slot, int kv_len, int next_pos, void* stream) {
   if (!e || slot < 0 || slot >= e->lim.max_slots) return fail(LCC_ERR_ARG, "bad slot");
   if (kv_len < 0 || kv_len > e->lim.max_kv_len) return fail(LCC_ERR_STATE, "kv_len %d out of range", kv_len);
+  std::lock_guard<std::mutex> lk(e->mu_llm);
   hipStream_t st = (hipStream_t)stream;
   MetaWriter mw; LCC_TRY(meta_begin(e, &mw));
   int32_t v[2] = {kv_len, next_pos}; int32_t* d = nullptr;
@@ -327,6 +336,7 @@ extern "C" int lcc_slot_get_length(const lcc_engine* e, int slot, int* kv_len, i
 }
 extern "C" int lcc_slot_read_tokens(lcc_engine* e, int slot, int32_t* out, int max_n, int* n_generated, void* stream) {
   if (!e || slot < 0 || slot >= e->lim.max_slots || !out || max_n < 0) return fail(LCC_ERR_ARG, "bad args");
+  std::lock_guard<std::mutex> lk(e->mu_llm);
   hipStream_t st = (hipStream_t)stream;
   int32_t v[3];
   unsigned chain_err = 0;

@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -125,9 +127,27 @@ struct lcc_engine {
   std::vector<int> h_kv_len, h_pos;
   std::vector<void*> h_kv_base;
 
+  // host-side serialisation of the model-level calls (round 6): lcc_llm_prefill / lcc_llm_decode / the slot calls share the LLM workspace,
+  // the meta ring and the host mirrors (mu_llm); lcc_vit_encode has its own workspace + ring (mu_vit) and may run beside them on a second
+  // stream.  The Python surface additionally holds ONE lock per model across a whole generate (modeling.py); these make the C-ABI itself
+  // safe for callers that do not.
+  std::mutex mu_llm, mu_vit;
+
   size_t llm_ws_bytes() const;
   size_t vit_ws_bytes() const;
 };
+
+// Model-level calls in flight on ANY engine of this process (host threads inside lcc_vit_encode / lcc_llm_prefill / lcc_llm_decode).  The
+// process-global routing knobs (lcc_debug_set_*) are read by those calls while they enqueue: changing one under a running call would mix
+// two kernel families inside one forward pass, so the setters refuse with LCC_ERR_STATE while this is non-zero (engine.hip).
+extern std::atomic<int> g_calls_in_flight;
+struct CallScope {
+  CallScope() { g_calls_in_flight.fetch_add(1, std::memory_order_acq_rel); }
+  ~CallScope() { g_calls_in_flight.fetch_sub(1, std::memory_order_acq_rel); }
+  CallScope(const CallScope&) = delete;
+  CallScope& operator=(const CallScope&) = delete;
+};
+int lcc_knob_guard(const char* name);     // 0, or LCC_ERR_STATE (with message) while a model-level call is in flight
 
 // shared between the translation units
 int lcc_ensure_ready(lcc_engine* e);      // buffers bound + every weight resolved

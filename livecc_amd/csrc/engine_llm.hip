@@ -263,7 +263,9 @@ int head_and_sample(lcc_engine* e, const LlmBuffers& b, const bf16_t* xn_rows, i
   // teacher forcing: the forced stream decides where a slot ends, so the model's own pick must not set `done` (a model EOS at
   // a step where the forced stream goes on froze the slot and later forced tokens overwrote its last history column)
   const bool forcing = e->forced != nullptr && B == e->forced_B && step_index < e->forced_steps;
-  const int sup_eos = forcing ? 1 : (sp ? sp->suppress_eos : 0);
+  // bit 0 masks the EOS scores (the caller's min_new_tokens), bit 1 only keeps a picked EOS from setting `done` (sampler.hip): under forcing the
+  // processed scores keep the oracle's definition (EOS unmasked unless the caller asked)
+  const int sup_eos = ((sp && sp->suppress_eos) ? 1 : 0) | (forcing ? 2 : 0);
   if (sp && sp->do_sample && sp->top_k != 1) {
     LCC_TRY(sample_topk_topp(logits, V, B, V, e->d_seen, e->words, d_slots, pen <= 0.f ? 1.0f : pen, thr_tok, use_thr, thr, sp->eos_token,
                              eos2, sup_eos, e->d_done, e->d_cur_tok, e->d_history, e->lim.max_history, e->d_hist_col,
@@ -290,6 +292,8 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
                                const int32_t* vit_index, const void* vit_embeds, const int32_t* pos3, const lcc_sampling* sp,
                                void* stream) {
   LCC_TRY(ensure_ready(e));
+  CallScope in_flight;
+  std::lock_guard<std::mutex> lk(e->mu_llm);
   if (n_streams <= 0 || !slots || !n_new || !ids || !pos3) return fail(LCC_ERR_ARG, "null argument");
   if (n_streams > e->lim.max_slots) return fail(LCC_ERR_STATE, "too many streams");
   hipStream_t st = (hipStream_t)stream;
@@ -421,6 +425,8 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
 extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots, int n_steps, int first_step_index,
                               const lcc_sampling* sp, void* stream) {
   LCC_TRY(ensure_ready(e));
+  CallScope in_flight;
+  std::lock_guard<std::mutex> lk(e->mu_llm);
   if (n_streams <= 0 || !slots || n_steps < 0) return fail(LCC_ERR_ARG, "bad argument");
   // <= 16 streams: one activation fragment per weight fragment of the weight-streaming GEMVs.  17..64 (bf16 weights): the same kernels with
   // 2-4 activation fragments per weight fragment (gemv_skinny_kernel<..., MG>, round 4); fp8 weights above 16 rows: the 64-row GEMM tiles
@@ -509,11 +515,13 @@ extern "C" int lcc_debug_set_forced_tokens(lcc_engine* e, const int32_t* dev_tok
   e->forced = dev_tokens; e->forced_steps = dev_tokens ? n_steps : 0; e->forced_B = dev_tokens ? n_streams : 0;
   return 0;
 }
-extern "C" int lcc_debug_set_fused_tails(int on) { g_fuse_tails = on ? 1 : 0; return 0; }
-extern "C" int lcc_debug_set_decode_chain(int on) { g_decode_chain = on ? 1 : 0; return 0; }
-extern "C" int lcc_debug_set_resid_waves(int mode) { return set_resid_waves(mode); }
-extern "C" int lcc_debug_set_skinny_rows(int rows) { return set_skinny_rows(rows); }
+// process-global knobs: refused (LCC_ERR_STATE, negative for the setters that return the previous value) while a model-level call is in flight
+extern "C" int lcc_debug_set_fused_tails(int on) { if (int kg__ = lcc_knob_guard("lcc_debug_set_fused_tails")) return kg__; g_fuse_tails = on ? 1 : 0; return 0; }
+extern "C" int lcc_debug_set_decode_chain(int on) { if (int kg__ = lcc_knob_guard("lcc_debug_set_decode_chain")) return kg__; g_decode_chain = on ? 1 : 0; return 0; }
+extern "C" int lcc_debug_set_resid_waves(int mode) { if (lcc_knob_guard("lcc_debug_set_resid_waves")) return -1; return set_resid_waves(mode); }
+extern "C" int lcc_debug_set_skinny_rows(int rows) { if (lcc_knob_guard("lcc_debug_set_skinny_rows")) return -1; return set_skinny_rows(rows); }
 extern "C" int lcc_debug_set_decode_path(int path) {
+  if (int kg__ = lcc_knob_guard("lcc_debug_set_decode_path")) return kg__;
   if (path != 0 && path != 1) return fail(LCC_ERR_ARG, "decode path must be 0 (round-1 launch sequence) or 1 (v2)");
   g_decode_path = path;
   return 0;
@@ -521,6 +529,7 @@ extern "C" int lcc_debug_set_decode_path(int path) {
 // bit 0: engine uses the fused decode attention for batches of >= 16 (stream, KV head) pairs (default); bit 2: for every batch;
 // bit 1: its key splits are merged in-launch (ticket) instead of by a combine launch
 extern "C" int lcc_debug_set_fused_attn(int mode) {
+  if (int kg__ = lcc_knob_guard("lcc_debug_set_fused_attn")) return kg__;
   g_fused_attn = (mode & 4) ? 2 : (mode & 1);
   set_attn_fused_tail((mode & 2) ? 0 : 1);
   return 0;

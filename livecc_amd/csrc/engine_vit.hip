@@ -7,7 +7,10 @@
 // ViT
 // ------------------------------------------------------------------------------------------------
 static int g_vit_fused_qkv = [] { const char* v = getenv("LCC_VIT_FUSED_QKV"); return v ? atoi(v) : 1; }();
-extern "C" int lcc_debug_set_vit_fused_qkv(int on) { const int old = g_vit_fused_qkv; g_vit_fused_qkv = on ? 1 : 0; return old; }
+extern "C" int lcc_debug_set_vit_fused_qkv(int on) {      // returns the previous value; -1 = refused (a model-level call is in flight)
+  if (lcc_knob_guard("lcc_debug_set_vit_fused_qkv")) return -1;
+  const int old = g_vit_fused_qkv; g_vit_fused_qkv = on ? 1 : 0; return old;
+}
 
 extern "C" int lcc_engine_set_vit_grid_cap(lcc_engine* e, int cap) {
   if (!e || cap < 0) return fail(LCC_ERR_ARG, "bad engine / cap");
@@ -15,15 +18,18 @@ extern "C" int lcc_engine_set_vit_grid_cap(lcc_engine* e, int cap) {
   return 0;
 }
 namespace {
-struct GridCapScope {      // the cap is host-side launch state: it holds for the launches made inside this call only
-  explicit GridCapScope(int cap) { set_grid_cap(cap); }
-  ~GridCapScope() { set_grid_cap(0); }
+struct GridCapScope {      // the cap is host-side launch state of THIS thread (gemm.hip: thread_local): it holds for the launches made inside this call only
+  int prev;
+  explicit GridCapScope(int cap) : prev(get_grid_cap()) { set_grid_cap(cap); }
+  ~GridCapScope() { set_grid_cap(prev); }
 };
 }  // namespace
 
 extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips, const float mean255[3], const float std255[3],
                               const float* rope_cos, const float* rope_sin, void* out_embeds, void* stream) {
   LCC_TRY(ensure_ready(e));
+  CallScope in_flight;
+  std::lock_guard<std::mutex> lk(e->mu_vit);
   GridCapScope cap_scope(e->vit_grid_cap);
   if (n_clips <= 0 || !clips || !rope_cos || !rope_sin || !out_embeds) return fail(LCC_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;

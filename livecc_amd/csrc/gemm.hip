@@ -36,7 +36,9 @@ __device__ unsigned int lcc_zero_page[256];  // 1 KB of zeros: operand source of
 // over every CU the HBM-bound decode kernels lose their memory-level parallelism and the "overlapped" tower simply adds its own duration
 // to the decode steps (8 streams: 4.88 vs 3.68 ms per step while a 20-ms tower runs; 1 stream: 3.23 vs 2.95 ms).  Half the CUs stream the
 // weights at the full HBM rate.  A multiple of 8 (virtual block id and physical block id then agree on the XCD).
-static int g_grid_cap = 0;
+// thread_local: the cap belongs to the host thread that is inside lcc_vit_encode -- a second thread launching prefill GEMMs
+// meanwhile is not capped, and two engines with different caps do not race.
+static thread_local int g_grid_cap = 0;
 void set_grid_cap(int cap) { g_grid_cap = cap <= 0 ? 0 : std::max(8, cap & ~7); }
 int get_grid_cap() { return g_grid_cap; }
 static inline unsigned capped_grid(long nblk) { return (unsigned)((g_grid_cap > 0 && nblk > g_grid_cap) ? g_grid_cap : nblk); }
@@ -1058,7 +1060,9 @@ static void launch_big_s(const GemmArgs& a, hipStream_t st) {
 // variable-height row tiles (gemm_vh_kernel): tiles_m = floor(F / 16) row tiles for F = ceil(M / 16) row fragments (small class: F / 8)
 static bool vh_legal(const GemmArgs& a, bool small = false) {
   const int F = (a.M + 15) >> 4, t = F >> (small ? 3 : 4);
-  return a.w_packed && !a.w_fp8 && (a.K % 64) == 0 && t >= 1 && F <= (small ? 9 : 18) * t && (a.N & 15) == 0;
+  // wscale == nullptr: gemm_w8's dequantisation fallback re-enters with w_fp8 = 0 and a LIVE row scale for the epilogue, which
+  // this kernel does not carry
+  return a.w_packed && !a.w_fp8 && a.wscale == nullptr && (a.K % 64) == 0 && t >= 1 && F <= (small ? 9 : 18) * t && (a.N & 15) == 0;
 }
 template <int EPI, int SMALL = 0>
 static void launch_vh(const GemmArgs& a, hipStream_t st) {

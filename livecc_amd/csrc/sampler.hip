@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void sample_greedy_kernel(
     for (int e = 0; e < 8; ++e) {
       if (penalty != 1.0f && ((bits >> e) & 1u)) v[e] = v[e] < 0.f ? v[e] * penalty : v[e] / penalty;
       const int id = c * 8 + e;
-      if (suppress_eos && (id == eos_token || id == eos_token2)) v[e] = -INFINITY;  // MinNewTokensLengthLogitsProcessor
+      if ((suppress_eos & 1) && (id == eos_token || id == eos_token2)) v[e] = -INFINITY;  // MinNewTokensLengthLogitsProcessor
       if (so) so[id] = v[e];
       // online max / exp-sum over ALL scores (softmax denominator of the threshold processor)
       if (v[e] > mx) { sum = sum * __expf(mx - v[e]) + 1.f; mx = v[e]; }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void sample_greedy_kernel(
       if (col < hist_ld) history[(size_t)slot * hist_ld + col] = tok;
       hist_col[slot] = col + 1;
     }
-    if (done != nullptr && (tok == eos_token || tok == eos_token2)) done[slot] = 1;
+    if (done != nullptr && !(suppress_eos & 2) && (tok == eos_token || tok == eos_token2)) done[slot] = 1;
   }
 }
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(
     for (int e = 0; e < 8; ++e) {
       if (penalty != 1.0f && ((bits >> e) & 1u)) v[e] = v[e] < 0.f ? v[e] * penalty : v[e] / penalty;
       const int id = c * 8 + e;
-      if (suppress_eos && (id == eos_token || id == eos_token2)) v[e] = -INFINITY;
+      if ((suppress_eos & 1) && (id == eos_token || id == eos_token2)) v[e] = -INFINITY;
       if (so) so[id] = v[e];
       if (v[e] > mx) { sum = sum * __expf(mx - v[e]) + 1.f; mx = v[e]; }
       else sum += __expf(v[e] - mx);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(
 
 __global__ __launch_bounds__(64) void sample_final_kernel(
     const float* __restrict__ part, int V, const int32_t* __restrict__ stream_slot, int thr_token, int use_thr, float thr_value,
-    int eos_token, int eos_token2, int32_t* __restrict__ done, int32_t* __restrict__ out_tokens, int32_t* __restrict__ history, int hist_ld,
+    int eos_token, int eos_token2, int no_done, int32_t* __restrict__ done, int32_t* __restrict__ out_tokens, int32_t* __restrict__ history, int hist_ld,
     int32_t* __restrict__ hist_col, float* __restrict__ scores_out) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int slot = stream_slot[b];
@@ -214,9 +214,11 @@ __global__ __launch_bounds__(64) void sample_final_kernel(
     if (col < hist_ld) history[(size_t)slot * hist_ld + col] = tok;
     hist_col[slot] = col + 1;
   }
-  if (done != nullptr && (tok == eos_token || tok == eos_token2)) done[slot] = 1;
+  if (done != nullptr && !no_done && (tok == eos_token || tok == eos_token2)) done[slot] = 1;
 }
 
+// suppress_eos: bit 0 = both EOS ids are masked to -inf (MinNewTokensLengthLogitsProcessor); bit 1 = a picked EOS does not set done[slot]
+// (teacher forcing: the forced stream decides where a slot ends, and the processed scores keep HF's definition -- EOS unmasked)
 int sample_greedy(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, int words_per_stream,
                   const int32_t* stream_slot, float repetition_penalty, int thr_token, int use_thr, float thr_value,
                   int eos_token, int eos_token2, int suppress_eos, int32_t* done, int32_t* out_tokens, int32_t* history, int hist_ld,
@@ -226,7 +228,7 @@ int sample_greedy(const bf16_t* logits, int ld, int B, int V, uint32_t* seen, in
   if (ws != nullptr && V >= 8192) {   // ws: B * 32 * 8 floats of scratch
     sample_partial_kernel<<<dim3(SAMPLE_NB, B), dim3(256), 0, st>>>(logits, ld, V, seen, words_per_stream, stream_slot, repetition_penalty,
                                                                    thr_token, eos_token, eos_token2, suppress_eos, done, ws, scores_out);
-    sample_final_kernel<<<dim3(B), dim3(64), 0, st>>>(ws, V, stream_slot, thr_token, use_thr, thr_value, eos_token, eos_token2, done, out_tokens,
+    sample_final_kernel<<<dim3(B), dim3(64), 0, st>>>(ws, V, stream_slot, thr_token, use_thr, thr_value, eos_token, eos_token2, suppress_eos & 2, done, out_tokens,
                                                       history, hist_ld, hist_col, scores_out);
     return 0;
   }
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(SNT) void sample_topk_topp_kernel(SampleParams P) {
   const uint32_t* sb = P.seen + (size_t)slot * P.words;
   const int V = P.V, nch = V / 8;
   const float penalty = P.penalty;
-  const int eos1 = P.suppress_eos ? P.eos_token : -1, eos2 = P.suppress_eos ? P.eos_token2 : -1;
+  const int eos1 = (P.suppress_eos & 1) ? P.eos_token : -1, eos2 = (P.suppress_eos & 1) ? P.eos_token2 : -1;
 
   // processed scores BEFORE the warpers of the 8 ids of chunk c (penalty, EOS mask; `thr_dead` = threshold processor fired)
   auto load8 = [&](int c, int thr_dead, float (&v)[8]) {
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(SNT) void sample_topk_topp_kernel(SampleParams P) {
       if (col < P.hist_ld) P.history[(size_t)slot * P.hist_ld + col] = tok;
       P.hist_col[slot] = col + 1;
     }
-    if (P.done != nullptr && (tok == P.eos_token || tok == P.eos_token2)) P.done[slot] = 1;
+    if (P.done != nullptr && !(P.suppress_eos & 2) && (tok == P.eos_token || tok == P.eos_token2)) P.done[slot] = 1;
   }
 }
 

@@ -16,11 +16,18 @@ design decisions, not omissions:
     construction: video features are consumed whenever the un-cached suffix contains <|video_pad|> (line 37-39).
   * frames may be handed over as uint8 (`frames=`) so that normalise+patchify run on the GPU; the HF
     `pixel_values_videos` fp32 tensor is accepted too.
+  * ONE engine lock per model (round 6): `generate` / `generate_batch` / `get_video_features` / `new_stream` /
+    `StreamState.release` serialise on `model._lock` (re-entrant).  The engine has one activation workspace, one meta ring
+    and one ViT workspace; the reference is called with `default_concurrency_limit=5` over one model object
+    (ref demo/app.py:178) and races on `rope_deltas` -- here concurrent callers with their own stream states are safe and
+    produce the tokens of the serial run (tests/test_gpu_facade.py).
 No CPU path: everything below needs the HIP library and a GPU, and raises otherwise.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 
 import dataclasses
 from typing import List, Optional, Sequence
@@ -46,9 +53,13 @@ class StreamState:
         return self.model.engine.slot_length(self.slot)[0]
 
     def release(self) -> None:
-        if not self.released:
-            self.released = True
-            self.model._free_slots.append(self.slot)
+        lock = getattr(self.model, "_lock", None)          # (stand-in models of the CPU tests have no engine lock)
+        if lock is None:
+            lock = contextlib.nullcontext()
+        with lock:
+            if not self.released:
+                self.released = True
+                self.model._free_slots.append(self.slot)
 
     def __bool__(self):  # `if past_key_values:` in ref demo/infer.py:281,286
         return True
@@ -120,6 +131,7 @@ class LiveCCForConditionalGeneration:
         self.engine = Engine(cfg, weights, self.device, max_slots=max_streams, max_kv_len=max_kv_len,
                              max_new_rows=max_new_rows, max_patches=max_patches, max_history=max_history)
         self._free_slots = list(range(max_streams - 1, -1, -1))
+        self._lock = threading.RLock()          # every engine entry point below holds it for the whole call (see the module docstring)
         self.text_offset_rule = text_offset_rule
         self.prepare_inputs_for_generation = None   # assignable, as ref demo/infer.py:50 does
         self.generation_config: dict = {}            # from_pretrained fills it from generation_config.json (do_sample / top_k ...)
@@ -173,11 +185,12 @@ class LiveCCForConditionalGeneration:
 
     # ---- stream slots ----
     def new_stream(self) -> StreamState:
-        if not self._free_slots:
-            raise RuntimeError(f"all {self.engine.max_slots} stream slots are in use (raise max_streams)")
-        st = StreamState(self, self._free_slots.pop())
-        self.engine.reset_slot(st.slot)
-        return st
+        with self._lock:
+            if not self._free_slots:
+                raise RuntimeError(f"all {self.engine.max_slots} stream slots are in use (raise max_streams)")
+            st = StreamState(self, self._free_slots.pop())
+            self.engine.reset_slot(st.slot)
+            return st
 
     # ---- generate ----
     @staticmethod
@@ -261,7 +274,14 @@ class LiveCCForConditionalGeneration:
         `prefetch`: clips ({'frames': uint8 GPU tensor, 'frames_layout': ...}) that a LATER call will pass as `frames`: their vision
         tower (compute-bound) is launched on a low-priority side stream right after this call's prefill and runs under its decode
         steps (HBM-bound weight streaming); the later call picks the embeddings up by the clip's storage (pointer, shape, layout).
-        The frames must not be modified in between.  Results are bit-identical to the un-prefetched call."""
+        The frames must not be modified in between.  Results are bit-identical to the un-prefetched call.
+        Thread-safe: the whole call (ViT, prefill, every decode step, the token read-back) runs under the model's engine lock."""
+        with self._lock:
+            return self._generate_batch_locked(requests, repetition_penalty, logits_processor, max_new_tokens, force_length, eos_token_id,
+                                               output_logits, output_scores, do_sample, temperature, top_k, top_p, seed, prefetch, teacher_tokens)
+
+    def _generate_batch_locked(self, requests, repetition_penalty, logits_processor, max_new_tokens, force_length, eos_token_id, output_logits,
+                               output_scores, do_sample, temperature, top_k, top_p, seed, prefetch, teacher_tokens) -> List[GenerateOutput]:
         cfg, eng = self.cfg, self.engine
         if eos_token_id is None:
             eos_ids = list(self.eos_token_ids)
@@ -552,12 +572,13 @@ class LiveCCForConditionalGeneration:
     @torch.inference_mode()
     def get_video_features(self, pixel_values_videos: torch.Tensor = None, video_grid_thw=None, frames=None,
                            frames_layout: str = "TCHW") -> torch.Tensor:
-        if frames is not None:
-            return self._vit_encode([dict(frames=frames.to(self.device).contiguous(), layout=frames_layout)])
-        g = torch.as_tensor(video_grid_thw).reshape(-1, 3).tolist()
-        pv = pixel_values_videos.to(self.device, dtype=torch.float32).contiguous()
-        clips, off = [], 0
-        for t, h, w in g:
-            clips.append(dict(pixel_values=pv[off:off + t * h * w], grid=(t, h, w)))
-            off += t * h * w
-        return self._vit_encode(clips)
+        with self._lock:
+            if frames is not None:
+                return self._vit_encode([dict(frames=frames.to(self.device).contiguous(), layout=frames_layout)])
+            g = torch.as_tensor(video_grid_thw).reshape(-1, 3).tolist()
+            pv = pixel_values_videos.to(self.device, dtype=torch.float32).contiguous()
+            clips, off = [], 0
+            for t, h, w in g:
+                clips.append(dict(pixel_values=pv[off:off + t * h * w], grid=(t, h, w)))
+                off += t * h * w
+            return self._vit_encode(clips)

@@ -10,7 +10,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, torch_ops as _T
 
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU_ERF, EPI_RESIDUAL, EPI_SWIGLU = range(5)
 
@@ -49,6 +49,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     M, K = x.shape
     N = w.shape[0] if packed_shape is None else packed_shape[0]
     assert (w.shape[1] if packed_shape is None else packed_shape[1]) == K
+    _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"), _chk(bias, torch.bfloat16, "bias"), _chk(residual, torch.bfloat16, "residual")
+    t = _T.op("linear")          # the dispatcher path (torch.ops.livecc_amd.linear) when the registration library is present
+    if t is not None:
+        return t(x, w, bias, int(epilogue), residual, 0 if packed_shape is None else int(N), 0 if packed_shape is None else int(K))
     out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load()
     _lib.check(lib.lcc_gemm_bf16(_chk(x, torch.bfloat16, "x"), K, _chk(w, torch.bfloat16, "w"), K, 0 if packed_shape is None else 1,
@@ -157,6 +161,10 @@ def gemv_num_splits(N: int, K: int) -> int:
 
 
 def layernorm(x, w, b, eps=1e-6):
+    _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"), _chk(b, torch.bfloat16, "b")
+    t = _T.op("layernorm")
+    if t is not None:
+        return t(x, w, b, float(eps))
     y = torch.empty_like(x)
     rows = x.numel() // x.shape[-1]
     _lib.check(_lib.load().lcc_layernorm_bf16(_chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"),
@@ -166,6 +174,10 @@ def layernorm(x, w, b, eps=1e-6):
 
 
 def rmsnorm(x, w, eps=1e-6):
+    _chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w")
+    t = _T.op("rmsnorm")
+    if t is not None:
+        return t(x, w, float(eps))
     y = torch.empty_like(x)
     rows = x.numel() // x.shape[-1]
     _lib.check(_lib.load().lcc_rmsnorm_bf16(_chk(x, torch.bfloat16, "x"), _chk(w, torch.bfloat16, "w"), y.data_ptr(), rows,
@@ -186,6 +198,10 @@ def add_rmsnorm_(h, w, eps=1e-6, delta=None, partial=None):
 
 
 def swiglu(gate, up):
+    _chk(gate, torch.bfloat16, "gate"), _chk(up, torch.bfloat16, "up")
+    t = _T.op("swiglu")
+    if t is not None:
+        return t(gate, up)
     out = torch.empty_like(gate)
     _lib.check(_lib.load().lcc_swiglu_bf16(_chk(gate, torch.bfloat16, "gate"), _chk(up, torch.bfloat16, "up"), out.data_ptr(),
                                            gate.numel(), _st(gate)), "lcc_swiglu_bf16")
@@ -198,6 +214,10 @@ def patchify_norm(frames: torch.Tensor, layout: str, mean255, std255) -> torch.T
         T, H, W, _ = frames.shape
     else:
         T, _, H, W = frames.shape
+    _chk(frames, torch.uint8, "frames")
+    t = _T.op("patchify_norm")
+    if t is not None:
+        return t(frames, lay, [float(v) for v in mean255], [float(v) for v in std255])
     P = ((T + 1) // 2) * (H // 14) * (W // 14)
     out = torch.empty(P, 1176, dtype=torch.bfloat16, device=frames.device)
     m = (C.c_float * 3)(*[float(v) for v in mean255])
@@ -304,6 +324,12 @@ def rope_kv_append(qkv: Optional[torch.Tensor], cos, sin, tok_stream, tok_pos, k
                    partial: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
                    kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
     S = cos.shape[0]
+    t = _T.op("rope_kv_append")
+    if t is not None:
+        for a, dt, nm in ((qkv, torch.bfloat16, "qkv"), (partial, torch.float32, "partial"), (bias, torch.bfloat16, "bias"), (cos, torch.bfloat16, "cos"),
+                          (sin, torch.bfloat16, "sin"), (tok_stream, torch.int32, "tok_stream"), (tok_pos, torch.int32, "tok_pos"), (kv_len, torch.int32, "kv_len")):
+            _chk(a, dt, nm)
+        return t(qkv, partial, bias, cos, sin, tok_stream, tok_pos, kv_len, kv.ptrs, kv.buf, kv.n_layers, kv.n_kv_heads, kv.lmax, int(layer), int(n_q_heads))
     # n_q_heads == 0: append-only use (the HF Cache plugin): the kernel still wants a valid pointer
     q = torch.empty(S, n_q_heads * 128, dtype=torch.bfloat16, device=cos.device)
     dummy = torch.empty(16, dtype=torch.bfloat16, device=cos.device) if n_q_heads == 0 else None
@@ -326,8 +352,12 @@ def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tu
             ts.append(slot); tq.append(row + o); tn.append(min(tile_rows, n_new - o)); tp.append(past + o)
         row += n_new
     dev = q.device
-    out = torch.empty_like(q)
     a, b, c, d = _i32(ts, dev), _i32(tq, dev), _i32(tn, dev), _i32(tp, dev)
+    _chk(q, torch.bfloat16, "q")
+    t = _T.op("attn_prefill")
+    if t is not None:
+        return t(q, kv.ptrs, kv.buf, kv.n_layers, kv.n_kv_heads, kv.lmax, int(layer), a, b, c, d, int(n_q_heads), int(tile_rows), int(nsplit))
+    out = torch.empty_like(q)
     ws_o = torch.empty(q.shape[0] * n_q_heads * nsplit * 128, dtype=torch.float32, device=dev) if nsplit > 1 else None
     ws_ml = torch.empty(q.shape[0] * n_q_heads * nsplit * 2, dtype=torch.float32, device=dev) if nsplit > 1 else None
     _lib.check(_lib.load().lcc_attn_prefill_bf16(_chk(q, torch.bfloat16, "q"), out.data_ptr(), a.data_ptr(), b.data_ptr(),
@@ -340,6 +370,10 @@ def attn_prefill(q: torch.Tensor, kv: KvArena, layer: int, segments: Sequence[Tu
 def attn_decode(q: torch.Tensor, kv: KvArena, layer: int, slots: torch.Tensor, kv_len: torch.Tensor, n_q_heads: int,
                 nsplit: int):
     B = q.shape[0]
+    _chk(q, torch.bfloat16, "q"), _chk(slots, torch.int32, "slots"), _chk(kv_len, torch.int32, "kv_len")
+    t = _T.op("attn_decode")
+    if t is not None:
+        return t(q, kv.ptrs, kv.buf, kv.n_layers, kv.n_kv_heads, kv.lmax, int(layer), slots, kv_len, int(n_q_heads), int(nsplit))
     out = torch.empty_like(q)
     ws_o = torch.empty(B * kv.n_kv_heads * nsplit * 16 * 128, dtype=torch.float32, device=q.device)
     ws_ml = torch.empty(B * kv.n_kv_heads * nsplit * 16 * 2, dtype=torch.float32, device=q.device)
@@ -388,6 +422,13 @@ def sample_greedy(logits: torch.Tensor, seen: torch.Tensor, slots: torch.Tensor,
                   want_scores: bool = False, two_stage: bool = False, eos_token2: int = -1, done: Optional[torch.Tensor] = None):
     B, V = logits.shape
     n_slots, words = seen.shape
+    if not two_stage and done is None:          # the single-launch form is what torch.ops.livecc_amd.sample_greedy registers
+        _chk(logits, torch.bfloat16, "logits"), _chk(seen, torch.int32, "seen"), _chk(slots, torch.int32, "slots")
+        t = _T.op("sample_greedy")
+        if t is not None:
+            out, scores = t(logits, seen, slots, float(repetition_penalty), int(thr_token), thr_value is not None, float(thr_value or 0.0),
+                            int(eos_token), int(eos_token2), bool(suppress_eos), bool(want_scores))
+            return out, (scores if want_scores else None)
     out = torch.zeros(n_slots, dtype=torch.int32, device=logits.device)
     scores = torch.empty(B, V, dtype=torch.float32, device=logits.device) if want_scores else None
     ws = torch.empty(B * 256, dtype=torch.float32, device=logits.device) if two_stage else None

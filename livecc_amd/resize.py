@@ -146,6 +146,10 @@ def resize_bicubic_aa(frames: torch.Tensor, height: int, width: int, layout: str
     dev = frames.device
     xmin, xsize, wx, kx = _taps_on(dev, Win, width, tap_major=True)
     ymin, ysize, wy, ky = _taps_on(dev, Hin, height)
+    from . import torch_ops as _T
+    t = _T.op("resize_bicubic_aa")          # dispatcher path (torch.ops.livecc_amd.resize_bicubic_aa) when the registration library is present
+    if t is not None:
+        return t(frames, 0 if layout == "THWC" else 1, int(height), int(width), xmin, xsize, wx, int(kx), ymin, ysize, wy, int(ky))
     out = torch.empty(T, 3, height, width, dtype=torch.uint8, device=dev)
     tmp = torch.empty(T * 3 * Hin * width, dtype=torch.float32, device=dev)
     _lib.check(_lib.load().lcc_resize_bicubic_aa_u8(

@@ -15,14 +15,28 @@ and one scheduler thread owns the device:
   * back-pressure: a stream that falls more than `max_lag_s` behind either keeps catching up one chunk per step ("catch_up",
     the reference's behaviour: it processes every pending chunk) or skips the stale frames ("drop": the skipped interval is
     never shown to the model, the next chunk starts at the newest due frame pair);
-  * stateless mode (`hf_spaces`, ref demo/infer.py:176-178): results carry a light state without KV / past_ids.
+  * stateless mode (`hf_spaces`, ref demo/infer.py:176-178): results carry a light state without KV / past_ids;
+  * end of the KV window (round 6; the reference has no policy: ref demo/infer.py:61-180 grows `past_key_values` until HF runs out
+    of trained positions, README.md:77-79 quotes 24k visual + 8k text): BEFORE a batch is formed, a stream whose next chunk would
+    not fit its KV slot (cached + new rows + generation headroom > max_kv_len) is either ended with a result that carries
+    `window_full=True` (`window_policy="end"`, default) or restarted from its system prompt with the current chunk as a first
+    turn (`"restart"`: the KV slot is recycled, the result carries `restarted=True`) -- one full stream can no longer fail the
+    batched call of every other stream;
+  * error isolation: when the batched `generate_batch` raises, every stream's KV length is rolled back to what it was before
+    the call and the streams are retried ONE BY ONE; a stream that fails alone is ended with `error=...` in its result state,
+    the others are served as if the bad stream had not been in the batch;
+  * one lock: a step holds the model's engine lock (modeling.LiveCCForConditionalGeneration._lock) from batch formation to the
+    last token read, so `step` / `add_stream` / `remove_stream` may be called from several threads (ref demo/app.py:178 runs
+    five concurrent callers over one model object).
 
 Video decoding stays external: a stream is a GPU-resident uint8 frame tensor plus its pts (or any object with the same two
 attributes that a decoder thread appends to).
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
+import threading
 import time
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -52,15 +66,22 @@ class _Stream:
     ended: bool = False
     dropped_s: float = 0.0
     ahead: Optional[dict] = None         # the chunk after the current one, fetched + resized ahead (its ViT runs under this step's decode)
+    window_full: bool = False            # ended because the next chunk would not fit the KV slot (window_policy="end")
+    restarts: int = 0                    # times the stream was restarted from its system prompt (window_policy="restart")
+    error: Optional[str] = None          # ended because its own generate call failed
 
 
 class StreamServer:
     def __init__(self, infer: LiveCCDemoInfer, max_new_tokens: int = 16, repetition_penalty: float = 1.05,
                  streaming_eos_base_threshold: Optional[float] = None, streaming_eos_threshold_step: float = 0.0,
                  default_query: str = "Please describe the video.", max_lag_s: float = 4.0, lag_policy: str = "catch_up",
-                 force_length: bool = False, prefetch: bool = True):
+                 force_length: bool = False, prefetch: bool = True, window_policy: str = "end"):
         if lag_policy not in ("catch_up", "drop"):
             raise ValueError(lag_policy)
+        if window_policy not in ("end", "restart"):
+            raise ValueError(window_policy)
+        self.window_policy = window_policy
+        self._mu = threading.RLock()          # the stream table; the engine itself is guarded by the model's own lock
         self.infer, self.model, self.cfg = infer, infer.model, infer.cfg
         self.max_new_tokens, self.repetition_penalty = max_new_tokens, repetition_penalty
         self.thr = (streaming_eos_base_threshold, streaming_eos_threshold_step)
@@ -71,18 +92,25 @@ class StreamServer:
         self.prefetch = prefetch
 
     # ---- stream management ----
+    def _engine_lock(self):
+        """The model's engine lock (re-entrant: generate_batch takes it again); stand-in models of the CPU tests have none."""
+        return getattr(self.model, "_lock", None) or contextlib.nullcontext()
+
     def add_stream(self, sid, video_frames: torch.Tensor, video_pts, query: Optional[str] = None, t_start: float = 0.0,
                    max_pixels: int = 384 * 28 * 28, layout: str = "THWC") -> None:
-        if len(self.streams) >= self.model.engine.max_slots:
-            raise RuntimeError(f"all {self.model.engine.max_slots} stream slots of this GPU are in use")
-        hw = video_frames.shape[1:3] if layout == "THWC" else video_frames.shape[2:4]
-        rh, rw = R.smart_resized_hw(int(hw[0]), int(hw[1]), int(video_frames.shape[0]), max_pixels)
-        self.streams[sid] = _Stream(sid, video_frames, np.asarray(video_pts, dtype=np.float64), query, layout, float(t_start), (rh, rw))
+        with self._mu:
+            if len(self.streams) >= self.model.engine.max_slots:
+                raise RuntimeError(f"all {self.model.engine.max_slots} stream slots of this GPU are in use")
+            hw = video_frames.shape[1:3] if layout == "THWC" else video_frames.shape[2:4]
+            rh, rw = R.smart_resized_hw(int(hw[0]), int(hw[1]), int(video_frames.shape[0]), max_pixels)
+            self.streams[sid] = _Stream(sid, video_frames, np.asarray(video_pts, dtype=np.float64), query, layout, float(t_start), (rh, rw))
 
     def remove_stream(self, sid) -> None:
-        st = self.streams.pop(sid)
-        if st.kv is not None:
-            st.kv.release()
+        with self._mu, self._engine_lock():
+            st = self.streams.pop(sid)
+            if st.kv is not None:
+                st.kv.release()
+                st.kv = None
 
     # ---- which chunk of a stream is due (ref demo/infer.py steps 1-2, one chunk at a time) ----
     def _next_chunk_timestamps(self, st: _Stream, now: float) -> Optional[List[float]]:
@@ -125,10 +153,40 @@ class StreamServer:
         return st.t_start + st.last_timestamp + protocol.FRAME_TIME_INTERVAL + 1e-6
 
     # ---- one scheduler step: at most one chunk per stream, all chunks in one batched generate ----
+    def _turn_ids(self, st: _Stream, start: float, stop: float, grid) -> np.ndarray:
+        if self.infer.text is not None:
+            msg = st.query or self.default_query
+            q = msg if st.sent_query != msg else None
+            st.sent_query = msg
+            return self.infer.text.turn_ids(start, stop, grid, q, continuing=st.past_ids is not None)
+        return self.infer.turn_builder.turn_ids(st.turn_index, protocol.num_video_tokens(grid, self.cfg))
+
+    def _fits_window(self, n_ids_total: int) -> bool:
+        """lcc_llm_prefill's capacity rule (engine_llm.hip: cached + new + max_history <= max_kv_len) on the host, BEFORE the batch exists."""
+        eng = self.model.engine
+        cap, head = getattr(eng, "max_kv_len", None), getattr(eng, "max_history", 0)
+        return cap is None or n_ids_total + head <= cap
+
+    def _light_state(self, st: _Stream, hf_spaces: bool, **flags) -> dict:
+        state = dict(last_timestamp=st.last_timestamp, turn_index=st.turn_index, dropped_s=st.dropped_s, restarts=st.restarts, **flags)
+        if not hf_spaces:
+            state.update(past_ids=st.past_ids, past_key_values=st.kv)
+        return state
+
+    def _end_stream(self, st: _Stream) -> None:
+        st.ended, st.ahead = True, None
+        if st.kv is not None:
+            st.kv.release()
+            st.kv = None
+
     @torch.inference_mode()
     def step(self, now: float, hf_spaces: bool = False):
-        reqs, metas = [], []
-        for st in self.streams.values():
+        with self._mu, self._engine_lock():
+            return self._step(now, hf_spaces)
+
+    def _step(self, now: float, hf_spaces: bool):
+        reqs, metas, results = [], [], []
+        for st in list(self.streams.values()):
             if st.ended:
                 continue
             ts = self._next_chunk_timestamps(st, now)
@@ -145,25 +203,40 @@ class StreamServer:
                 continue
             start, stop = clip_ts[0], clip_ts[len(idxs) - 1] + protocol.FRAME_TIME_INTERVAL
             grid = protocol.grid_of(clip.shape[0], clip.shape[2], clip.shape[3], self.cfg)
-            if self.infer.text is not None:
-                msg = st.query or self.default_query
-                q = msg if st.sent_query != msg else None
-                st.sent_query = msg
-                new_ids = self.infer.text.turn_ids(start, stop, grid, q, continuing=st.past_ids is not None)
-            else:
-                new_ids = self.infer.turn_builder.turn_ids(st.turn_index, protocol.num_video_tokens(grid, self.cfg))
+            # end of the KV window, decided here so that the batch never contains a stream the engine would refuse.  The turn ids are
+            # only built once the chunk is known to run (the synthetic TurnBuilder is a seeded stream: an unused draw would shift it).
+            restarted = False
+            n_new_est = protocol.num_video_tokens(grid, self.cfg) + 64           # text of a turn is a few dozen ids (checked exactly below)
+            if st.past_ids is not None and not self._fits_window(len(st.past_ids) + n_new_est):
+                if self.window_policy == "end":
+                    st.window_full = True
+                    self._end_stream(st)
+                    results.append((st.sid, (start, stop), "", self._light_state(st, hf_spaces, window_full=True, ended=True)))
+                    continue
+                # "restart": recycle the KV slot, the current chunk becomes the first turn of a fresh conversation (system prompt + query)
+                if st.kv is not None:
+                    st.kv.release()
+                st.kv, st.past_ids, st.sent_query, st.turn_index = None, None, None, 0
+                st.restarts += 1
+                restarted = True
+            new_ids = self._turn_ids(st, start, stop, grid)
             ids = new_ids if st.past_ids is None else np.concatenate([st.past_ids, new_ids])
+            if not self._fits_window(len(ids)):          # a single turn larger than the whole slot (or the estimate above was short)
+                st.window_full = True
+                self._end_stream(st)
+                results.append((st.sid, (start, stop), "", self._light_state(st, hf_spaces, window_full=True, ended=True)))
+                continue
             reqs.append(dict(input_ids=torch.from_numpy(ids), frames=clip, frames_layout="TCHW", state=st.kv))
-            metas.append((st, start, stop, len(ids), idxs[-1], clip_ts[-1]))     # ref :117-118 keeps timestamps[-1]
+            metas.append((st, start, stop, len(ids), idxs[-1], clip_ts[-1], restarted))     # ref :117-118 keeps timestamps[-1]
         if not reqs:
-            return []
+            return results
         procs = None
         if self.thr[0] is not None and self.infer.streaming_eos_token_id is not None:
             procs = [ThresholdLogitsProcessor(self.infer.streaming_eos_token_id, self.thr[0], self.thr[1] or 0.0)]
         ahead = []
         if self.prefetch:
             fti = protocol.FRAME_TIME_INTERVAL
-            for (st, start, stop, n_in, last_idx, last_ts) in metas:
+            for (st, start, stop, n_in, last_idx, last_ts, _) in metas:
                 nts = [last_ts + fti + i * fti for i in range(protocol.STREAMING_FPS_FRAMES)]
                 if nts[-1] > float(st.pts[-1]):
                     continue                                   # the next pair is not (completely) in the buffer yet
@@ -171,21 +244,45 @@ class StreamServer:
                 if len(idxs) == protocol.STREAMING_FPS_FRAMES:
                     st.ahead = dict(ts=nts, index_from=last_idx + 1, clip=clip, clip_ts=clip_ts, idxs=idxs)
                     ahead.append(dict(frames=clip, frames_layout="TCHW"))
-        outs = self.model.generate_batch(reqs, repetition_penalty=self.repetition_penalty, logits_processor=procs,
-                                         max_new_tokens=self.max_new_tokens, force_length=self.force_length,
-                                         **({"prefetch": ahead} if ahead else {}))
-        results = []
-        for (st, start, stop, n_in, last_idx, last_ts), o in zip(metas, outs):
+        gen_kw = dict(repetition_penalty=self.repetition_penalty, max_new_tokens=self.max_new_tokens, force_length=self.force_length)
+        # KV lengths before the call: what a failed batched call is rolled back to before the per-stream retries
+        eng = self.model.engine
+        snap = {}
+        if hasattr(eng, "slot_length"):
+            for (st, *_rest) in metas:
+                if st.kv is not None:
+                    snap[id(st)] = eng.slot_length(st.kv.slot)
+        try:
+            outs = self.model.generate_batch(reqs, logits_processor=procs, **gen_kw, **({"prefetch": ahead} if ahead else {}))
+        except Exception as exc:          # LccError / ValueError / RuntimeError: isolate the stream(s) that cause it
+            if len(reqs) == 1:
+                outs = [exc]
+            else:
+                outs = []
+                for rq, (st, *_rest) in zip(reqs, metas):
+                    if id(st) in snap:
+                        eng.set_slot_length(st.kv.slot, *snap[id(st)])
+                    p1 = None
+                    if procs is not None:
+                        p1 = [ThresholdLogitsProcessor(self.infer.streaming_eos_token_id, self.thr[0], self.thr[1] or 0.0)]
+                    try:
+                        outs.append(self.model.generate_batch([rq], logits_processor=p1, **gen_kw)[0])
+                    except Exception as exc1:
+                        outs.append(exc1)
+        for (st, start, stop, n_in, last_idx, last_ts, restarted), o in zip(metas, outs):
+            if isinstance(o, Exception):
+                st.error = f"{type(o).__name__}: {o}"
+                self._end_stream(st)
+                results.append((st.sid, (start, stop), "", self._light_state(st, hf_spaces, error=st.error, ended=True)))
+                continue
             seq = o.sequences[0].cpu().numpy()
             st.kv, st.past_ids = o.past_key_values, seq[:-1]            # ref demo/infer.py:173-174
             st.turn_index += 1
             st.last_pts_index, st.last_timestamp = last_idx, last_ts
             eos = set(getattr(self.model, "eos_token_ids", None) or (self.cfg.eos_token_id,))     # <|im_end|> and <|endoftext|>
             toks = [int(t) for t in seq[n_in:] if int(t) not in eos]
-            state = dict(last_timestamp=st.last_timestamp, turn_index=st.turn_index, dropped_s=st.dropped_s)
-            if not hf_spaces:
-                state.update(past_ids=st.past_ids, past_key_values=st.kv)
-            results.append((st.sid, (start, stop), self.infer.decode(toks), state))
+            flags = dict(restarted=True) if restarted else {}
+            results.append((st.sid, (start, stop), self.infer.decode(toks), self._light_state(st, hf_spaces, **flags)))
         return results
 
     # ---- driver loops ----

@@ -39,10 +39,32 @@ LIVE_TWINS = {
 }
 SENTINEL = "test_zz_no_parity_test_was_skipped_by_the_time_budget"
 BUDGET_SKIPPED = []          # node ids skipped by a time budget in this session (read by the sentinel)
+GPU_SKIPPED = []             # (node id, reason) of EVERY skipped GPU-tier test of this session, whatever the reason (round 6)
+# Skips the sentinel tolerates on a GPU box, by reason substring: none of them is a parity comparison that silently did not run.
+#   * a hardware-capacity probe of an OPT-IN variant (the chained decode launch needs both grids resident at once);
+#   * LCC_SKIP_SLOW=1 / LCC_ALLOW_BUDGET_SKIPS=1: deliberately shortened local runs (never set by the driver).
+ALLOWED_SKIP_REASONS = ("do not fit this chip at once", "LCC_SKIP_SLOW=1")
+
+
+def pytest_runtest_logreport(report):
+    if report.skipped and "gpu" in getattr(report, "keywords", {}) and "test_gpu_zz_tier" not in report.nodeid:
+        reason = report.longrepr[2] if isinstance(report.longrepr, tuple) and len(report.longrepr) == 3 else str(report.longrepr)
+        GPU_SKIPPED.append((report.nodeid, str(reason)))
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """The C-ABI library, built on demand (hipcc cross-compiles without a GPU): CPU-tier tests that call host-only entry points use this
+    instead of relying on another test file having built the git-ignored .so first."""
+    from livecc_amd import _lib
+    if not _lib.lib_available():
+        from livecc_amd import build
+        build.build(verbose=False)
+    return _lib.load()
 
 
 def _slow_rank(item):
-    if SENTINEL in item.nodeid:
+    if "test_gpu_zz_tier" in item.nodeid:
         return len(_SLOW_ORDER) + 1
     for i, name in enumerate(_SLOW_ORDER):
         if name in item.nodeid:
@@ -70,7 +92,7 @@ def slow_budget(request):
 
 def pytest_runtest_setup(item):
     """Safety net of the same limit: past LCC_TIER_LIMIT_S (default 1,080 s) the remaining GPU tests skip instead of being killed."""
-    if "gpu" not in item.keywords or SENTINEL in item.nodeid:
+    if "gpu" not in item.keywords or "test_gpu_zz_tier" in item.nodeid:
         return
     limit = float(os.environ.get("LCC_TIER_LIMIT_S", "1080"))
     if limit > 0 and time.time() - _SESSION_T0 > limit:

@@ -9,11 +9,8 @@ from livecc_amd import _lib
 
 
 @pytest.fixture(scope="module")
-def lib():
-    if not _lib.lib_available():
-        from livecc_amd import build
-        build.build(verbose=False)
-    return _lib.load()
+def lib(built_lib):
+    return built_lib
 
 
 def test_every_declared_symbol_is_exported(lib):

@@ -37,6 +37,30 @@ def test_gpus_2_self_launches_two_ranks():
     assert c2["tokens_per_s_per_stream"] == pytest.approx(min(c2["tokens_per_s_per_rank"]) / 8, rel=1e-2)
     assert c2["value"] == pytest.approx(16 * 3 * 16 * c2["steps"] / (c2["ms_per_replay"] * c2["steps"] / 1e3), rel=1e-2)
     assert c2["roofline"]["peak"] == 5000.0 and c2["roofline"]["bound"] == "mfma"
+    assert c2["stream_ids_rank0"] == [0, 2, 4, 6, 8, 10, 12, 14] and c2["stream_id_sum_per_rank"] == [56, 64]       # stream s -> rank s % 2
+
+
+@pytest.mark.timeout(600)
+def test_gpus_8_runs_the_north_star_job_shape_on_gloo():
+    """the first real 8-GPU run must have no first-time code.  `bench.py --gpus 8 --standin` = 8 gloo ranks: 64 streams,
+    stream s on rank s % 8, 8-way gather of the per-rank counters, one broadcast, no collective in the data path, `configs2.streams == 64`."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"] + SMALL, env=dict(_env(), OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["config"]["streams"] == 8 and len(out["tokens_per_s_per_rank"]) == 8
+    assert len(out["decode_step_ms_per_rank"]) == 8 and len(out["weight_broadcast_s_per_rank"]) == 8
+    c2 = out["configs2"]
+    assert c2["streams"] == 64 and c2["streams_per_gpu"] == 8 and c2["n_gpus"] == 8 and c2["data_path_collectives"] == 0
+    assert "BASELINE.json configs[2]" in c2["workload"] and "scaled" not in c2["workload"]
+    assert c2["stream_ids_rank0"] == [0, 8, 16, 24, 32, 40, 48, 56]                                  # s % 8 == 0
+    assert c2["stream_id_sum_per_rank"] == [8 * r + 224 for r in range(8)]                           # rank r holds {r, r + 8, ..., r + 56}
+    assert len(c2["tokens_per_s_per_rank"]) == 8 and all(x > 0 for x in c2["tokens_per_s_per_rank"])
+    assert c2["tokens_per_s_per_stream"] == pytest.approx(min(c2["tokens_per_s_per_rank"]) / 8, rel=1e-2)
+    assert c2["value"] == pytest.approx(64 * 3 * 16 * c2["steps"] / (c2["ms_per_replay"] * c2["steps"] / 1e3), rel=1e-2)
+    assert c2["roofline"]["peak"] == 8 * 2500.0 and len(c2["weight_broadcast"]["seconds_per_rank"]) == 8
+    assert out["value_no_prefetch"] is not None and out["value_no_prefetch"] > 0
 
 
 @pytest.mark.timeout(120)

@@ -12,7 +12,7 @@ H, I, QKV = 3584, 18944, 4608
 
 
 @pytest.fixture(scope="module")
-def ops():
+def ops(built_lib):          # conftest: builds the git-ignored library when this file runs alone / on a fresh checkout
     from livecc_amd import ops as o
     return o
 
@@ -50,7 +50,7 @@ def test_other_row_counts_keep_their_round_4_routes(ops):
     assert ops.gemm_plan(11648, 5120, 1280, ops.EPI_QUICK_GELU)[0] in (256, 272)
 
 
-def test_the_switch_restores_the_128_row_slabs():
+def test_the_switch_restores_the_128_row_slabs(built_lib):
     code = ("import sys; sys.path.insert(0, %r)\nfrom livecc_amd import ops\n"
             "s = ops.gemm_plan(386, 3584, 18944, ops.EPI_NONE)[1]\nprint(s, ops.gemm_plan(386, 3584, 18944, ops.EPI_NONE, nsplit=s)[0])" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LCC_GEMM_VH_SMALL="0"), timeout=120)

@@ -139,3 +139,129 @@ def test_next_chunk_is_fetched_ahead_and_reused(srv):
     quiet.add_stream("a", *_video(240), t_start=0.0, max_pixels=4 * 28 * 28)
     assert [span for _, span, _, _ in quiet.run(realtime=False)] == [span for _, span, _, _ in out]
     assert set(quiet.model.prefetched) == {0}
+
+
+# ---- round 6: end of the KV window, per-stream error isolation, locking -------------------------------
+class _Slot:
+    def __init__(self, slot):
+        self.slot, self.released = slot, False
+
+    def release(self):
+        self.released = True
+
+
+class CapModel(FakeModel):
+    """Stand-in with the engine's capacity rule (cached + new + max_history <= max_kv_len) and a switchable failure."""
+
+    def __init__(self, cfg, max_kv_len, max_history=3):
+        super().__init__(cfg)
+        self.engine = type("E", (), {"max_slots": 4, "max_kv_len": max_kv_len, "max_history": max_history})()
+        self.lengths, self.rolled_back, self.fail_ids, self.next_slot = {}, [], set(), 0
+        self.engine.slot_length = lambda slot: (self.lengths.get(slot, 0), self.lengths.get(slot, 0))
+        self.engine.set_slot_length = lambda slot, kv, pos: (self.rolled_back.append((slot, kv)), self.lengths.__setitem__(slot, kv))
+
+    def generate_batch(self, reqs, **kw):
+        self.batches.append(len(reqs))
+        for r in reqs:          # like lcc_llm_prefill: the WHOLE batched call fails on one bad stream
+            n = int(r["input_ids"].numel())
+            if n + self.engine.max_history > self.engine.max_kv_len:
+                raise RuntimeError(f"KV capacity {self.engine.max_kv_len} exceeded")
+            if r["state"] is not None and r["state"].slot in self.fail_ids:
+                # a half-done call: pretend the prefill of every stream of the batch already advanced its KV
+                for q in reqs:
+                    if q["state"] is not None:
+                        self.lengths[q["state"].slot] = int(q["input_ids"].numel())
+                raise RuntimeError("injected failure")
+        outs = []
+        for r in reqs:
+            st = r["state"]
+            if st is None:
+                st = _Slot(self.next_slot)
+                self.next_slot += 1
+            seq = torch.cat([r["input_ids"].view(-1), torch.tensor([7, 8, 9])]).view(1, -1)
+            self.lengths[st.slot] = seq.numel() - 1
+            outs.append(type("O", (), {"sequences": seq, "past_key_values": st})())
+        return outs
+
+
+def _cap_server(monkeypatch, max_kv_len, **kw):
+    def fake_clip(frames, h, w, ts, pts, index_from, layout="THWC"):
+        from livecc_amd import resize as R
+        idxs, kept = R.select_clip_frames(ts, pts, index_from)
+        return (torch.zeros(len(idxs), 3, h, w, dtype=torch.uint8) if idxs else None), kept, idxs
+    monkeypatch.setattr(server.R, "get_smart_resized_clip", fake_clip)
+    inf = FakeInfer()
+    inf.model = CapModel(inf.cfg, max_kv_len)
+    return server.StreamServer(inf, max_new_tokens=3, **kw)
+
+
+def test_a_full_kv_window_ends_that_stream_only(monkeypatch):
+    srv = _cap_server(monkeypatch, max_kv_len=160)
+    srv.add_stream("long", *_video(600), t_start=0.0, max_pixels=4 * 28 * 28)     # 20 s: outgrows 160 rows
+    srv.add_stream("short", *_video(150), t_start=0.0, max_pixels=4 * 28 * 28)    # 5 s
+    out = srv.run(realtime=False)
+    by = {}
+    for sid, span, text, state in out:
+        by.setdefault(sid, []).append((span, text, state))
+    assert by["long"][-1][2].get("window_full") is True and by["long"][-1][2]["ended"] and by["long"][-1][1] == ""
+    assert srv.streams["long"].window_full and srv.streams["long"].ended and srv.streams["long"].kv is None
+    assert [s for s, _, _ in by["short"]] == [(0.0, 3.0), (3.0, 4.0), (4.0, 5.0)]          # served to its end, untouched
+    assert not any(st.get("window_full") for _, _, st in by["short"])
+    assert not any("error" in st for _, _, st in by["long"] + by["short"]), "the engine was never handed a stream it would refuse"
+    assert len(by["long"]) >= 3 and all(t != "" for _, t, _ in by["long"][:-1])
+
+
+def test_restart_policy_recycles_the_slot_and_continues(monkeypatch):
+    srv = _cap_server(monkeypatch, max_kv_len=160, window_policy="restart")
+    srv.add_stream("v", *_video(600), t_start=0.0, max_pixels=4 * 28 * 28)
+    out = srv.run(realtime=False)
+    spans = [span for _, span, _, _ in out]
+    assert spans[0] == (0.0, 3.0) and spans[-1][1] >= 19.0, "every chunk of the 20-s video was served"
+    assert all(b - a == 1.0 for a, b in spans[1:])
+    flagged = [st for _, _, _, st in out if st.get("restarted")]
+    assert len(flagged) >= 2 and srv.streams["v"].restarts == len(flagged)
+    assert not any(st.get("window_full") or "error" in st for _, _, _, st in out)
+    with pytest.raises(ValueError):
+        server.StreamServer(FakeInfer(), window_policy="nope")
+
+
+def test_one_failing_stream_does_not_fail_the_batch(monkeypatch):
+    srv = _cap_server(monkeypatch, max_kv_len=100000)
+    for sid in ("a", "b", "c"):
+        srv.add_stream(sid, *_video(180), t_start=0.0, max_pixels=4 * 28 * 28)
+    assert len(srv.step(0.0)) == 3
+    m = srv.model
+    bad = srv.streams["b"].kv.slot
+    before = {sid: m.lengths[srv.streams[sid].kv.slot] for sid in ("a", "c")}
+    m.fail_ids.add(bad)
+    n_batches = len(m.batches)
+    res = {sid: (span, text, st) for sid, span, text, st in srv.step(3.2)}
+    assert m.batches[n_batches:] == [3, 1, 1, 1], "one batched attempt, then one call per stream"
+    assert "injected failure" in res["b"][2]["error"] and res["b"][2]["ended"] and srv.streams["b"].ended and srv.streams["b"].kv is None
+    for sid in ("a", "c"):
+        assert res[sid][0] == (3.0, 4.0) and res[sid][1] != "" and "error" not in res[sid][2]
+        assert (srv.streams[sid].kv.slot, before[sid]) in m.rolled_back, "the half-done batched call was rolled back before the retry"
+    later = srv.run(realtime=False)
+    assert sorted({sid for sid, *_ in later}) == ["a", "c"]
+
+
+def test_server_steps_hold_the_engine_lock(monkeypatch):
+    import threading
+    srv = _cap_server(monkeypatch, max_kv_len=100000)
+    held = []
+
+    class Probe:
+        def __enter__(self):
+            held.append("in")
+
+        def __exit__(self, *a):
+            held.append("out")
+    srv.model._lock = Probe()
+    srv.add_stream("a", *_video(120), t_start=0.0, max_pixels=4 * 28 * 28)
+    srv.step(0.0)
+    assert held == ["in", "out"]
+    srv.model._lock = threading.RLock()
+    ths = [threading.Thread(target=srv.step, args=(3.2,)) for _ in range(4)]     # concurrent steps: the chunk is served exactly once
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert srv.streams["a"].turn_index == 2
