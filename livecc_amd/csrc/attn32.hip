@@ -16,6 +16,7 @@
 // Layouts (gfx950 v_mfma_f32_32x32x16_bf16): A lane l = A[i = l & 31][k = (l >> 5) * 8 + e]; B lane l = B[k = (l >> 5) * 8 + e][j = l & 31];
 // C/D lane l, r = 0..15: D[i = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3)][j = l & 31].
 // With key(i) = tile * 32 + swap23(i): score register r of lane-half hh holds key offset 16 * (r >> 3) + 8 * hh + (r & 7).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -170,29 +171,49 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
 // ------------------------------------------------------------------------------------------------------------------------------
 // LLM prefill (causal, GQA): grid = (query tiles, KV heads, key splits); NWAVE waves: wave w < G computes query head hk * G + w, every
 // wave feeds the DMA ring.  Tile tables as attn_prefill_kernel: stream slot, first row in q, valid rows (<= 32), cache index of row 0.
+// Round 6, two changes of the work mapping (both leave every (row, head)'s arithmetic untouched: bit-identical outputs):
+//  * XCD-chunked block order (`xcd_chunks`): the grid is 1-D; work item = (key split, KV head, query tile) with the query tile fastest, and
+//    the items are dealt to the 8 XCDs in CONTIGUOUS chunks (block b runs on XCD b % 8 -- observed placement, used for speed only): the
+//    query tiles of one stream that read the SAME keys of a (KV head, split) then run on ONE XCD and share its L2.  Before, blockIdx.x
+//    = query tile put the 13 tiles of a 386-row chunk on 8 different XCDs, i.e. every K / V byte was pulled into 8 L2s (8 x 386 rows x
+//    6.5k keys: 1.4 GB of L2 fills per launch = 3.4 TB/s, all of it LDS-DMA latency in front of the ring's vmcnt waits).
+//  * (row, head) pair packing (`pack`): a wave's 32 query columns are 32 consecutive (head, row) PAIRS of the tile's nq x G pairs, head-major
+//    (pair p = head_local * nq + row), instead of "wave w = head w, column = row".  With nq = 32 that is the same thing; a ragged tile
+//    (386 rows = 12 x 32 + 2) packs its 2 x 7 = 14 pairs into ONE wave instead of running seven waves with two live columns each -- 1/7
+//    of the MFMA work for 1/13 of a chunk's blocks.
 template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
     const bf16_t* __restrict__ q, bf16_t* __restrict__ out, const int32_t* __restrict__ tile_stream,
     const int32_t* __restrict__ tile_q0, const int32_t* __restrict__ tile_nq, const int32_t* __restrict__ tile_pos0,
     bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int heads, float scale_log2e, int nsplit,
-    float* __restrict__ ws_o, float* __restrict__ ws_ml) {
+    float* __restrict__ ws_o, float* __restrict__ ws_ml, int n_tiles, int xcd_chunks, int pack) {
   constexpr int D = 128, KP = 8, VP = 8, NP = KP + VP, NSTAGE = 10, PW = (NP + NWAVE - 1) / NWAVE;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];      // NSTAGE x NP pieces of 1 KB in MFMA fragment (lane) order
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, hh = lane >> 5;
-  const int grp = blockIdx.x, hk = blockIdx.y, G = heads / lay.n_kv_heads;
-  const int h = min(hk * G + wave, heads - 1);
-  const bool active = wave < G;
+  const int n_items = n_tiles * lay.n_kv_heads * nsplit;
+  int item = blockIdx.x;
+  if (xcd_chunks) item = (int)(blockIdx.x & 7) * ((n_items + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (item >= n_items) return;                           // (the grid is rounded up to 8 chunks; the whole block leaves before any barrier)
+  const int grp = item % n_tiles, hk = (item / n_tiles) % lay.n_kv_heads, split = item / (n_tiles * lay.n_kv_heads);
+  const int G = heads / lay.n_kv_heads;
   const int strm = tile_stream[grp], q0 = tile_q0[grp], nq = tile_nq[grp], pos0 = tile_pos0[grp];
+  // this lane's (head, row) pair
+  const int pairs = nq * G;
+  const int pidx = min(wave * 32 + col, pairs - 1);      // clamped: surplus columns compute a valid pair and are not stored
+  const int hl = pack ? pidx / nq : min(wave, G - 1);
+  const int qr = pack ? pidx - hl * nq : min(col, nq - 1);
+  const int h = hk * G + hl;
+  const bool active = pack ? wave * 32 < pairs : wave < G;
+  const bool valid = pack ? wave * 32 + col < pairs : (wave < G && col < nq);
   const bf16_t* base = kv_base[strm] + (size_t)layer * lay.layer_stride();
   const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
   const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
   const int nkeys = pos0 + nq, ntile = (nkeys + 31) / 32;
   const int per = (ntile + nsplit - 1) / nsplit;
-  const int tb = nsplit > 1 ? min(ntile, (int)blockIdx.z * per) : 0;
+  const int tb = nsplit > 1 ? min(ntile, split * per) : 0;
   const int te = nsplit > 1 ? min(ntile, tb + per) : ntile;
   const int ldq = heads * D;
-  const int qr = min(col, nq - 1);                       // this lane's query row inside the tile (clamped: surplus columns are not stored)
   const int key_limit = pos0 + qr + 1;                   // causal, bottom-right aligned: keys 0 .. pos (inclusive)
 
   // Q^T fragments (B operand of K . Q^T), resident for the whole key loop: Q[row qr][d = ks * 16 + hh * 8 .. + 8]
@@ -244,10 +265,9 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
   if (!active) return;
 
   float l = xor32_sum(l_run);
-  const bool valid = col < nq;
   if (nsplit > 1) {      // partial (o, m, l) of this key split; attn_prefill_combine_kernel merges them
     if (valid) {
-      const size_t slot = ((size_t)(q0 + col) * heads + h) * nsplit + blockIdx.z;
+      const size_t slot = ((size_t)(q0 + qr) * heads + h) * nsplit + split;
       float* op = ws_o + slot * D;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
   }
   const float inv = 1.f / l;
   if (valid) {
-    bf16_t* op = out + (size_t)(q0 + col) * ldq + h * D;
+    bf16_t* op = out + (size_t)(q0 + qr) * ldq + h * D;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -282,14 +302,18 @@ template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const int32_t* __restrict__ grp_seg,
     const int32_t* __restrict__ grp_q0, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
-    const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e, int n_groups) {
+    const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e, int n_groups, int xcd_chunks) {
   constexpr int D = 80, KP = 5, DT = 3, VP = 6, NP = KP + VP, NSTAGE = 10, PW = (NP + NWAVE - 1) / NWAVE;
   extern __shared__ __attribute__((aligned(16))) u32x4 alds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, hh = lane >> 5;
-  // one (group, head) per block, or a persistent walk under the grid cap (gemm.hip: g_grid_cap): virtual block vb = head * n_groups + group
-  const int nvb = n_groups * heads;
-  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  // one (group, head) per block, or a persistent walk under the grid cap (gemm.hip: g_grid_cap): virtual block vb = head * n_groups + group.
+  // xcd_chunks (round 6): the virtual blocks are dealt to the 8 XCDs in contiguous chunks (block b runs on XCD b % 8: speed only), so the
+  // ~6 row groups that read the same segment's K / V of one head share ONE L2 instead of landing on six
+  const int nvb = n_groups * heads, c8 = (nvb + 7) >> 3, vlimit = xcd_chunks ? 8 * c8 : nvb;
+  for (int vb0 = blockIdx.x; vb0 < vlimit; vb0 += gridDim.x) {
+  const int vb = xcd_chunks ? (vb0 & 7) * c8 + (vb0 >> 3) : vb0;
+  if (vb >= nvb) break;
   const int h = vb / n_groups, grp = vb - h * n_groups, E = heads * D, ld = 3 * E;
   const int sg = grp_seg[grp], q0 = grp_q0[grp] + wave * 32;
   const int s0 = seg_start[sg], sl = seg_len[sg];
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
           st8(op + d, (u32x2){pack2(o[dt][4 * r4] * inv, o[dt][4 * r4 + 1] * inv), pack2(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv)});
       }
   }
-  if (vb + (int)gridDim.x < nvb) __syncthreads();     // the next (group, head)'s DMA ring reuses the stages
+  if (vb0 + (int)gridDim.x < vlimit) __syncthreads();     // the next (group, head)'s DMA ring reuses the stages
   }
 }
 
@@ -370,8 +394,10 @@ static void vit32_launch_t(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, con
   if (once.first()) (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const long nvb = (long)n_groups * heads;
   const int cap = get_grid_cap();
-  attn_vit32_kernel<NWAVE><<<dim3((unsigned)((cap > 0 && nvb > cap) ? cap : nvb)), dim3(NWAVE * 64), lds, st>>>(
-      qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads, total_blocks, scale_log2e, n_groups);
+  static const int xcd = [] { const char* v = getenv("LCC_ATTN32_XCD"); return v ? atoi(v) : 1; }();      // A/B: 0 = virtual block = physical block
+  const long nb = (cap > 0 && nvb > cap) ? cap : (xcd ? (nvb + 7) / 8 * 8 : nvb);      // (the cap is a multiple of 8: gemm.hip set_grid_cap)
+  attn_vit32_kernel<NWAVE><<<dim3((unsigned)nb), dim3(NWAVE * 64), lds, st>>>(
+      qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads, total_blocks, scale_log2e, n_groups, xcd);
 }
 int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
                       const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
@@ -397,13 +423,18 @@ int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stre
     (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)attn_gqa32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  const dim3 grid(n_tiles, lay.n_kv_heads, nsplit > 1 ? nsplit : 1);
+  const int S = nsplit > 1 ? nsplit : 1;
+  // LCC_ATTN32_XCD / LCC_ATTN32_PACK (A/B, read once): 0 = the round-3..5 work mapping (blockIdx = tile / KV head / split; wave = head)
+  static const int xcd = [] { const char* v = getenv("LCC_ATTN32_XCD"); return v ? atoi(v) : 1; }();
+  static const int pack = [] { const char* v = getenv("LCC_ATTN32_PACK"); return v ? atoi(v) : 1; }();
+  const long n_items = (long)n_tiles * lay.n_kv_heads * S;
+  const dim3 grid((unsigned)(xcd ? ((n_items + 7) / 8) * 8 : n_items));
   if (G <= 4)
     attn_gqa32_kernel<4><<<grid, dim3(256), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
-                                                       scale_log2e, nsplit > 1 ? nsplit : 1, ws_o, ws_ml);
+                                                       scale_log2e, S, ws_o, ws_ml, n_tiles, xcd, pack);
   else
     attn_gqa32_kernel<8><<<grid, dim3(512), lds, st>>>(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_q_heads,
-                                                       scale_log2e, nsplit > 1 ? nsplit : 1, ws_o, ws_ml);
+                                                       scale_log2e, S, ws_o, ws_ml, n_tiles, xcd, pack);
   return 0;
 }
 

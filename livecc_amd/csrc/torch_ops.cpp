@@ -33,7 +33,9 @@ void chk(const Tensor& t, at::ScalarType dt, const char* name) {
   TORCH_CHECK(t.is_cuda(), name, ": expected a GPU tensor (livecc_amd has no CPU path)");
   TORCH_CHECK(t.scalar_type() == dt, name, ": expected ", dt, ", got ", t.scalar_type());
   TORCH_CHECK(t.is_contiguous(), name, ": tensor must be contiguous");
-  TORCH_CHECK(!t.requires_grad(), name, ": livecc_amd ops are inference ops (no autograd formula)");
+  // inference ops: no autograd formula.  A parameter of an HF module has requires_grad = true even under torch.no_grad() / inference_mode(),
+  // so the refusal applies only where a graph would actually be recorded
+  TORCH_CHECK(!(at::GradMode::is_enabled() && t.requires_grad()), name, ": livecc_amd ops are inference ops (no autograd formula): call under torch.no_grad()");
   // the kernels read bf16 / fp32 operands with 16-byte loads (index tables and uint8 frames have no such requirement)
   if (dt == at::kBFloat16 || dt == at::kFloat) TORCH_CHECK(((uintptr_t)t.data_ptr() & 15) == 0, name, ": data pointer must be 16-byte aligned");
 }

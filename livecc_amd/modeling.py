@@ -122,7 +122,11 @@ class LiveCCForConditionalGeneration:
         max_kv_len      = KV capacity per stream; default = the trained 32k window + max_history of generation headroom.
         text_offset_rule: "hf4" = transformers-4.5x M-RoPE text offset after a vision block (what the released checkpoints
         were trained with, ref README.md:30); "hf5" = the installed 5.15 oracle's rule.  Identical for every streaming chunk;
-        they differ for one-shot long clips (grid_t > max(h,w)/2)."""
+        they differ for one-shot long clips (grid_t > max(h,w)/2).
+        PINNING STATUS: "hf5" is pinned to the EXECUTED transformers 5.15 (`get_rope_index`, tests/test_protocol.py + every one-shot GPU
+        fixture).  "hf4" is UNPINNED: it restates the 4.5x algorithm (`st_idx = llm_pos_ids_list[-1].max() + 1`) from memory of that
+        source -- no 4.5x wheel / sdist exists offline (searched the image and the pip cache, round 6) -- and is checked only against
+        that restatement (tests/test_protocol.py:137,177).  bench.py says so in `config.workload` whenever the hf4 rule is what ran."""
         self.cfg, self.weights = cfg, weights
         self.config = _Cfg(cfg)
         self.device = torch.device(device)

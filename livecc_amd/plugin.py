@@ -74,22 +74,24 @@ def apply_livecc_amd_kernel_to_qwen2_vl(rms_norm: bool = True, layer_norm: bool 
     if rms_norm:
         class LccRMSNorm(_SAVED["Qwen2VLRMSNorm"]):
             def forward(self, hidden_states):
-                x = hidden_states.contiguous()
-                return ops.rmsnorm(x.view(-1, x.shape[-1]), self.weight, self.variance_epsilon).view_as(x)
+                # inference plugins: the native ops carry no autograd formula (torch.ops.livecc_amd.* refuse a tensor that would record a
+                # graph), so parameters and activations are detached -- under generate()'s no_grad() that is a no-op
+                x = hidden_states.detach().contiguous()
+                return ops.rmsnorm(x.view(-1, x.shape[-1]), self.weight.detach(), self.variance_epsilon).view_as(x)
         m.Qwen2VLRMSNorm = LccRMSNorm
 
     if layer_norm:
         class LccLayerNorm(torch.nn.LayerNorm):
             def forward(self, x):
-                x = x.contiguous()
-                return ops.layernorm(x.view(-1, x.shape[-1]), self.weight, self.bias, self.eps).view_as(x)
+                x = x.detach().contiguous()
+                return ops.layernorm(x.view(-1, x.shape[-1]), self.weight.detach(), self.bias.detach(), self.eps).view_as(x)
         m.LayerNorm = LccLayerNorm
 
     if swiglu:
         class LccMLP(_SAVED["Qwen2MLP"]):
             def forward(self, x):
-                g = self.gate_proj(x).contiguous()
-                u = self.up_proj(x).contiguous()
+                g = self.gate_proj(x).detach().contiguous()
+                u = self.up_proj(x).detach().contiguous()
                 return self.down_proj(ops.swiglu(g.view(-1, g.shape[-1]), u.view(-1, u.shape[-1])).view_as(g))
         m.Qwen2MLP = LccMLP
 
