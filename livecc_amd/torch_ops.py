@@ -54,10 +54,28 @@ def try_load():
         return None
 
 
+_WRAPPED: dict = {}
+
+
 def op(name: str):
-    """The registered op `name` when the dispatcher path is on, else None; counts the call."""
+    """The registered op `name` when the dispatcher path is on, else None; counts the call.  Errors keep the binding's contract: a failed
+    TORCH_CHECK / a non-zero `lcc_*` status surfaces as `LccError` (a RuntimeError), exactly as through ctypes; a CPU tensor is refused
+    by the dispatcher itself (NotImplementedError: no CPU kernel is registered)."""
     ns = try_load()
     if ns is None:
         return None
     CALLS[name] += 1
-    return getattr(ns, name)
+    fn = _WRAPPED.get(name)
+    if fn is None:
+        from . import _lib
+        raw = getattr(ns, name)
+
+        def fn(*args, _raw=raw):
+            try:
+                return _raw(*args)
+            except NotImplementedError:
+                raise
+            except RuntimeError as e:
+                raise _lib.LccError(str(e).split("\nException raised from")[0]) from None
+        _WRAPPED[name] = fn
+    return fn

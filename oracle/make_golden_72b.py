@@ -2,6 +2,9 @@
 BASELINE.json configs[4] (Qwen2-VL-72B shapes, LLM Linear weights as OCP e4m3 + fp32 row scales).
 
     python oracle/make_golden_72b.py [--layers N] [--frames T] [--out PATH] [--profile]      (build container: 62 GB of host RAM, 8 cores: ~40 min)
+    python oracle/make_golden_72b.py --variant decisive      -> tests/golden/qwen2vl72b_fp8_decisive.npz (round 6: the `decisive` seeded weights of
+    livecc_amd/weights.py -- embedding-aligned lm_head -- so that configs[4] has greedy tokens DECIDED by the model on every step: with the
+    i.i.d. weights of the fixture above HF's own top-1 margin is inside its bf16 noise at 72B and no step is decided)
     (--profile also writes tests/golden/qwen2vl72b_fp8_depth_profile.npz: the residual stream of both dtypes after every 4th layer at 4 prompt
     rows x 512 hidden dims + the all-dims rms(bf16 - fp32) of every layer -- the depth profile of the reference's own error)
 
@@ -40,6 +43,8 @@ from oracle.make_golden_7b_long import pack, sample_ids  # noqa: E402
 SEED_IN, T, H, W = 1234, 6, 392, 728
 N_FORCED, SEED_W = 4, 0
 PATH = os.path.join(ROOT, "tests", "golden", "qwen2vl72b_fp8_full_depth.npz")
+PATH_DECISIVE = os.path.join(ROOT, "tests", "golden", "qwen2vl72b_fp8_decisive.npz")
+VARIANT = "tiled"          # --variant decisive: embedding table + lm_head of the decisive synthetic model (the layers are the same seeded tiles)
 # depth profile (--profile): the residual stream after every PROFILE_EVERY-th decoder layer, both dtypes, at the last PROFILE_ROWS prompt rows x
 # PROFILE_DIMS seeded hidden dims -- where along the 80 layers does an implementation's error against the fp32 truth build up?
 PROFILE_PATH = os.path.join(ROOT, "tests", "golden", "qwen2vl72b_fp8_depth_profile.npz")
@@ -84,7 +89,7 @@ def build_shell(cfg1, dtype):
             name = _normalise_hf_key(k)
             if ".layers." in name and "visual" not in name:
                 continue
-            p.copy_(_quantised(name, synthetic_param(name, shapes, SEED_W, "cpu")).to(dtype))
+            p.copy_(_quantised(name, synthetic_param(name, shapes, SEED_W, "cpu", variant=VARIANT)).to(dtype))
         for name, buf in m.named_buffers():
             if "inv_freq" in name:
                 dim = buf.numel() * 2
@@ -101,7 +106,7 @@ def fill_layer(layers, cfg_full, l):
         named = [dict(layer.named_parameters()) for layer in layers]
         for k in named[0]:
             name = f"language_model.layers.{l}.{k}"
-            w = _quantised(name, synthetic_param(name, shapes, SEED_W, "cpu"))
+            w = _quantised(name, synthetic_param(name, shapes, SEED_W, "cpu", variant=VARIANT))
             for nm in named:
                 nm[k].copy_(w.to(nm[k].dtype))
 
@@ -177,7 +182,7 @@ def generate(n_layers=None, frames_t=T, path=PATH, profile_path=None):
             h = state[dt][0][:, -N_FORCED:]
             logits[dt] = m.lm_head(m.model.language_model.norm(h))[0].float()
     l16, l32 = logits[torch.bfloat16], logits[torch.float32]
-    out = dict(meta=np.asarray([SEED_IN, frames_t, H, W, N_FORCED, SEED_W, L], dtype=np.int64), sample_ids=sid.numpy(), ids=ids, tokens=forced,
+    out = dict(meta=np.asarray([SEED_IN, frames_t, H, W, N_FORCED, SEED_W, L], dtype=np.int64), variant=np.asarray(VARIANT), sample_ids=sid.numpy(), ids=ids, tokens=forced,
                grid=np.asarray(grid, dtype=np.int64), hf_bf16_argmax=l16.argmax(-1).numpy().astype(np.int64), hf_fp32_argmax=l32.argmax(-1).numpy().astype(np.int64))
     pack(out, "t0", l16, l32, sid)
     np.savez_compressed(path, **out)
@@ -196,5 +201,8 @@ if __name__ == "__main__":
     a = sys.argv[1:]
     nl = int(a[a.index("--layers") + 1]) if "--layers" in a else None
     ft = int(a[a.index("--frames") + 1]) if "--frames" in a else T
-    p = a[a.index("--out") + 1] if "--out" in a else PATH
+    if "--variant" in a:
+        VARIANT = a[a.index("--variant") + 1]
+        assert VARIANT in ("tiled", "decisive")
+    p = a[a.index("--out") + 1] if "--out" in a else (PATH_DECISIVE if VARIANT == "decisive" else PATH)
     generate(nl, ft, p, PROFILE_PATH if "--profile" in a else None)
