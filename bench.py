@@ -457,7 +457,12 @@ def live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64, 96, 112
         expected = N * n_chunks
         for sid in list(srv.streams):
             srv.remove_stream(sid)
-        del srv, model
+        # `srv.step = timed_step` closes over the bound method: a reference cycle (srv -> closure -> srv) that keeps the model -- up to
+        # 120 GB of KV slots at the long-history ladder -- alive until the cyclic collector runs; break it and collect before the next model
+        srv.step = inner
+        del srv, model, timed_step, inner
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         a = np.sort(np.asarray(lat)) if lat else np.asarray([float("inf")])
         busy = float(sum(d for d, _ in steps))
@@ -1015,6 +1020,8 @@ def main():
     if (args.more_configs == "on" or (args.more_configs == "auto" and want_live)) and not args.standin:
         try:
             del model
+            import gc
+            gc.collect()          # the child processes (72B fp8: 73 GB of weights + its KV) need the HBM the parent's models held
             torch.cuda.empty_cache()
             more = more_configs(args)
         except Exception as e:

@@ -42,6 +42,9 @@ LCC_DEVICE float xor32_sum(float x) {
 
 __device__ unsigned int lcc_attn32_zero_page[256];
 
+// (Round 6, measured null and removed: a static `s_setprio 1` for the younger or for the older half of the waves -- MI355X_MICROARCH "Two
+// waves per SIMD" item 4 -- 416-421 us either way at 8 x 386 rows x 6.2k keys, tower 20.8 ms either way: profiles/r06/attn_static_prio_ab.jsonl.)
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // The key loop shared by the LLM prefill kernel (D = 128) and the ViT kernel (D = 80): software pipeline, one key tile per REGION.
 // The softmax of tile t (vector pipe: ~70 VALU instructions) is issued next to the MFMAs that do not depend on it -- the P . V of tile
