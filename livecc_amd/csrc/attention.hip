@@ -578,17 +578,19 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
 // one wave per block; split s handles key tiles [s*per, (s+1)*per).  HBM-bound: L*512 bytes per KV head.
 // Partial (o, m, l) go to a workspace, attn_decode_combine merges the splits.
 // ------------------------------------------------------------------------------------------------
+template <bool DIRECT>
 __global__ __launch_bounds__(64) void attn_decode_kernel(
     const bf16_t* __restrict__ q, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
     bf16_t* const* __restrict__ kv_base,
     KvLayout lay, int layer, int n_q_heads, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml,
-    float scale_log2e) {
+    float scale_log2e, AttnDirect dir) {
   constexpr int D = 128, KS = 4, NQ = 1;
   const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int G = n_q_heads / lay.n_kv_heads;
-  const int slot_id = slots[b];
-  const int n = kv_len[slot_id] + 1;  // the new token's K/V were appended at index kv_len[slot] by rope_kv_append
+  const int slot_id = DIRECT ? 0 : slots[b];
+  // the new token's K/V were appended at index kv_len[slot] by rope_kv_append.  DIRECT: the host's count (kernels.h: AttnDirect)
+  const int n = DIRECT ? (b == 0 ? dir.n[0] : (b == 1 ? dir.n[1] : (b == 2 ? dir.n[2] : dir.n[3]))) : kv_len[slot_id] + 1;
   const int ntile = (n + 31) / 32;
   const int per = (ntile + nsplit - 1) / nsplit;
   const int t0 = split * per, t1 = min(ntile, t0 + per);
@@ -601,7 +603,8 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[0][ks] = ld16(qp + ks * 32 + g * 8);
   }
-  const bf16_t* base = kv_base[slot_id] + (size_t)layer * lay.layer_stride();
+  const bf16_t* base = (DIRECT ? (b == 0 ? dir.base[0] : (b == 1 ? dir.base[1] : (b == 2 ? dir.base[2] : dir.base[3]))) : kv_base[slot_id]) +
+                       (size_t)layer * lay.layer_stride();
   const bf16_t* kbase = base + (size_t)hk * lay.head_stride();
   const bf16_t* vbase = base + lay.kv_stride() + (size_t)hk * lay.head_stride();
   auto krow = [&](int key) { return kbase + (size_t)min(key, n - 1) * D; };
@@ -1020,12 +1023,17 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
 }
 
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
-                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st) {
+                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st,
+                     const AttnDirect* direct) {
   if (B <= 0) return 0;
   if (lay.head_dim != 128 || (lay.lmax & 31) || n_q_heads / lay.n_kv_heads > 16) return LCC_ERR_SHAPE;
   g_launch_counts[LC_ATTN_DECODE]++; g_launch_counts[LC_ATTN_DECODE_COMBINE]++; g_launch_counts[LC_LAST_DECODE_NSPLIT] = nsplit;
-  attn_decode_kernel<<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
-      q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128));
+  if (direct != nullptr && direct->used == B && B <= 4)
+    attn_decode_kernel<true><<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
+        q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128), *direct);
+  else
+    attn_decode_kernel<false><<<dim3(nsplit, lay.n_kv_heads, B), dim3(64), 0, st>>>(
+        q, slots, kv_len, kv_base, lay, layer, n_q_heads, nsplit, ws_o, ws_ml, scale_l2e(128), AttnDirect{});
   attn_decode_combine_kernel<<<dim3(n_q_heads, B), dim3(256), 0, st>>>(ws_o, ws_ml, out, n_q_heads,
                                                                        lay.n_kv_heads, nsplit);
   return 0;

@@ -196,7 +196,8 @@ bool decode_v2_ok(const lcc_engine* e) {
 // the 28 decoder layers of ONE decode step over B rows, v2 launch sequence.  On entry b.h / b.stats / b.cos / b.sin come from
 // decode_step_begin; on exit b.h is the residual stream after the last layer and b.stats its per-tile sums of squares (the final
 // RMSNorm runs as the prologue of the lm_head GEMV).
-int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, hipStream_t st) {
+int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_t* d_slots, int nsplit_attn, hipStream_t st,
+                         const AttnDirect* direct = nullptr) {
   const int H = e->c.hidden_size, I = e->c.intermediate_size;
   const float eps = e->c.rms_eps;
   if (e->llm_over) return fail(LCC_ERR_STATE, "per-layer input overrides are a prefill-only instrument (decode pipeline v2 carries row statistics)");
@@ -219,7 +220,7 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     const LlmLayerW& L = e->llm[l];
     DgArgs a;
     if (l == 0 || !chain) LCC_TRY(dgemv_qkv_rope(qkv_args(l), st));     // otherwise launched together with the previous layer's down_proj
-    LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st));
+    LCC_TRY(attn_decode_bf16(b.q, b.attn, d_slots, e->d_kv_len, e->d_kv_base, e->lay, l, B, e->c.n_q_heads, nsplit_attn, b.ws_o, b.ws_ml, st, direct));
     a = DgArgs(); a.W = L.o_w; a.wscale = L.o_s; a.M = B; a.N = H; a.K = e->qd; a.X = b.attn; a.ldx = e->qd; a.Hres = b.h; a.stats_out = b.stats;
     LCC_TRY(dgemv_resid(a, st));
     if (e->llm_taps) HIP_TRY(hipMemcpyAsync(e->llm_taps + (size_t)(2 * l + 1) * tap_stride, b.h, tap_bytes, hipMemcpyDeviceToDevice, st));
@@ -477,7 +478,14 @@ extern "C" int lcc_llm_decode(lcc_engine* e, int n_streams, const int32_t* slots
     if (v2) {
       LCC_TRY(decode_step_begin(d_slots, e->d_cur_tok, e->d_done, e->d_seen, e->words, e->embed, bf.h, bf.stats, e->c.hidden_size, e->d_pos,
                                 e->inv_freq, bf.cos, bf.sin, n_streams, st));
-      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, st));
+      // the step's key counts and arena pointers travel by value (kernels.h: AttnDirect; LCC_ATTN_DIRECT=0: index loads on the device)
+      static const int direct_on = [] { const char* v = getenv("LCC_ATTN_DIRECT"); return v ? atoi(v) : 1; }();
+      AttnDirect dir;
+      if (direct_on && n_streams <= 4) {
+        for (int bb = 0; bb < n_streams; ++bb) { dir.base[bb] = (const bf16_t*)e->h_kv_base[slots[bb]]; dir.n[bb] = e->h_kv_len[slots[bb]] + step + 1; }
+        dir.used = n_streams;
+      }
+      LCC_TRY(run_decode_layers_v2(e, bf, n_streams, d_slots, nsplit, st, dir.used ? &dir : nullptr));
     } else {
       LCC_TRY(seen_set(e->d_seen, e->words, e->d_cur_tok, d_slots, n_streams, 1, e->d_done, st));
       LCC_TRY(embed_gather_bf16(e->d_cur_tok, d_slots, nullptr, e->embed, nullptr, bf.h, n_streams, e->c.hidden_size, st));

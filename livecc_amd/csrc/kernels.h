@@ -140,8 +140,15 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
                       const int32_t* tile_nq, const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay,
                       int layer, int n_tiles, int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o, float* ws_ml,
                       hipStream_t st);
+// Host-known stream state of a decode step, passed BY VALUE to the decode attention (round 6): the arena pointer and the key count
+// (cached keys + the new token) of each of up to 4 rows.  The kernel then has no dependent index loads (slots[b] -> kv_len[slot], kv_base[slot]
+// -> K / V: two cross-XCD round trips in front of the first key tile).  The host knows both: lcc_llm_decode counts the steps it enqueues;
+// a stream that EOS froze on the device (`done`) has fewer keys than the host's count -- its step output is discarded anyway (the sampler
+// leaves a done slot untouched), and the rows past its length are finite bytes of the same arena.
+struct AttnDirect { const bf16_t* base[4]; int n[4]; int used = 0; };
 int attn_decode_bf16(const bf16_t* q, bf16_t* out, const int32_t* slots, const int32_t* kv_len, bf16_t* const* kv_base,
-                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st);
+                     KvLayout lay, int layer, int B, int n_q_heads, int nsplit, float* ws_o, float* ws_ml, hipStream_t st,
+                     const AttnDirect* direct = nullptr);
 void set_attn_fused_tail(int v);
 // fused decode attention: bias + M-RoPE + KV append + attention + split merge in one launch (reads the qkv GEMV's fp32 slabs)
 int attn_decode_fused_bf16(const float* qkv_part, int ns_qkv, const bf16_t* bias, const bf16_t* cs, const bf16_t* sn,
