@@ -911,11 +911,16 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
     const int fr = min((n0 >> 4) + (st >> 1), nfrag - 1);
     bsrc[q] = W + ((size_t)fr * K32 + (st & 1)) * 512 + lane * 8;
   }
+  // Round 6: activation pieces (8 rows each) that lie entirely beyond the last 16-row MFMA tile are not fetched at all -- at M = 386 the rows
+  // 400..447 of the 448-row image (6 of 56 pieces: 11 % of the activation DMA, which is 70 % of this kernel's L2 -> LDS traffic) were copies
+  // of row 385 that no MFMA reads.  Wave-uniform; the ring's waits are vmcnt(0), so the piece count per wave need not be uniform.
+  const int m_rows = (M + 15) & ~15;
   auto issue = [&](int kt, int stage) {
     u32x4* sbase = dsmem + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < A_PER_WAVE; ++q)
-      glds16((A + aoffs[q] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
+      if ((wave * A_PER_WAVE + q) * 8 < m_rows)
+        glds16((A + aoffs[q] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       if (q < nb)
@@ -927,9 +932,10 @@ __global__ __launch_bounds__(512) void gemm_tall_kernel(
   // issue port for ~60-100 cycles, and right after the barrier both waves of a SIMD are at the same point)
   auto issue_piece = [&](int kt, int stage, int q) {
     u32x4* sbase = dsmem + stage * STAGE;
-    if (q < A_PER_WAVE)
-      glds16((A + aoffs[q < A_PER_WAVE ? q : 0] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
-    else {
+    if (q < A_PER_WAVE) {
+      if ((wave * A_PER_WAVE + q) * 8 < m_rows)
+        glds16((A + aoffs[q < A_PER_WAVE ? q : 0] + kt * BK), lds_addr(sbase + (wave * A_PER_WAVE + q) * 64));
+    } else {
       const int qq = min(q - A_PER_WAVE, nb - 1);
       glds16((bsrc[qq] + (size_t)kt * 1024), lds_addr(sbase + A_UNITS + (st0 + qq) * 64));
     }
@@ -1187,7 +1193,9 @@ static void launch_tall(const GemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_tall_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  static const int sched = [] { const char* v = getenv("LCC_TALL_SCHED"); return v ? atoi(v) : 0; }();   // 0 compiler order, 1 pinned, 2 pinned + spread DMA
+  // 0 compiler order, 1 pinned (default since round 6: 127.6 vs 131.6-132.6 us at M = 386 on N(0,1) activations, A/B/A/B, bit-identical --
+  // profiles/r06/m386_gemms_tall_sched_ab.jsonl; before the LDS-DMA went into inline asm the compiler's order had been the faster one), 2 pinned + spread DMA
+  static const int sched = [] { const char* v = getenv("LCC_TALL_SCHED"); return v ? atoi(v) : 1; }();
   if (sched == 2)
     gemm_tall_kernel<EPI, 2><<<dim3((a.N + 159) / 160), dim3(512), lds, st>>>(a.A, a.lda, a.W, a.bias, a.residual, a.ldr, a.C, a.ldc, a.M, a.N, a.K);
   else if (sched == 1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Target of the rocprofv3 PMC passes (tools/run_profiles.sh): launches ONLY the dominant kernel of the bench -- the decode
+"""Target of the rocprofv3 PMC passes (tools/r6_gpu_calls.sh pmc_gemv; earlier rounds: tools/archive/run_profiles.sh): launches ONLY the dominant kernel of the bench -- the decode
 gate/up weight-streaming GEMV at LiveCC-7B shapes (packed weights, M = 1; the v2 kernel with the RMSNorm prologue, then the round-1
 kernel) -- a few times over rotating weight buffers
 (> 256 MiB Infinity Cache in total), so that the per-dispatch FETCH_SIZE / WRITE_SIZE counters can be read per launch."""
@@ -39,7 +39,7 @@ if "--gemm" in sys.argv:
     sys.exit(0)
 if "--gemv-rows" in sys.argv:
     # the weight-streaming gate/up GEMV (+ SwiGLU) at M = 8 (one activation fragment per weight fragment) and M = 32 / 64 (MG = 2 / 4):
-    # what makes the multi-fragment kernel slower per byte (tools/gpu_call.sh pmc_gemv)
+    # what makes the multi-fragment kernel slower per byte (tools/archive/gpu_call.sh pmc_gemv)
     ws = [ops.pack_weight((torch.randn(2 * I, H, device=dev) * 0.02).to(torch.bfloat16)) for _ in range(3)]
     for M in (8, 32, 64):
         x = torch.randn(M, H, device=dev).to(torch.bfloat16)

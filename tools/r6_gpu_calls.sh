@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round-6 GPU calls, one recipe each:   gpurun --timeout N -- 'bash tools/r6_gpu_calls.sh <recipe>'
+# Every recipe writes under gpurun_out/r6_<recipe>/; what is judged is copied into profiles/r06/ afterwards.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}; RECIPE=${1:-help}; O=$R/gpurun_out/r6_$RECIPE; mkdir -p $O; cd $R
+export TMPDIR=/tmp LCC_PARITY_OUT=$O
+QUIET="--cpu-baseline off --parity off --share8 off --live2fps off --more-configs off"
+step() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(json.dumps(dict($1, tokens_per_s=d['value'], ms_per_replay=d['ms_per_step'], decode_step_us=r['decode_step']['avg_step_us'], us_per_layer=r['decode_step']['us_per_layer'], gate_up_us=r['avg_launch_us'])))"; }
+case $RECIPE in
+tier)          # the whole GPU tier as the driver runs it (pytest.ini adds -rs) + smoke()
+  ( time python -m pytest tests/ -x -q -m gpu 2>&1 | tail -40 ) > $O/pytest_gpu_tail.txt 2>&1
+  ( python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > $O/smoke_tail.txt 2>&1
+  tail -45 $O/pytest_gpu_tail.txt; cat $O/smoke_tail.txt ;;
+bench)         # the driver's default line + rocprofv3 kernel stats / step breakdown of a short run of the same command
+  ( time python bench.py > $O/bench_default_n1.json 2> $O/bench_default_n1.err ) 2> $O/bench_time.txt
+  cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python $R/bench.py --steps 1 --warmup 1 --no-prefetch $QUIET > $O/bench_under_rocprof.json 2> $O/rocprof.err
+  cd $R; cp $O/prof/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
+  python tools/trace_breakdown.py $(ls $O/prof/*kernel_trace.csv | head -1) > $O/step_breakdown_1streams_noprefetch.json 2> $O/breakdown.err
+  rm -rf $O/prof; tail -c 600 $O/bench_default_n1.json; cat $O/bench_time.txt; head -8 $O/bench_kernel_stats.csv ;;
+pmc)           # T2 evidence: MfmaUtil of all four LLM GEMMs at M = 3088 / 386 -> profiles/roofline_traffic.json (copy it back!)
+  cd /tmp; timeout 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pmc -o g -- python $R/tools/r6_pmc_llm_gemms.py $O/pmc/manifest.json > $O/pmc.log 2>&1
+  cd $R; python tools/r6_summarize_llm_gemm_pmc.py $O/pmc > $O/llm_gemm_mfma_util.json 2> $O/summ.err
+  cp profiles/roofline_traffic.json $O/roofline_traffic.json; find $O/pmc -name "*.csv" -size +2000k -delete
+  python -c "import json; d=json.load(open('$O/llm_gemm_mfma_util.json')); print({k: v['mfma_util_pct'] for k, v in d['per_gemm'].items()}, d['per_layer'])"; tail -3 $O/summ.err ;;
+pmc_gemv)      # HBM bytes per launch of the dominant kernel (FETCH_SIZE / WRITE_SIZE in separate passes) -> roofline_traffic.json
+  cd /tmp
+  for C in FETCH_SIZE WRITE_SIZE; do timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/p/pmc_$C -o gemv -- python $R/tools/pmc_target.py > $O/pmc_$C.log 2>&1; done
+  cd $R; python tools/summarize_pmc.py $O/p > $O/roofline_traffic_gemv.json 2> $O/summ.err; find $O/p -name "*.csv" -size +2000k -delete
+  python -c "import json; d=json.load(open('$O/roofline_traffic_gemv.json')); print(d['gemv_gate_up_hbm_bytes_per_launch'], d['algorithmic_bytes_per_launch'], d['kernel_source_sha16'])" ;;
+attn_map)      # XCD-chunked block order / (row, head) pair packing of the 32x32x16 attention kernels, A/B/A/B
+  for cfg in "0 0" "1 0" "0 1" "1 1" "0 0" "1 1"; do set -- $cfg
+    LCC_ATTN32_XCD=$1 LCC_ATTN32_PACK=$2 python tools/bench_attn.py --only32 2>/dev/null | sed "s/^{/{\"xcd\": $1, \"pack\": $2, /" >> $O/attn_map_ab.jsonl
+    LCC_ATTN32_XCD=$1 python tools/r5_tower.py "xcd$1" >> $O/tower_xcd_ab.jsonl 2>/dev/null; done
+  cat $O/attn_map_ab.jsonl $O/tower_xcd_ab.jsonl ;;
+attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
+  for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
+  cat $O/attn_direct_ab.jsonl ;;
+attn_tps)      # key tiles per split of the decode attention with the split cap raised
+  for cfg in "4 64" "2 128" "3 128" "4 64" "2 128" "3 128"; do set -- $cfg
+    LCC_ATTN_TPS=$1 LCC_ATTN_MAXSPLIT=$2 python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "tps=$1, maxsplit=$2" >> $O/attn_tps_maxsplit_ab.jsonl; done
+  cat $O/attn_tps_maxsplit_ab.jsonl ;;
+tall)          # one-chunk GEMMs: tall kernel schedule A/B
+  for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
+rccl)          # can RCCL run two ranks on the box's one GPU?
+  timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_direct attn_tps tall rccl" ;;
+esac
