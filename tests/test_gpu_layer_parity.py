@@ -302,10 +302,15 @@ def test_qwen2vl_72b_fp8_full_depth_against_the_committed_hf_logits(dev):
         recd["argmax_equal_bf16"] += int(own == int(gd["hf_bf16_argmax"][k]))
         mor = float(top2[0] - top2[1]) / float(gd["t0_rms_err_bf16_full_vocab"][k])
         recd["margin_over_rms_err"].append(round(mor, 1))
-        if mor > 8.0:
+        # Through 80 fp8 layers the reference's own bf16 error (rms 0.33-0.37 of a logit scale of 8.6-9.6) eats most of the margin the decisive
+        # head has at 7B (13-60 x noise): here HF fp32's top-1 / top-2 margin is 1.6-5.1 x rms(HF_bf16 - fp32) on the four steps -- yet HF bf16,
+        # HF fp32 and the id the head's permutation predicts for the current token agree on all four.  A step counts as decided at > 3 x rms
+        # (~2 sigma of the difference of two logits: 3 of the 4 steps); the fourth (1.6 x) is reported, not asserted.
+        if mor > 3.0:
             recd["decided"] += 1
             recd["decided_equal"] += int(own == want)
+    assert np.array_equal(gd["hf_bf16_argmax"], gd["hf_fp32_argmax"]), "the fixture's two HF runs agree on every step's token"
     record("qwen2vl72b_fp8_decisive_vs_committed_golden", recd)
     print("72B fp8, 80 layers, decisive weights:", recd)
-    assert recd["decided"] >= 1 and recd["decided_equal"] == recd["decided"], recd
+    assert recd["decided"] >= 3 and recd["decided_equal"] == recd["decided"], recd
     assert max(recd["rms_ratio"]) <= 1.25, recd
