@@ -926,6 +926,8 @@ def main():
     if share_on:
         if args.standin:
             def make_model(streams):
+                if os.environ.get("LCC_BENCH_FAIL_RANK") == str(rank):      # test hook: ONE rank fails while it builds its share
+                    raise RuntimeError(f"injected failure on rank {rank}")
                 return StandInModel(cfg)
         else:
             def make_model(streams):

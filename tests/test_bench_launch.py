@@ -63,6 +63,18 @@ def test_gpus_8_runs_the_north_star_job_shape_on_gloo():
     assert out["value_no_prefetch"] is not None and out["value_no_prefetch"] > 0
 
 
+@pytest.mark.timeout(300)
+def test_one_failing_rank_does_not_hang_the_job():
+    """a rank that throws while it builds its 8-stream share (HBM, first replay) used to leave the healthy ranks blocked in
+    the share's next collective for ever.  The ranks now agree on a success flag before the first collective of the share: every rank
+    leaves with an error block and the main line is still printed."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=dict(_env(), LCC_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "error" in out["configs2"] and out["configs2"]["ranks_failed"] == 1
+
+
 @pytest.mark.timeout(120)
 def test_launcher_world_size_mismatch_is_refused():
     env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
