@@ -1004,9 +1004,9 @@ def main():
         try:
             del model
             torch.cuda.empty_cache()
-            live = live2fps(cfg, arena, dev, args, protocol, ladder=(8, 32, 64, 96, 112, 128))
+            live = live2fps(cfg, arena, dev, args, protocol, ladder=(8, 64, 96, 112, 128))
             try:      # capacity @ history: the same ladder with 22k keys already cached per stream (a stream that has been live for a minute)
-                lh = live2fps(cfg, arena, dev, args, protocol, ladder=(8, 16, 32, 48, 64), history_keys=22000)
+                lh = live2fps(cfg, arena, dev, args, protocol, ladder=(16, 32, 48, 64), history_keys=22000)
                 live["at_long_history"] = dict(capacity_streams_under_deadline=lh["capacity_streams_under_deadline"], ladder=lh["ladder"],
                                                       history_keys_at_join=lh["history_keys_at_join"], history_keys_at_end=lh["history_keys_at_end"])
                 live["capacity_at_history"] = {f"{live['history_keys_at_end']} keys": live["capacity_streams_under_deadline"],
