@@ -13,6 +13,9 @@
 // (max / sum / rescale factor) are lane-local plus two cross-lane steps (xor 16, 32), P feeds the second
 // MFMA directly from registers (the MFMA row->key map is permuted so a lane ends with 8 consecutive keys),
 // and no LDS is used at all: every operand goes HBM/L2 -> VGPR -> MFMA once.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -628,6 +631,10 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
   }
 }
 
+// (Round 6, measured slower and removed: a multi-wave form -- 8 waves per block sharing a key range, merged through LDS, so that 8 / 16 key splits
+// instead of ~51 leave few enough partials to merge them in the o-projection's prologue instead of a combine launch.  Decode step 2930 -> 3134 us
+// with 8 splits (32 blocks), 3012 with 16, 3390 with 4: a CU pulls ~35 GB/s of K / V however many waves it runs, so the 13.4 MB of a launch
+// need all 204 CUs' worth of one-wave blocks -- and with it the 51 partials.  profiles/r06/decode_attn_multiwave_ab.jsonl.)
 // grid = (Hq, B), 256 threads = 8 split groups x 32 lanes (4 consecutive d each).  Group q merges splits q, q+8, ...
 // with all its loads in flight at once; the 8 partial (m, num, den) triples are merged through LDS.
 __global__ __launch_bounds__(256) void attn_decode_combine_kernel(
