@@ -227,9 +227,10 @@ int run_decode_layers_v2(lcc_engine* e, const LlmBuffers& b, int B, const int32_
     a = DgArgs(); a.W = L.gate_up_w; a.wscale = L.gate_up_s; a.M = B; a.N = 2 * I; a.K = H; a.H = b.h; a.stats = b.stats; a.n_stat = H / 16; a.norm_w = L.post_norm;
     a.eps = eps; a.C = b.act; a.ldc = I;
     const bool prof = e->prof_on && l == e->c.n_layers / 2 && 2 * (e->prof_n + 1) <= (int)e->prof_ev.size();   // one sample per step
-    if (prof) HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n], st));
+    // the sampled launch carries its events on the dispatch (kernel begin / end timestamps: kernels.h)
+    if (prof) dgemv_attach_events_to_next_swiglu(e->prof_ev[2 * e->prof_n], e->prof_ev[2 * e->prof_n + 1]);
     LCC_TRY(dgemv_norm_swiglu(a, st));
-    if (prof) { HIP_TRY(hipEventRecord(e->prof_ev[2 * e->prof_n + 1], st)); e->prof_n++; }
+    if (prof) e->prof_n++;
     a = DgArgs(); a.W = L.down_w; a.wscale = L.down_s; a.M = B; a.N = H; a.K = I; a.X = b.act; a.ldx = I; a.Hres = b.h; a.stats_out = b.stats;
     if (chain && l + 1 < e->c.n_layers) {
       const unsigned target = ++e->chain_epoch[l] * (unsigned)(H / 16);     // monotonic counter: every launch adds H/16 arrivals

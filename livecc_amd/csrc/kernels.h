@@ -204,6 +204,10 @@ int dgemv_qkv_rope(const DgArgs& a, hipStream_t st);      // [RMSNorm] q|k|v Lin
 int set_resid_waves(int mode);   // 0: 8-wave blocks, 1: 16 waves for bf16 weights with K >= 8192 (default), 2: 16 waves always; returns the old mode
 int dgemv_resid(const DgArgs& a, hipStream_t st);         // o_proj / down_proj [residual add in place + per-tile sums of squares]
 int dgemv_norm_swiglu(const DgArgs& a, hipStream_t st);   // [RMSNorm] gate/up Linear [SwiGLU]
+// Live timing of the dominant kernel (round 6): the NEXT dgemv_norm_swiglu launch of this host thread carries the two events ON THE DISPATCH
+// (hipExtLaunchKernel: start = the kernel's begin timestamp, stop = its end -- what rocprofv3 reports) instead of being bracketed by
+// hipEventRecord calls, whose pair also times ~3.5 us of dispatch gaps around a 44-us kernel (47.3 vs 43.9 us, profiles/r06).
+void dgemv_attach_events_to_next_swiglu(hipEvent_t start, hipEvent_t stop);
 // chained launch: down_proj of layer l + q/k/v of layer l+1, the consumer's weights prefetched under the producer (decode_v2.hip)
 int dgemv_chain_capacity();
 int dgemv_down_qkv(const DgArgs& down, const DgArgs& qkv, unsigned* flag, unsigned target, unsigned* err, hipStream_t st);
