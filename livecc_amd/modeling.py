@@ -281,11 +281,20 @@ class LiveCCForConditionalGeneration:
         The frames must not be modified in between.  Results are bit-identical to the un-prefetched call.
         Thread-safe: the whole call (ViT, prefill, every decode step, the token read-back) runs under the model's engine lock."""
         with self._lock:
-            return self._generate_batch_locked(requests, repetition_penalty, logits_processor, max_new_tokens, force_length, eos_token_id,
-                                               output_logits, output_scores, do_sample, temperature, top_k, top_p, seed, prefetch, teacher_tokens)
+            created: List[StreamState] = []          # stream slots this call allocated for requests without a state
+            try:
+                return self._generate_batch_locked(requests, repetition_penalty, logits_processor, max_new_tokens, force_length, eos_token_id,
+                                                   output_logits, output_scores, do_sample, temperature, top_k, top_p, seed, prefetch, teacher_tokens,
+                                                   created)
+            except BaseException:
+                # a failed call gives its fresh slots back AT ONCE: the exception's traceback keeps this frame's StreamState objects alive for as
+                # long as the caller holds the exception, and a caller that retries (StreamServer's per-stream isolation) needs the slots now
+                for st in created:
+                    st.release()
+                raise
 
     def _generate_batch_locked(self, requests, repetition_penalty, logits_processor, max_new_tokens, force_length, eos_token_id, output_logits,
-                               output_scores, do_sample, temperature, top_k, top_p, seed, prefetch, teacher_tokens) -> List[GenerateOutput]:
+                               output_scores, do_sample, temperature, top_k, top_p, seed, prefetch, teacher_tokens, created) -> List[GenerateOutput]:
         cfg, eng = self.cfg, self.engine
         if eos_token_id is None:
             eos_ids = list(self.eos_token_ids)
@@ -311,7 +320,10 @@ class LiveCCForConditionalGeneration:
         states, ids_new, pos3, clips, slots = [], [], [], [], []
         full_ids = []
         for rq in requests:
-            st = rq.get("state") or self.new_stream()
+            st = rq.get("state")
+            if st is None:
+                st = self.new_stream()
+                created.append(st)
             if st.released or st.model is not self:
                 raise ValueError("past_key_values: this stream state was released (its KV slot may serve another stream) or belongs to "
                                  "another model")

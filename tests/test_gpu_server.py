@@ -273,3 +273,27 @@ def test_an_error_in_one_stream_is_isolated_by_per_stream_retries(dev, native):
     b = [(s, t, st) for i, s, t, st in broken if i == "b"]
     assert len(b) == 2 and "released" in b[1][2]["error"] and b[1][2]["ended"]
     assert len(native._free_slots) == native.engine.max_slots
+
+
+def test_a_failed_generate_batch_gives_its_fresh_slots_back_at_once(dev, native):
+    """A call that allocated stream slots for requests without a state and then failed must not keep them until the caller lets go of the
+    exception (its traceback holds the call's frame): StreamServer's per-stream retries need the slots while they handle the error."""
+    from livecc_amd import protocol
+    cfg = native.cfg
+    frames = torch.from_numpy(protocol.synth_frames(6, 56, 84, seed=3, layout="TCHW")).to(dev)
+    ids = protocol.TurnBuilder(cfg, seed=3).turn_ids(0, protocol.num_video_tokens(protocol.grid_of(6, 56, 84, cfg), cfg))
+    good = dict(input_ids=torch.from_numpy(ids), frames=frames, frames_layout="TCHW", state=None)
+    bad = dict(input_ids=torch.from_numpy(ids), state=None)                      # <|video_pad|> ids without frames: refused
+    free0 = len(native._free_slots)
+    held = None
+    try:
+        native.generate_batch([good, good, bad], max_new_tokens=2, force_length=True)
+    except ValueError as e:
+        held = e                                                                  # keep the exception (and its traceback) alive
+        assert len(native._free_slots) == free0, "the two slots allocated before the bad request are free again"
+    assert held is not None and "no frames" in str(held)
+    outs = native.generate_batch([good, good], max_new_tokens=2, force_length=True)       # and usable
+    assert len(outs) == 2
+    for o in outs:
+        o.past_key_values.release()
+    assert len(native._free_slots) == free0
