@@ -13,6 +13,15 @@
  *   - bf16 tensors are raw uint16 storage; row-major; K (inner) dimension contiguous; pointers 16-byte aligned.
  *   - return value: 0 on success, a negative lcc_status on error (shape/dtype/alignment are validated up
  *     front, never UB on a bad shape); lcc_last_error() returns the message of the calling thread.
+ *   - threads (SURVEY 8b "thread-compatible per stream-state object"; ref:demo/app.py:178 calls one model from five): the operator-level
+ *     entry points are re-entrant (they touch only their arguments).  On ONE engine, lcc_llm_prefill / lcc_llm_decode / lcc_slot_* serialise
+ *     on a mutex of that engine (one activation workspace, one meta ring, host mirrors of the slot lengths) and lcc_vit_encode on a second one
+ *     (the vision tower has its own workspace + ring and may run beside the LLM calls on another stream); the caller still orders the DEVICE
+ *     work, i.e. passes streams that respect the data flow.  The process-global lcc_debug_set_* knobs are launch-routing state: while any
+ *     thread is inside lcc_vit_encode / lcc_llm_prefill / lcc_llm_decode they return LCC_ERR_STATE (the setters that return the previous value:
+ *     -1) instead of changing the kernel family in the middle of a forward pass.
+ *   - the same operator-level entry points are registered as PyTorch custom ops (torch.ops.livecc_amd.*) by livecc_amd/csrc/torch_ops.cpp, a
+ *     separate library that only forwards to the symbols declared here.
  */
 #ifndef LIVECC_AMD_H
 #define LIVECC_AMD_H
