@@ -187,7 +187,7 @@ LCC_DEVICE void attn_loop(AttnAcc<D, NQ>& acc, KRow krow, VBlk vblk, int t0, int
 // already rotated in place; vt is the blocked-transposed V written by vit_rope_vt.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NQ>
-__global__ __launch_bounds__(256) void attn_vit_kernel(
+__global__ __launch_bounds__(256, 2) void attn_vit_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
     const int32_t* __restrict__ tile_seg, const int32_t* __restrict__ tile_q0,
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
@@ -556,7 +556,7 @@ LCC_DEVICE void attn_shared_body(
 // kernel: one block per (x, y, z) grid point, or -- vgx > 0 (the ViT launches under the grid cap, gemm.hip: g_grid_cap) -- a persistent walk over
 // the vgx x vgy virtual blocks
 template <int D, int NQ, int MODE, int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
+__global__ __launch_bounds__(NWAVE * 64, 2) void attn_shared_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
     const int32_t* __restrict__ t0a, const int32_t* __restrict__ t1a, const int32_t* __restrict__ t2a,
     const int32_t* __restrict__ t3a, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
@@ -582,7 +582,11 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_shared_kernel(
 // Partial (o, m, l) go to a workspace, attn_decode_combine merges the splits.
 // ------------------------------------------------------------------------------------------------
 template <bool DIRECT>
-__global__ __launch_bounds__(64) void attn_decode_kernel(
+// __launch_bounds__(64, 2): with one wave per SIMD allowed (512 registers) hipcc selects the AGPR form of the MFMAs and moves the score / output
+// accumulators to and from the vector registers around the softmax -- 88 v_accvgpr_read / write per key tile inside the loop (round-6 audit of
+// the .s files, tools/audit_agpr_copies.py); a minimum of two waves per SIMD caps the kernel at 256 registers (it uses 220) and the MFMAs
+// take their accumulators in VGPRs.
+__global__ __launch_bounds__(64, 2) void attn_decode_kernel(
     const bf16_t* __restrict__ q, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
     bf16_t* const* __restrict__ kv_base,
     KvLayout lay, int layer, int n_q_heads, int nsplit, float* __restrict__ ws_o, float* __restrict__ ws_ml,
@@ -738,7 +742,7 @@ LCC_DEVICE void store_sc1_f32x4(float* p, f32x4 v) {   // write-through (sc1) 16
 }
 
 template <int NS, int TAIL, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void attn_decode_fused_kernel(
+__global__ __launch_bounds__(NW * 64, 2) void attn_decode_fused_kernel(
     const float* __restrict__ qkv_part, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ cs_tab,
     const bf16_t* __restrict__ sn_tab, const int32_t* __restrict__ slots, const int32_t* __restrict__ kv_len,
     bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int B, int n_q_heads, int nsplit,

@@ -63,6 +63,17 @@ __device__ unsigned int lcc_attn32_zero_page[256];
 //
 // (Round 5, measured null and removed: reading the next region's first three V^T fragments at the end of the region before it -- no LDS
 // round trip in front of a region's first MFMAs -- 377-382 us either way at 8 x 386 rows x 6.2k keys, profiles/r05/attn_pipe_ab.txt.)
+// (Round 6, measured and removed -- both were tests of "the kernel is bound by the staging of its K / V tiles":
+//   * ROW-MAJOR stage images (every LDS-DMA instruction copies one contiguous KB of the cache -- 4 K rows / 16 V^T rows -- into an XOR-swizzled
+//     [32][256 B] / [D][64 B] image, conflict-free fragment reads, same bits) instead of the fragment-order pieces below, whose DMA gathers 64
+//     separate 16-byte chunks: 8 x 386 rows 427.8 / 429.0 us vs 431.3 / 420.4, one-shot piece 690 / 692 vs 687 / 685, tower 20.80-20.88 ms vs
+//     20.52 (8 K pieces instead of 5 there): a null; profiles/r06/attn_rowmajor_staging_ab.jsonl, tower_rowmajor_staging_ab.jsonl.
+//   * one wave per SIMD (the 7 heads of a KV head as two 4-wave blocks with a ring each): 675 vs 420 us,
+//     profiles/r06/attn_one_wave_per_simd_ab.jsonl.  NOT a clean test, found afterwards: the 4-wave instantiation was compiled in the AGPR form
+//     (see attn_gqa32_kernel) and issued 329 instructions per region against the 8-wave kernel's 185 (of which 32 v_pk_mul sit in the skipped
+//     rescale branch: 16 MFMAs, 16 fragment reads, 83 vector and ~38 scalar instructions per region and wave).  A 4-wave block with 1.8 x the
+//     instructions took 0.8 of the 8-wave block's time, so a wave alone on its SIMD runs its stream ~2.2 x faster than one that shares it:
+//     the two waves of a SIMD do not overlap their matrix and vector work, they mostly take turns.)
 template <int D, int PW, class Issue>
 LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf)[D / 16], int tb, int te, int mlim, int lim, float scale_log2e,
                                 bool active, int lane, int hh, f32x16 (&o)[(D + 31) / 32], float& m_run, float& l_run) {
@@ -184,8 +195,11 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
 //    (pair p = head_local * nq + row), instead of "wave w = head w, column = row".  With nq = 32 that is the same thing; a ragged tile
 //    (386 rows = 12 x 32 + 2) packs its 2 x 7 = 14 pairs into ONE wave instead of running seven waves with two live columns each -- 1/7
 //    of the MFMA work for 1/13 of a chunk's blocks.
+// __launch_bounds__(.., 2): never the AGPR form of the MFMAs -- the 4-wave instantiation (G <= 4) was built with 512 registers allowed and
+// copied O and the scores between AGPRs and VGPRs in every region (144 v_accvgpr_read / write on top of 115 vector instructions; round-6 audit,
+// tools/audit_agpr_copies.py); 236 VGPRs now, no copies.
 template <int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
+__global__ __launch_bounds__(NWAVE * 64, 2) void attn_gqa32_kernel(
     const bf16_t* __restrict__ q, bf16_t* __restrict__ out, const int32_t* __restrict__ tile_stream,
     const int32_t* __restrict__ tile_q0, const int32_t* __restrict__ tile_nq, const int32_t* __restrict__ tile_pos0,
     bf16_t* const* __restrict__ kv_base, KvLayout lay, int layer, int heads, float scale_log2e, int nsplit,
@@ -301,8 +315,10 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_gqa32_kernel(
 // and 3 d-tiles for O^T (the third half empty: its V^T rows 80..95 come from a zero page).  qkv = [P, 3E] with q, k rotated in place,
 // vt = V blocked-transposed [head][32-key block][80][32] (vit_rope_vt_kernel); keys past the segment end are masked, and the K rows of
 // the last (partial) tile are clamped into the segment (the next segment's rows are NOT part of this attention).
+// (the 4-wave instantiation keeps one wave per SIMD and the AGPR form: capped at 256 registers it spills 52 bytes; it is an opt-in variant,
+// LCC_VIT32_MIN_BLOCKS4, and its 118 accumulator copies per region are what made it lose to the 8-wave form in rounds 3 and 6)
 template <int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64) void attn_vit32_kernel(
+__global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 1) void attn_vit32_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const int32_t* __restrict__ grp_seg,
     const int32_t* __restrict__ grp_q0, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e, int n_groups, int xcd_chunks) {

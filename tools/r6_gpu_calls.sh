@@ -35,6 +35,23 @@ attn_map)      # XCD-chunked block order / (row, head) pair packing of the 32x32
     LCC_ATTN32_XCD=$1 LCC_ATTN32_PACK=$2 python tools/bench_attn.py --only32 2>/dev/null | sed "s/^{/{\"xcd\": $1, \"pack\": $2, /" >> $O/attn_map_ab.jsonl
     LCC_ATTN32_XCD=$1 python tools/r5_tower.py "xcd$1" >> $O/tower_xcd_ab.jsonl 2>/dev/null; done
   cat $O/attn_map_ab.jsonl $O/tower_xcd_ab.jsonl ;;
+attn_rowmajor) # RECORD of a removed variant (LCC_ATTN32_ROWMAJOR no longer exists; attn32.hip keeps the result): row-major (coalesced LDS-DMA)
+               # vs fragment-order staging of the 32x32x16 attention kernels: same bits first, then A/B/A/B
+  for m in 0 3; do LCC_ATTN32_ROWMAJOR=$m timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_vit_fused.py -q -x -k "attn or vit" 2>&1 | tail -2 | sed "s/^/rowmajor=$m: /" >> $O/attn_rowmajor_tests.txt; done
+  for m in 0 3 0 3; do
+    LCC_ATTN32_ROWMAJOR=$m python tools/bench_attn.py --only32 2>/dev/null | sed "s/^{/{\"rowmajor\": $m, /" >> $O/attn_rowmajor_ab.jsonl
+    LCC_ATTN32_ROWMAJOR=$m python tools/r5_tower.py "rowmajor$m" >> $O/tower_rowmajor_ab.jsonl 2>/dev/null; done
+  cat $O/attn_rowmajor_tests.txt $O/attn_rowmajor_ab.jsonl $O/tower_rowmajor_ab.jsonl ;;
+attn_vgprform) # decode attention after __launch_bounds__(64, 2) (VGPR-form MFMAs, no v_accvgpr copies in the key loop): correctness, the cold-cache
+               # split sweep of profiles/r06/attn_decode_split_sweep.jsonl again, and the decode step of the replay
+  timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_decode_v2.py -q -x -k "attn or decode" 2>&1 | tail -2 > $O/tests.txt
+  cd /tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o s -- python $R/tools/r6_attn_decode_splits.py > $O/sweep.log 2>&1
+  cd $R; python tools/r6_attn_decode_splits.py --reduce $(ls $O/tr/*kernel_trace.csv | head -1) > $O/attn_decode_split_sweep_vgprform.jsonl; rm -rf $O/tr
+  for i in 1 2; do python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "vgpr_form=1" >> $O/decode_step_vgprform.jsonl; done
+  python bench.py --steps 2 --warmup 1 --cpu-baseline off --parity off --share8 on --live2fps off --more-configs off 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(vgpr_form=1, tokens_per_s=d['value'], configs2_share=d['configs2_share'])))" >> $O/share8_vgprform.jsonl
+  cat $O/tests.txt $O/attn_decode_split_sweep_vgprform.jsonl $O/decode_step_vgprform.jsonl; cut -c1-900 $O/share8_vgprform.jsonl ;;
 attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
   for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
   cat $O/attn_direct_ab.jsonl ;;
@@ -46,5 +63,5 @@ tall)          # one-chunk GEMMs: tall kernel schedule A/B
   for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
 rccl)          # can RCCL run two ranks on the box's one GPU?
   timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
-*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_direct attn_tps tall rccl" ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_direct attn_tps tall rccl" ;;
 esac
