@@ -85,9 +85,15 @@ int lcc_debug_set_gemm_variant(int variant);
  * w_fp8 != 0: *tile_rows = 0 (fp8 weights route inside their own entry point), *engine_splits as for fp8 weights. */
 int lcc_debug_gemm_plan(int M, int N, int K, int epilogue, int nsplit, int w_fp8, int32_t* tile_rows, int32_t* engine_splits);
 /* attention: 0 = per-wave kernels (operands straight from L2); 1 = prefill shares K/V tiles through an LDS-DMA ring,
- * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on 32-row query tiles / 32x32x16 MFMAs
- * (csrc/attn32.hip; applies to calls with tile_rows = 32, the engine then always builds 32-row tiles) */
+ * ViT per-wave; 2 = LDS-shared for both; 3 (default) = 2 with the LLM prefill on the 32x32x16 MFMAs (csrc/attn32.hip; applies to
+ * calls with tile_rows >= 32; the engine then builds tiles of 32 or lcc_debug_attn_tile_rows() rows) */
 int lcc_debug_set_attn_variant(int variant);
+/* The tallest query tile the engine builds for the LLM prefill attention under the current variant (it takes it when that saves a
+ * round of blocks on the chip or the grid is below one round, else 32 rows), and the largest `tile_rows` that lcc_attn_prefill_bf16
+ * accepts besides 16 and 32: under variant 3 a block of the 32x32x16 kernel packs (row, head) pairs into
+ * 8 x 32 columns (4 x 32 at <= 4 query heads per KV head), i.e. 256 / G rows -- 36 for Qwen2-VL-7B (28 / 4 heads), 32 for the 72B
+ * (64 / 8); 32 otherwise.  Host logic only (no launch, no GPU); < 0 = LCC_ERR_ARG for head counts that do not divide. */
+int lcc_debug_attn_tile_rows(int n_q_heads, int n_kv_heads);
 /* 1: on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add + RMSNorm) run as the
  * TAIL of that GEMV in its last-arriving block (agent-scope release/acquire); 0 (default, measured faster): separate kernels */
 int lcc_debug_set_fused_tails(int on);
@@ -182,8 +188,9 @@ int lcc_rope_kv_append_bf16(const void* qkv_bf16, const float* qkv_partial, int 
                             const void* cos, const void* sin, const int32_t* tok_stream, const int32_t* tok_pos,
                             const int32_t* kv_len, void* const* kv_base, lcc_kv_layout lay, int layer, void* q_out, int S,
                             int n_q_heads, void* stream);
-/* Qwen2VLAttention core (Q2VL:537-556): causal GQA over the in-place cache.  A tile = up to tile_rows (16 or 32)
- * consecutive new rows of one stream: slot, first row in q, valid rows, cache index of the first row. */
+/* Qwen2VLAttention core (Q2VL:537-556): causal GQA over the in-place cache.  A tile = up to tile_rows (16, 32, or
+ * under attention variant 3 anything up to lcc_debug_attn_tile_rows()) consecutive new rows of one stream: slot, first row in q, valid
+ * rows, cache index of the first row.  LCC_ERR_SHAPE for any other tile_rows. */
 int lcc_attn_prefill_bf16(const void* q, void* out, const int32_t* tile_stream, const int32_t* tile_q0,
                           const int32_t* tile_nq, const int32_t* tile_pos0, void* const* kv_base, lcc_kv_layout lay,
                           int layer, int n_tiles, int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o,

@@ -984,16 +984,19 @@ int attn_prefill_bf16(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, 
                       int layer, int n_tiles, int n_q_heads, int tile_rows, int nsplit, int n_rows, float* ws_o, float* ws_ml,
                       hipStream_t st) {
   if (n_tiles <= 0) return 0;
-  if (lay.head_dim != 128 || (lay.lmax & 31) || (tile_rows != 16 && tile_rows != 32)) return LCC_ERR_SHAPE;
+  if (lay.head_dim != 128 || (lay.lmax & 31) || lay.n_kv_heads < 1 || n_q_heads % lay.n_kv_heads) return LCC_ERR_SHAPE;
   if (nsplit > 1 && (!ws_o || !ws_ml || nsplit > 16)) return LCC_ERR_ARG;
   const int G = n_q_heads / lay.n_kv_heads;
+  // tile_rows: 16 or 32 for every kernel; the 32x32x16 kernel also takes the taller tiles its pair packing can fill (36 rows at G = 7)
+  const bool tall32 = g_attn_variant == 3 && G <= 8 && tile_rows > 32 && tile_rows <= attn32_max_tile_rows(G);
+  if (tile_rows != 16 && tile_rows != 32 && !tall32) return LCC_ERR_SHAPE;
   const int S = nsplit > 1 ? nsplit : 1;
   // Default for prefill: the LDS-shared kernel (the G heads of a KV group fetch every K/V tile once: G x less L2/TA traffic,
   // which bounds the per-wave kernel at ~17 TB/s of 64-byte row segments) TOGETHER with the key split (which gives every SIMD
   // 2-3 waves for the dependent MFMA->softmax->MFMA chain).  g_attn_variant 0 forces the per-wave kernel.
   g_launch_counts[LC_LAST_PREFILL_NSPLIT] = S;
   if (S > 1) g_launch_counts[LC_ATTN_PREFILL_COMBINE]++;
-  if (g_attn_variant == 3 && tile_rows == 32 && G <= 8) {   // 32x32x16 MFMA kernel (attn32.hip)
+  if (g_attn_variant == 3 && tile_rows >= 32 && G <= 8) {   // 32x32x16 MFMA kernel (attn32.hip)
     g_launch_counts[LC_ATTN_PREFILL_MFMA32]++;
     if (int rc = attn_prefill32_launch(q, out, tile_stream, tile_q0, tile_nq, tile_pos0, kv_base, lay, layer, n_tiles, n_q_heads, S, ws_o,
                                        ws_ml, scale_l2e(128), st)) return rc;

@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -430,7 +432,24 @@ int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const in
   return 0;
 }
 
-// launcher: 32-row tiles only; the caller (attention.hip: attn_prefill_bf16) runs the split merge
+// Query rows per tile.  With the (row, head) pair packing a block serves nq x G pairs in NWAVE x 32 columns, so a tile may hold up to
+// NWAVE * 32 / G rows: 36 at G = 7 (252 of the 256 columns busy -- with 32-row tiles the eighth wave of every block idles, and a block's time
+// is that of its busiest SIMD either way), 42 at G = 6, 32 at G = 8 or 4.  LCC_ATTN32_TILE_ROWS (A/B, read once): 32 = the round-3..6 tiles.
+static int attn32_pack_on() {
+  static const int pack = [] { const char* v = getenv("LCC_ATTN32_PACK"); return v ? atoi(v) : 1; }();
+  return pack;
+}
+int attn32_max_tile_rows(int G) {
+  if (G < 1 || G > 8 || !attn32_pack_on()) return 32;
+  return std::min(64, ((G <= 4 ? 4 : 8) * 32) / G);
+}
+int attn32_tile_rows(int G) {
+  static const int forced = [] { const char* v = getenv("LCC_ATTN32_TILE_ROWS"); return v ? atoi(v) : 0; }();
+  const int mx = attn32_max_tile_rows(G);
+  return forced >= 16 ? std::min(forced, mx) : mx;
+}
+
+// launcher: tiles of <= attn32_max_tile_rows(G) rows; the caller (attention.hip: attn_prefill_bf16) runs the split merge
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,
                           int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st) {
@@ -445,7 +464,7 @@ int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stre
   const int S = nsplit > 1 ? nsplit : 1;
   // LCC_ATTN32_XCD / LCC_ATTN32_PACK (A/B, read once): 0 = the round-3..5 work mapping (blockIdx = tile / KV head / split; wave = head)
   static const int xcd = [] { const char* v = getenv("LCC_ATTN32_XCD"); return v ? atoi(v) : 1; }();
-  static const int pack = [] { const char* v = getenv("LCC_ATTN32_PACK"); return v ? atoi(v) : 1; }();
+  const int pack = attn32_pack_on();
   const long n_items = (long)n_tiles * lay.n_kv_heads * S;
   const dim3 grid((unsigned)(xcd ? ((n_items + 7) / 8) * 8 : n_items));
   if (G <= 4)

@@ -323,7 +323,21 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
   // prefills only (e.g. the 8 x 1114-row first turn), where the grid is several waves of blocks either way.
   // attention variant 3 (attn32.hip: 32x32x16 MFMAs, one wave = 32 rows of one head) always takes 32-row tiles.
   const bool mfma32 = get_attn_variant() == 3 && e->c.n_q_heads / e->c.n_kv_heads <= 8;
-  const int tile_rows = (mfma32 || (long)((S + 31) / 32) * e->c.n_q_heads >= 6144) ? 32 : 16;
+  // Round 6: a block of that kernel can hold 8 x 32 / G rows -- 36 at 7 heads per KV head, all eight waves busy instead of seven -- and a
+  // block's time does not depend on that (it is set by its busiest SIMD).  The taller tile is taken when it saves a ROUND of blocks on the
+  // chip, or when the grid does not fill one round anyway (a streaming chunk: fewer tiles leave room for one more key split); measured
+  // (profiles/r06/attn_tall_tiles_ab.jsonl): one chunk 73.4 -> 65 us, 8 first turns (1152 -> 1024 blocks: 5 -> 4 rounds) 142 -> 133 us,
+  // 8 chunks (416 -> 352 blocks, two rounds either way) 387 = 387 us, a 4,096-row piece (512 -> 456, two rounds) 674 -> 684 us.
+  int tile_rows = mfma32 ? 32 : ((long)((S + 31) / 32) * e->c.n_q_heads >= 6144 ? 32 : 16);
+  if (mfma32) {
+    const int tall = attn32_tile_rows(e->c.n_q_heads / e->c.n_kv_heads);
+    if (tall > 32) {
+      long t32 = 0, tt = 0;
+      for (int b = 0; b < n_streams; ++b) { t32 += (n_new[b] + 31) / 32; tt += (n_new[b] + tall - 1) / tall; }
+      const long cus = e->cu_count, b32 = t32 * e->c.n_kv_heads, bt = tt * e->c.n_kv_heads;
+      if (b32 < cus || (bt + cus - 1) / cus < (b32 + cus - 1) / cus) tile_rows = tall;
+    }
+  }
   int row = 0;
   for (int b = 0; b < n_streams; ++b) {
     const int past = e->h_kv_len[slots[b]];

@@ -129,6 +129,10 @@ int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const in
                       const int32_t* seg_start, const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads,
                       int total_blocks, float scale_log2e, hipStream_t st, int group_rows = 256);
 // LLM prefill attention on 32-row tiles / 32x32x16 MFMAs (attn32.hip); partials in the layout of attn_prefill_combine_kernel
+// query rows per tile of the 32x32x16 prefill kernel: the most a block can serve (NWAVE * 32 / G with the pair packing, else 32) and what
+// the engine builds (LCC_ATTN32_TILE_ROWS caps it)
+int attn32_max_tile_rows(int G);
+int attn32_tile_rows(int G);
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,
                           int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st);

@@ -24,6 +24,11 @@ static KvLayout to_lay(lcc_kv_layout l) { return KvLayout{l.n_layers, l.n_kv_hea
 extern "C" int lcc_debug_set_gemv_variant(int variant) { if (int kg__ = lcc_knob_guard("lcc_debug_set_gemv_variant")) return kg__; set_gemv_variant(variant); return 0; }
 extern "C" int lcc_debug_set_gemm_variant(int variant) { if (int kg__ = lcc_knob_guard("lcc_debug_set_gemm_variant")) return kg__; set_gemm_variant(variant); return 0; }
 extern "C" int lcc_debug_set_attn_variant(int variant) { if (int kg__ = lcc_knob_guard("lcc_debug_set_attn_variant")) return kg__; set_attn_variant(variant); return 0; }
+extern "C" int lcc_debug_attn_tile_rows(int n_q_heads, int n_kv_heads) {   // host logic only: no launch
+  if (n_kv_heads < 1 || n_q_heads < n_kv_heads || n_q_heads % n_kv_heads) return fail(LCC_ERR_ARG, "lcc_debug_attn_tile_rows: invalid head counts");
+  const int G = n_q_heads / n_kv_heads;
+  return (get_attn_variant() == 3 && G <= 8) ? attn32_tile_rows(G) : 32;
+}
 extern "C" int lcc_debug_gemm_plan(int M, int N, int K, int epilogue, int nsplit, int w_fp8, int32_t* tile_rows, int32_t* engine_splits) {
   if (M <= 0 || N <= 0 || K <= 0 || !tile_rows || !engine_splits) return fail(LCC_ERR_ARG, "lcc_debug_gemm_plan: invalid arguments");
   *engine_splits = gemm_tiled_num_splits(M, N, K, w_fp8 == 0);

@@ -137,7 +137,7 @@ Tensor attn_prefill(const Tensor& q, const Tensor& kv_ptrs, const Tensor& kv_buf
   TORCH_CHECK(q.dim() == 2 && q.size(1) == n_q_heads * 128, "attn_prefill: q must be [S, Hq*128]");
   const int64_t nt = tile_stream.numel();
   TORCH_CHECK(tile_q0.numel() == nt && tile_nq.numel() == nt && tile_pos0.numel() == nt, "attn_prefill: the four tile tables must have one entry per tile");
-  TORCH_CHECK((tile_rows == 16 || tile_rows == 32) && nsplit >= 1 && nsplit <= 8 && layer >= 0 && layer < n_layers, "attn_prefill: bad tile_rows / nsplit / layer");
+  TORCH_CHECK(tile_rows >= 16 && tile_rows <= 64 && nsplit >= 1 && nsplit <= 8 && layer >= 0 && layer < n_layers, "attn_prefill: bad tile_rows / nsplit / layer");
   Tensor out = at::empty_like(q), ws_o, ws_ml;
   if (nsplit > 1) {
     ws_o = at::empty({q.size(0) * n_q_heads * nsplit * 128}, q.options().dtype(at::kFloat));

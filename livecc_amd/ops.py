@@ -116,6 +116,16 @@ LAUNCH_COUNTERS = ("attn_decode", "attn_decode_combine", "attn_decode_fused", "a
                    "last_prefill_nsplit", "gemm_tall", "attn_vit32", "gemm_vh", "gemm_vit_qkv")
 
 
+def attn_tile_rows(n_q_heads: int, n_kv_heads: int) -> int:
+    """The tallest query tile the engine builds for the LLM prefill attention = the largest tile_rows attn_prefill takes besides 16 / 32
+    (lcc_debug_attn_tile_rows: host logic, no GPU): 36 at 28 / 4 heads under the default attention variant (8 x 32 packed (row, head)
+    columns per block / 7 heads), 32 at 64 / 8."""
+    rc = _lib.load().lcc_debug_attn_tile_rows(int(n_q_heads), int(n_kv_heads))
+    if rc < 0:
+        _lib.check(rc, "lcc_debug_attn_tile_rows")
+    return int(rc)
+
+
 def gemm_plan(M: int, N: int, K: int, epilogue: int = EPI_NONE, nsplit: int = 0, w_fp8: bool = False) -> Tuple[int, int]:
     """(tile_rows, engine_splits) of lcc_debug_gemm_plan: the kernel family that serves this packed-weight GEMM and the split count the
     engine's prefill asks for at this shape.  Host logic only: needs the library, not a GPU."""

@@ -95,3 +95,17 @@ def test_no_kernel_spills_to_scratch():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "check_resources.py")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-500:]
     assert p.stdout.count("vgpr=") > 50
+
+
+def test_production_attention_kernels_keep_their_accumulators_in_vgprs():
+    """hipcc selects the AGPR form of the MFMAs whenever a kernel may run one wave per SIMD, and then copies the attention accumulators to the
+    vector registers and back around every softmax (round 6: 88-144 v_accvgpr_read / write per key tile).  The kernels on the default path
+    are built with a minimum of two waves per SIMD; tools/audit_agpr_copies.py reads the gfx950 assembly (no GPU needed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_agpr_copies.py"), "attention.hip", "attn32.hip"], capture_output=True, text=True)
+    assert p.returncode == 0 and "AGPR copies inside an MFMA block" in p.stdout, p.stdout[-1500:] + p.stderr[-500:]
+    flagged = [line for line in p.stdout.splitlines() if line.startswith(("attention.hip", "attn32.hip"))]
+    for name in ("attn_decode_kernel<", "attn_decode_fused_kernel<", "attn_gqa32_kernel<", "attn_vit32_kernel<8>"):
+        assert not [line for line in flagged if name in line], (name, flagged)

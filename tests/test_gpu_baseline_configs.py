@@ -100,13 +100,19 @@ def test_prefill_attention_long_cache_vs_fp32(dev, L, S):
     try:
         for variant in (2, 3, 1, 0):
             ops.set_attn_variant(variant)
-            for tr, ns in ((16, 1), (16, 4), (32, 2), (16, 8), (32, 8), (32, 1), (32, 5)):
-                if variant == 3 and tr != 32:
-                    continue            # variant 3 = the 32-row / 32x32x16-MFMA kernel (attn32.hip)
+            tall = ops.attn_tile_rows(Hq, Hkv)      # 36 under variant 3 at 28 / 4 heads (the engine's tiles), else 32
+            unsplit = {}
+            for tr, ns in ((16, 1), (16, 4), (32, 2), (16, 8), (32, 8), (32, 1), (32, 5)) + (((tall, 1), (tall, 5)) if tall > 32 else ()):
+                if variant == 3 and tr < 32:
+                    continue            # variant 3 = the 32x32x16-MFMA kernel (attn32.hip): tiles of 32 rows and more
                 if variant in (0, 1) and (tr, ns) not in ((16, 4), (32, 8)):
                     continue
                 got = ops.attn_prefill(q, kv, 0, [(0, S, past)], Hq, tile_rows=tr, nsplit=ns)
                 _check_attn(got.view(S, Hq, D), ref, f"attn_prefill_long[L{L},S{S},v{variant},rows{tr},split{ns}]")
+                if variant == 3 and ns == 1:
+                    unsplit[tr] = got
+            if variant == 3 and tall > 32:           # a (row, head) pair sees the same key tiles in the same order whatever tile it sits in
+                assert torch.equal(unsplit[32], unsplit[tall]), "36-row tiles must reproduce the 32-row tiles bit for bit"
     finally:
         ops.set_attn_variant(ops.ATTN_DEFAULT_VARIANT)
 

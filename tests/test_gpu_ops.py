@@ -582,6 +582,28 @@ def _ref_attn_causal(q, k, v, past):
     return torch.einsum("hqk,khd->qhd", att.softmax(-1), vv)
 
 
+def test_attn_prefill_tile_rows_contract(dev):
+    """tile_rows: 16 or 32 for every kernel; under variant 3 also up to lcc_debug_attn_tile_rows (256 / G packed columns); anything else is
+    LCC_ERR_SHAPE -- never a launch over tiles the kernel cannot hold."""
+    from livecc_amd import _lib, ops
+    Hq, Hkv, D, S = 28, 4, 128, 40
+    kv = ops.KvArena(1, 1, Hkv, 256, dev)
+    q = _rand((S, Hq * D), dev, 1.0, 3)
+    assert ops.attn_tile_rows(28, 4) == 36 and ops.attn_tile_rows(64, 8) == 32 and ops.attn_tile_rows(12, 2) == 42
+    with pytest.raises(_lib.LccError):
+        ops.attn_tile_rows(28, 5)
+    for bad in (37, 48, 24, 8):
+        with pytest.raises(_lib.LccError):
+            ops.attn_prefill(q, kv, 0, [(0, S, 0)], Hq, tile_rows=bad)
+    try:
+        ops.set_attn_variant(2)
+        assert ops.attn_tile_rows(28, 4) == 32
+        with pytest.raises(_lib.LccError):
+            ops.attn_prefill(q, kv, 0, [(0, S, 0)], Hq, tile_rows=36)
+    finally:
+        ops.set_attn_variant(ops.ATTN_DEFAULT_VARIANT)
+
+
 @pytest.mark.parametrize("Hq,Hkv", [(2, 1), (7, 1), (28, 4), (12, 2), (8, 1)])
 def test_rope_append_prefill_decode_attention(dev, Hq, Hkv, attn_variant):
     """M-RoPE apply + KV append (bit-level vs HF's bf16 op sequence), then prefill and decode attention over the cache."""
@@ -612,7 +634,9 @@ def test_rope_append_prefill_decode_attention(dev, Hq, Hkv, attn_variant):
         assert torch.equal(kv.k_view(slot, layer)[:, :past + S].float(), K.transpose(0, 1)), "K cache append"
         assert torch.equal(kv.v_view(slot, layer)[:, :past + S].float(), V.transpose(0, 1)), "V cache append (blocked-transposed)"
         ref = _ref_attn_causal(q_ref, K, V, past)
-        for tr, ns in ((32, 1), (16, 1), (16, 3), (32, 2)):
+        # the engine's own tile height (36 rows at 7 heads per KV head under variant 3: (row, head) pairs fill the 8 x 32 columns of a block)
+        tall = ops.attn_tile_rows(Hq, Hkv)
+        for tr, ns in ((32, 1), (16, 1), (16, 3), (32, 2)) + (((tall, 1), (tall, 2)) if tall > 32 else ()):
             got = ops.attn_prefill(q_got, kv, layer, [(slot, S, past)], Hq, tile_rows=tr, nsplit=ns)
             _check_attn(got.view(S, Hq, D), rb(ref), f"attn_prefill[Hq{Hq},turn{turn},rows{tr},split{ns}]")
         past += S

@@ -5,7 +5,7 @@ of the MFMAs whenever a kernel may have one wave per SIMD (__launch_bounds__ <= 
 for a GEMM (the accumulators are zeroed once and read once), expensive for attention, whose softmax reads the scores and rescales O in the
 vector registers every key tile.  No GPU needed.
 
-    python tools/audit_agpr_copies.py [--all]        (default: only kernels with copies inside an MFMA block)
+    python tools/audit_agpr_copies.py [file.hip ...] [--all]        (default: every source; only kernels with copies inside an MFMA block)
 """
 import collections
 import os
@@ -53,16 +53,19 @@ def audit(text):
 
 def main():
     show_all = "--all" in sys.argv
-    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    srcs = [os.path.join(CSRC, a) if not os.path.isabs(a) and not os.path.exists(a) else a for a in args] or \
+        sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     bad = 0
-    with tempfile.TemporaryDirectory() as td:
-        for src in srcs:
-            rows = audit(asm_of(src, os.path.join(td, os.path.basename(src) + ".s")))
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as td, ThreadPoolExecutor(max_workers=4) as pool:
+        texts = list(pool.map(lambda src: asm_of(src, os.path.join(td, os.path.basename(src) + ".s")), srcs))
+        for src, text in zip(srcs, texts):
+            rows = audit(text)
             names = subprocess.run(["c++filt"], input="\n".join(r["symbol"] for r in rows), capture_output=True, text=True).stdout.splitlines()
             for r, n in zip(rows, names):
                 n = re.sub(r"\(.*", "", n)
-                # copies beside the MFMAs of a block that also zeroes / drains the accumulators (a GEMM's first / last block) are expected:
-                # report a block only when its copies outnumber what one init or one drain of its MFMAs' accumulators needs
+                # copies in the entry block (accumulators zeroed before the loop) are expected; a GEMM's drain block holds no MFMA
                 hot = [h for h in r["mfma_blocks_with_copies"] if h["block"] != "entry"]
                 if hot:
                     bad += 1

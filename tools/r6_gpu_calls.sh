@@ -52,6 +52,14 @@ attn_vgprform) # decode attention after __launch_bounds__(64, 2) (VGPR-form MFMA
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(vgpr_form=1, tokens_per_s=d['value'], configs2_share=d['configs2_share'])))" >> $O/share8_vgprform.jsonl
   cat $O/tests.txt $O/attn_decode_split_sweep_vgprform.jsonl $O/decode_step_vgprform.jsonl; cut -c1-900 $O/share8_vgprform.jsonl ;;
+attn_tall)     # query tiles of 8 x 32 / G rows (36 at 7 heads per KV head: the pair packing fills all eight waves) vs 32-row tiles
+  timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_baseline_configs.py tests/test_gpu_e2e.py tests/test_gpu_golden.py tests/test_gpu_torch_ops.py -q -x 2>&1 | tail -3 > $O/tests.txt
+  for i in 1 2; do python tools/bench_attn.py --only32 2>/dev/null >> $O/attn_tall_tiles_ab.jsonl; done
+  for r in 32 0 32 0; do LCC_ATTN32_TILE_ROWS=$r python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(json.dumps(dict(tile_rows_env=$r, tokens_per_s=d['value'], ms_per_replay=d['ms_per_step'], decode_step_us=r['decode_step']['avg_step_us'], prefill=r.get('chunk_prefill'))))" >> $O/replay_tall_tiles_ab.jsonl; done
+  cat $O/tests.txt $O/attn_tall_tiles_ab.jsonl; cut -c1-400 $O/replay_tall_tiles_ab.jsonl ;;
 attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
   for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
   cat $O/attn_direct_ab.jsonl ;;
@@ -63,5 +71,5 @@ tall)          # one-chunk GEMMs: tall kernel schedule A/B
   for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
 rccl)          # can RCCL run two ranks on the box's one GPU?
   timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
-*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_direct attn_tps tall rccl" ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall attn_direct attn_tps tall rccl" ;;
 esac
