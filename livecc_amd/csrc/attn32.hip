@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_gqa32_kernel(
 // (the 4-wave instantiation keeps one wave per SIMD and the AGPR form: capped at 256 registers it spills 52 bytes; it is an opt-in variant,
 // LCC_VIT32_MIN_BLOCKS4, and its 118 accumulator copies per region are what made it lose to the 8-wave form in rounds 3 and 6)
 template <int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 1) void attn_vit32_kernel(
+__global__ __launch_bounds__(NWAVE * 64, 2) void attn_vit32_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const int32_t* __restrict__ grp_seg,
     const int32_t* __restrict__ grp_q0, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
     const int32_t* __restrict__ seg_blk_start, int heads, int total_blocks, float scale_log2e, int n_groups, int xcd_chunks) {
@@ -353,22 +353,20 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 1) void attn_vit32_ker
 #pragma unroll
     for (int ks = 0; ks < KP; ++ks) settle_load(qf[ks]);     // before the first LDS-DMA piece (common.h: glds16)
   }
-  const bf16_t* zp = reinterpret_cast<const bf16_t*>(lcc_attn32_zero_page) + lane * 8;
-  const bf16_t* pbase[PW];
-  size_t pstride[PW];
-  int pkrow[PW];                                         // K pieces: this lane's key row inside a tile (-1: not a K piece)
+  // DMA sources: ONE 32-bit element offset per piece and lane from the wave-uniform base of the piece (K: kbase, V^T: vbase) -- the piece
+  // index is wave-uniform, so base and per-tile stride stay in SGPRs (round 6: the 64-bit pointer + stride + row per piece of the first
+  // version cost 5 VGPRs per piece in a kernel that sits at the 256-register limit).  V^T rows 80..95 of the third d-tile do not exist:
+  // their lanes fetch row 79 again (finite values; the output rows >= 80 are never stored).
+  const int krow = swap23(col);
+  unsigned poff[PW];
 #pragma unroll
   for (int j = 0; j < PW; ++j) {
     const int p = min(j * NWAVE + wave, NP - 1);
     if (p < KP) {
-      pkrow[j] = swap23(col);
-      pbase[j] = kbase + (size_t)pkrow[j] * ld + p * 16 + hh * 8;
-      pstride[j] = (size_t)32 * ld;
+      poff[j] = (unsigned)(krow * ld + p * 16 + hh * 8);
     } else {
-      const int dt = (p - KP) >> 1, s = (p - KP) & 1, d = dt * 32 + col;
-      pkrow[j] = -1;
-      pbase[j] = d < D ? vbase + (size_t)d * 32 + s * 16 + hh * 8 : zp;
-      pstride[j] = d < D ? (size_t)D * 32 : 0;
+      const int dt = (p - KP) >> 1, s = (p - KP) & 1, d = min(dt * 32 + col, D - 1);
+      poff[j] = (unsigned)(d * 32 + s * 16 + hh * 8);
     }
   }
   auto issue = [&](int t) {
@@ -377,9 +375,10 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 1) void attn_vit32_ker
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const int p = min(j * NWAVE + wave, NP - 1);
-      const bf16_t* src = pbase[j] + (size_t)tc * pstride[j];
-      if (pkrow[j] >= 0 && tc == ntile - 1)              // last tile: rows past the segment end are clamped (and masked)
-        src = kbase + (size_t)min(tc * 32 + pkrow[j], nkeys - 1) * ld + p * 16 + hh * 8;
+      const bool isk = p < KP;                           // wave-uniform
+      const bf16_t* src = (isk ? kbase + (size_t)tc * (32 * ld) : vbase + (size_t)tc * (D * 32)) + poff[j];
+      if (isk && tc == ntile - 1)                        // last tile: rows past the segment end are clamped (and masked)
+        src = kbase + (size_t)min(tc * 32 + krow, nkeys - 1) * ld + p * 16 + hh * 8;
       glds16(src, lds_addr(sbase + p * 64));
     }
   };

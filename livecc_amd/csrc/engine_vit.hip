@@ -145,7 +145,10 @@ extern "C" int lcc_vit_encode(lcc_engine* e, int n_clips, const lcc_clip* clips,
     // kernel with twice the blocks stays (41 us)
     // (the 4-wave form of the 32x32x16 kernel -- 128-row groups, 192 blocks for one chunk -- measured the same as the 16-row kernel:
     // 261.6 vs 262.1 tokens/s without prefetch, profiles/r03/knob_sweeps_call11_13.txt; off unless LCC_VIT32_MIN_BLOCKS4 says otherwise)
-    static const int vit32_min4 = [] { const char* v = getenv("LCC_VIT32_MIN_BLOCKS4"); return v ? atoi(v) : (1 << 30); }();
+    // Round 6: that instantiation had been compiled in the AGPR form (118 accumulator copies per region, tools/audit_agpr_copies.py); in the
+    // VGPR form it beats the 16-row kernel on one chunk (192 blocks): tower 5.20 -> 5.02 ms (profiles/r06/tower_4wave_vgprform_ab.jsonl), so
+    // grids of >= 128 four-wave blocks that are too small for the 8-wave form now take it.
+    static const int vit32_min4 = [] { const char* v = getenv("LCC_VIT32_MIN_BLOCKS4"); return v ? atoi(v) : 128; }();
     if (get_attn_variant() == 3 && e->vit_hd == 80 && (long)n_groups8 * heads >= 224)
       LCC_TRY(attn_vit32_launch(qkv, vt, attn, d_g8_seg, d_g8_q0, d_seg_start, d_seg_len, d_seg_blk, n_groups8, heads, blocks,
                                 1.4426950408889634f / sqrtf(80.f), st, 256));

@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 cfg = get_config("livecc-7b")
 native = LiveCCForConditionalGeneration(cfg, WeightArena(cfg, dev).fill_random(seed=5), dev, max_streams=1, max_kv_len=1024, max_new_rows=512,
                                         max_patches=16384, max_history=16)
-for streams in (8, 1):
+for streams in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (8, 1)):      # argv[2] = "1" or "8,1": which chunk counts to time
     clips = [dict(frames=torch.from_numpy(protocol.synth_frames(2, 392, 728, seed=21 + i, layout="TCHW")).to(dev), layout="TCHW") for i in range(streams)]
     for _ in range(2):
         native.engine.vit_encode(clips)

@@ -60,6 +60,16 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print(json.dumps(dict(tile_rows_env=$r, tokens_per_s=d['value'], ms_per_replay=d['ms_per_step'], decode_step_us=r['decode_step']['avg_step_us'], prefill=r.get('chunk_prefill'))))" >> $O/replay_tall_tiles_ab.jsonl; done
   cat $O/tests.txt $O/attn_tall_tiles_ab.jsonl; cut -c1-400 $O/replay_tall_tiles_ab.jsonl ;;
+tower4)        # tower attention after the AGPR-copy fixes: default routing vs the 4-wave 32x32x16 kernel for every grid (LCC_VIT32_MIN_BLOCKS4=0)
+  timeout 900 python -m pytest tests/test_gpu_vit_fused.py tests/test_gpu_ops.py -q -x -k "vit or tower" 2>&1 | tail -2 > $O/tests.txt
+  LCC_VIT32_MIN_BLOCKS4=0 timeout 900 python -m pytest tests/test_gpu_vit_fused.py tests/test_gpu_ops.py -q -x -k "vit or tower" 2>&1 | tail -2 | sed "s/^/min_blocks4=0: /" >> $O/tests.txt
+  for m in default 0 default 0; do
+    if [ $m = default ]; then python tools/r5_tower.py "routing=default" >> $O/tower_4wave_vgprform_ab.jsonl 2>/dev/null
+    else LCC_VIT32_MIN_BLOCKS4=$m python tools/r5_tower.py "min_blocks4=$m" >> $O/tower_4wave_vgprform_ab.jsonl 2>/dev/null; fi; done
+  cat $O/tests.txt $O/tower_4wave_vgprform_ab.jsonl ;;
+tower_prof)    # kernel stats of the one-chunk tower (2 frames 392x728 = 1,456 patches... x 2 temporal = one slice)
+  cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python $R/tools/r5_tower.py prof 1 > $O/tower.log 2>&1
+  cd $R; cp $O/prof/*kernel_stats.csv $O/tower_one_chunk_kernel_stats.csv; rm -rf $O/prof; head -30 $O/tower_one_chunk_kernel_stats.csv | cut -c1-200; cat $O/tower.log | tail -2 ;;
 attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
   for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
   cat $O/attn_direct_ab.jsonl ;;
@@ -71,5 +81,5 @@ tall)          # one-chunk GEMMs: tall kernel schedule A/B
   for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
 rccl)          # can RCCL run two ranks on the box's one GPU?
   timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
-*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall attn_direct attn_tps tall rccl" ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof attn_direct attn_tps tall rccl" ;;
 esac
