@@ -57,6 +57,10 @@ def parse(argv=None):
                          "(ref demo/infer.py:182-242): all 480 frames in ONE generate call (ViT over 96,000 patches in 240 segments, "
                          "one 24k-row LLM prefill served in pieces, then 32 decode tokens at L ~ 24k); both override "
                          "--frames/--height/--width/--max-new-tokens")
+    ap.add_argument("--time-budget-s", type=float, default=600.0,
+                    help="target wall time of the whole run: the OPTIONAL blocks (live2fps history ladder, configs[3] / configs[4] children and their "
+                         "fixture tests) are skipped -- with the reason in their block -- once the time left, after 130 s reserved for the CPU "
+                         "baseline + parity legs, no longer covers them; the main line, roofline, cpu_baseline and parity always run")
     ap.add_argument("--prefill-rows", type=int, default=4096, help="oneshot480: rows of one prefill launch sequence (max_new_rows)")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: LLM Linear weights as OCP e4m3 + fp32 row scales (BASELINE.json configs[4], 72B on one GPU)")
@@ -533,10 +537,23 @@ def _fixture_test(test_file, expr, keys, timeout_s):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def more_configs(args):
+def more_configs(args, left_s=lambda: 1e9, sections=None):
     """BASELINE.json configs[3] and configs[4] in the driver's own record: each as a child run of this file at its own
-    shapes + the committed-fixture parity test of that configuration; a failure of either leaves an `error` in its block, never in the line."""
+    shapes + the committed-fixture parity test of that configuration; a failure of either leaves an `error` in its block, never in the line.
+    `left_s()` = seconds left for optional work (--time-budget-s): a block that no longer fits says so instead of running (typical costs on
+    MI355X: one-shot child 35 s + its fixture test 15 s; 72B child 80 s + its two fixture tests 85 s)."""
     out = {}
+    sections = sections if sections is not None else {}
+    t_sec = time.perf_counter()
+
+    def lap(name):
+        nonlocal t_sec
+        sections[name] = round(time.perf_counter() - t_sec, 1)
+        t_sec = time.perf_counter()
+    if left_s() < 60:
+        out["configs3_oneshot480"] = dict(skipped=f"--time-budget-s: {left_s():.0f} s left for optional blocks, the one-shot child needs ~60")
+        out["configs4_72b_fp8"] = dict(skipped=f"--time-budget-s: {left_s():.0f} s left for optional blocks, the 72B child needs ~100")
+        return out
     try:
         j = _sub_bench(["--workload", "oneshot480", "--steps", "1", "--warmup", "1"], 600)
         rf = j.get("roofline") or {}
@@ -547,12 +564,17 @@ def more_configs(args):
                                  traffic=None, algorithmic_flops_per_call=rf.get("algorithmic_flops_per_call")),
                    decode_step_at_24k_keys=((rf.get("decode_gate_up") or {}).get("decode_step")))
         out["configs3_oneshot480"] = blk
+        lap("configs3_child")
         try:
             blk["parity"] = _fixture_test("test_gpu_golden.py", "oneshot480", ["livecc7b_oneshot480_vs_committed_golden"], 600)
         except Exception as e:
             blk["parity"] = dict(error=repr(e))
+        lap("configs3_fixture_test")
     except Exception as e:
         out["configs3_oneshot480"] = dict(error=repr(e))
+    if left_s() < 100:
+        out["configs4_72b_fp8"] = dict(skipped=f"--time-budget-s: {left_s():.0f} s left for optional blocks, the 72B child needs ~100")
+        return out
     try:
         j = _sub_bench(["--config", "qwen2vl-72b", "--weights", "fp8", "--steps", "1", "--warmup", "1"], 900)
         rf = j.get("roofline") or {}
@@ -564,10 +586,15 @@ def more_configs(args):
                    decode_step=dict(avg_step_us=ds.get("avg_step_us"), frac=ds.get("frac"), achieved=ds.get("achieved"), weight_bytes=ds.get("weight_bytes"),
                                     standalone_replay_without_prefetch=ds.get("standalone_replay_without_prefetch")))
         out["configs4_72b_fp8"] = blk
-        try:
-            blk["parity"] = _fixture_test("test_gpu_layer_parity.py", "72b", ["stream_72b_1layer_fp8", "qwen2vl72b_fp8_full_depth_vs_committed_golden"], 900)
-        except Exception as e:
-            blk["parity"] = dict(error=repr(e))
+        lap("configs4_child")
+        if left_s() < 100:
+            blk["parity"] = dict(skipped=f"--time-budget-s: {left_s():.0f} s left; tests/test_gpu_layer_parity.py -k 72b (~85 s) is part of the GPU tier")
+        else:
+            try:
+                blk["parity"] = _fixture_test("test_gpu_layer_parity.py", "72b", ["stream_72b_1layer_fp8", "qwen2vl72b_fp8_full_depth_vs_committed_golden"], 900)
+            except Exception as e:
+                blk["parity"] = dict(error=repr(e))
+            lap("configs4_fixture_tests")
     except Exception as e:
         out["configs4_72b_fp8"] = dict(error=repr(e))
     return out
@@ -800,6 +827,8 @@ def decisive_report(native_tokens, native_logits, ref):
 
 
 def main():
+    t_bench0 = time.perf_counter()
+    sections = {}            # wall seconds per block of this run (rank 0), reported as `sections_s`
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -1008,6 +1037,10 @@ def main():
                         vit_flops=fl["vit_flops"], llm_prefill_flops=fl["llm_prefill_flops"], prefill_rows=fl["prefill_rows"], patches=fl["patches"],
                         prefill_rows_per_launch_sequence=args.prefill_rows, frames_per_s_to_first_token=round(spg * args.frames / (ms1 * 1e-3), 1),
                         decode_gate_up=roof)
+    sections["main_line_and_roofline"] = round(time.perf_counter() - t_bench0, 1)
+
+    def left_s():            # seconds left for OPTIONAL blocks: the CPU baseline + parity legs (~110-130 s) always run at the end
+        return args.time_budget_s - 130.0 - (time.perf_counter() - t_bench0)
     live = None
     want_live = args.live2fps == "on" or (args.live2fps == "auto" and world == 1 and spg == 1 and cfg.name == "livecc-7b" and args.workload == "stream60"
                                           and args.frames == 60 and not fp8)
@@ -1015,13 +1048,21 @@ def main():
         try:
             del model
             torch.cuda.empty_cache()
-            live = live2fps(cfg, arena, dev, args, protocol, ladder=(8, 64, 96, 112, 128))
+            t_sec = time.perf_counter()
+            live = live2fps(cfg, arena, dev, args, protocol, ladder=(8, 96, 112))
+            sections["live2fps"] = round(time.perf_counter() - t_sec, 1)
             try:      # capacity @ history: the same ladder with 22k keys already cached per stream (a stream that has been live for a minute)
-                lh = live2fps(cfg, arena, dev, args, protocol, ladder=(16, 32, 48, 64), history_keys=22000)
+                if left_s() < 70:
+                    raise TimeoutError(f"--time-budget-s: {left_s():.0f} s left for optional blocks, the three rungs need ~70")
+                t_sec = time.perf_counter()
+                lh = live2fps(cfg, arena, dev, args, protocol, ladder=(32, 48, 64), history_keys=22000)
+                sections["live2fps_at_history"] = round(time.perf_counter() - t_sec, 1)
                 live["at_long_history"] = dict(capacity_streams_under_deadline=lh["capacity_streams_under_deadline"], ladder=lh["ladder"],
                                                       history_keys_at_join=lh["history_keys_at_join"], history_keys_at_end=lh["history_keys_at_end"])
                 live["capacity_at_history"] = {f"{live['history_keys_at_end']} keys": live["capacity_streams_under_deadline"],
                                                f"{lh['history_keys_at_end']} keys": lh["capacity_streams_under_deadline"]}
+            except TimeoutError as e:
+                live["at_long_history"] = dict(skipped=str(e))
             except Exception as e:
                 live["at_long_history"] = dict(error=repr(e))
         except Exception as e:       # never takes the main line down
@@ -1036,13 +1077,14 @@ def main():
             import gc
             gc.collect()          # the child processes (72B fp8: 73 GB of weights + its KV) need the HBM the parent's models held
             torch.cuda.empty_cache()
-            more = more_configs(args)
+            more = more_configs(args, left_s, sections)
         except Exception as e:
             more = dict(error=repr(e))
         model = LiveCCForConditionalGeneration(cfg, arena, dev, max_streams=spg, max_kv_len=min(32768, max(4096, kv_need)),
                                                max_new_rows=spg * (3 * n_tok_turn + 128), max_patches=spg * 12 * n_tok_turn + 64,
                                                max_history=max(16, args.max_new_tokens))
     cpu = par = None
+    t_cpu0 = time.perf_counter()
     want_cpu = (args.cpu_baseline == "on" or (args.cpu_baseline == "auto" and world == 1)) and not args.standin
     if want_cpu:
         cpu_cfg = args.cpu_config or args.config
@@ -1092,6 +1134,9 @@ def main():
         finally:
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)
+    if want_cpu:
+        sections["cpu_baseline_and_parity"] = round(time.perf_counter() - t_cpu0, 1)
+    sections["total"] = round(time.perf_counter() - t_bench0, 1)
     n_streams = world * spg
     tag = ""
     if cfg.name == "livecc-7b" and args.frames == 60 and args.workload == "stream60" and not fp8:
@@ -1127,7 +1172,7 @@ def main():
         "weight_broadcast_s_per_rank": [round(x, 3) for x in bcast_per_rank],
         "weight_broadcast_xgmi_bound_s": round(arena.nbytes() / 153e9, 3) if (arena is not None and world > 1) else 0.0,
         "ranks_pinned_to_gpu_numa_node": int(numa_pinned),
-        "roofline": roof, "cpu_baseline": cpu, "parity": par, ("configs2_share" if world == 1 else "configs2"): share, "live2fps": live, **(more or {}),
+        "sections_s": sections, "roofline": roof, "cpu_baseline": cpu, "parity": par, ("configs2_share" if world == 1 else "configs2"): share, "live2fps": live, **(more or {}),
         "timed_region": "frames resident in HBM as uint8 (resize / H2D outside the timed region); back-to-back replay: the NEXT turn's vision tower "
                         "is prefetched on a side stream under this turn's decode steps" + (" (disabled: --no-prefetch)" if args.no_prefetch else "") +
                         " -- available to a replay / a server that fetches ahead, NOT to a live 2-fps stream whose next frames do not exist yet",

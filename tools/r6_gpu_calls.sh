@@ -15,7 +15,7 @@ tier)          # the whole GPU tier as the driver runs it (pytest.ini adds -rs) 
   ( python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > $O/smoke_tail.txt 2>&1
   tail -45 $O/pytest_gpu_tail.txt; cat $O/smoke_tail.txt ;;
 bench)         # the driver's default line + rocprofv3 kernel stats / step breakdown of a short run of the same command
-  ( time python bench.py > $O/bench_default_n1.json 2> $O/bench_default_n1.err ) 2> $O/bench_time.txt
+  ( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_n1.json 2> $O/bench_default_n1.err ) 2> $O/bench_time.txt      # the driver's own command line (BENCH_rNN.json)
   cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o b -- python $R/bench.py --steps 1 --warmup 1 --no-prefetch $QUIET > $O/bench_under_rocprof.json 2> $O/rocprof.err
   cd $R; cp $O/prof/*kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
   python tools/trace_breakdown.py $(ls $O/prof/*kernel_trace.csv | head -1) > $O/step_breakdown_1streams_noprefetch.json 2> $O/breakdown.err
