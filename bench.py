@@ -57,10 +57,11 @@ def parse(argv=None):
                          "(ref demo/infer.py:182-242): all 480 frames in ONE generate call (ViT over 96,000 patches in 240 segments, "
                          "one 24k-row LLM prefill served in pieces, then 32 decode tokens at L ~ 24k); both override "
                          "--frames/--height/--width/--max-new-tokens")
-    ap.add_argument("--time-budget-s", type=float, default=600.0,
+    ap.add_argument("--time-budget-s", type=float, default=660.0,
                     help="target wall time of the whole run: the OPTIONAL blocks (live2fps history ladder, configs[3] / configs[4] children and their "
                          "fixture tests) are skipped -- with the reason in their block -- once the time left, after 130 s reserved for the CPU "
-                         "baseline + parity legs, no longer covers them; the main line, roofline, cpu_baseline and parity always run")
+                         "baseline + bf16 parity leg, no longer covers them, and so are -- in this order of priority -- the fp32, decisive-weights and "
+                         "HF-vs-HF legs of `--parity full`; the main line, roofline, cpu_baseline and the bf16 parity always run")
     ap.add_argument("--prefill-rows", type=int, default=4096, help="oneshot480: rows of one prefill launch sequence (max_new_rows)")
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: LLM Linear weights as OCP e4m3 + fp32 row scales (BASELINE.json configs[4], 72B on one GPU)")
@@ -1099,14 +1100,39 @@ def main():
                 np.save(teacher, ntok)
             cpu = cpu_baseline(cpu_cfg, args, args.cpu_budget, 2, teacher, out16)
             if do_par and os.path.exists(out16):
+                # the extra legs of `--parity full`, most valuable first, each only while --time-budget-s still covers its typical cost on
+                # the box's 128 cores (fp32 truth ~150 s, decisive weights ~90 s, the reference against itself ~130 s); a leg that does not
+                # fit leaves `skipped` in the block (every one of them also exists as a committed fixture of the GPU tier)
+                def fits(cost_s):
+                    return args.time_budget_s - (time.perf_counter() - t_bench0) >= cost_s
+                full = args.parity == "full"
+                skipped = {}
                 ref32 = None
-                if args.parity == "full":
+                t_leg = time.perf_counter()
+                if full and fits(170):
                     out32 = os.path.join(tmp, "ref32.npz")
                     run_cpu_leg(cpu_cfg, args, 4 * args.cpu_budget, 2, teacher, out32, dtype="float32")
                     ref32 = np.load(out32) if os.path.exists(out32) else None
+                    sections["parity_fp32_leg"] = round(time.perf_counter() - t_leg, 1)
+                elif full:
+                    skipped["fp32_truth"] = "--time-budget-s: the HF fp32 leg (~150 s) no longer fits; tests/test_gpu_golden.py holds the committed fp32 fixtures"
                 par = parity_report(ntok, nlog, np.load(out16), ref32)
-                if args.parity == "full":
+                if full and fits(100):
+                    # "token-id exact under greedy" (north_star) on weights where the argmax is decided by the model, not by rounding:
+                    # the SAME arena refilled in place with the decisive variant, the same two turns, HF CPU teacher-forced
+                    t_leg = time.perf_counter()
+                    arena.fill_tiled(seed=0, variant="decisive")
+                    dtok, dlog = native_parity_turns(model, cfg, args, protocol, 2, dev)
+                    td, od = os.path.join(tmp, "teacher_d.npy"), os.path.join(tmp, "refd.npz")
+                    np.save(td, dtok)
+                    run_cpu_leg(cpu_cfg, args, 2 * args.cpu_budget, 2, td, od, weights="decisive:0")
+                    par["decisive"] = decisive_report(dtok, dlog, np.load(od)) if os.path.exists(od) else dict(note="CPU leg cut by its budget")
+                    sections["parity_decisive_leg"] = round(time.perf_counter() - t_leg, 1)
+                elif full:
+                    skipped["decisive"] = "--time-budget-s: the decisive-weights leg (~90 s) no longer fits; tests/test_gpu_golden.py -k decisive holds the committed fixture"
+                if full and fits(150):
                     # the reference against ITSELF: a second bf16 leg under another evaluation order (eager attention, a quarter of the threads)
+                    t_leg = time.perf_counter()
                     out16b = os.path.join(tmp, "ref16b.npz")
                     thr_b = max(8, (os.cpu_count() or 32) // 4)
                     run_cpu_leg(cpu_cfg, args, 2 * args.cpu_budget, 2, teacher, out16b, attn="eager", threads=thr_b)
@@ -1115,15 +1141,12 @@ def main():
                                                                         f"HF bf16 sdpa / all cores vs HF bf16 eager / {thr_b} threads, same weights, same teacher tokens")
                         nf = par["reference_noise_floor"]
                         par["rel_dlogit_vs_bf16_over_reference_noise_floor"] = round(par["rel_dlogit_vs_bf16"] / max(nf["rel_dlogit_hf_vs_hf"], 1e-9), 3)
-                if args.parity == "full":
-                    # "token-id exact under greedy" (north_star) on weights where the argmax is decided by the model, not by rounding:
-                    # the SAME arena refilled in place with the decisive variant, the same two turns, HF CPU teacher-forced
-                    arena.fill_tiled(seed=0, variant="decisive")
-                    dtok, dlog = native_parity_turns(model, cfg, args, protocol, 2, dev)
-                    td, od = os.path.join(tmp, "teacher_d.npy"), os.path.join(tmp, "refd.npz")
-                    np.save(td, dtok)
-                    run_cpu_leg(cpu_cfg, args, 2 * args.cpu_budget, 2, td, od, weights="decisive:0")
-                    par["decisive"] = decisive_report(dtok, dlog, np.load(od)) if os.path.exists(od) else dict(note="CPU leg cut by its budget")
+                    sections["parity_noise_floor_leg"] = round(time.perf_counter() - t_leg, 1)
+                elif full:
+                    skipped["reference_noise_floor"] = ("--time-budget-s: the HF-vs-HF leg (~130 s) no longer fits (run with --time-budget-s 900 for it; last "
+                                                        "measured: profiles/r06/bench_time_budget_900_parity.json)")
+                if skipped:
+                    par["skipped"] = skipped
             elif do_par:
                 par = dict(note="the CPU leg was cut by its budget before it could write its logits", turns_compared=0)
             if cpu.get("value") is None and cpu_cfg != "qwen2vl-2b":
