@@ -65,7 +65,7 @@ __device__ unsigned int lcc_attn32_zero_page[256];
 //
 // (Round 5, measured null and removed: reading the next region's first three V^T fragments at the end of the region before it -- no LDS
 // round trip in front of a region's first MFMAs -- 377-382 us either way at 8 x 386 rows x 6.2k keys, profiles/r05/attn_pipe_ab.txt.)
-// (Round 6, measured and removed -- both were tests of "the kernel is bound by the staging of its K / V tiles":
+// (Round 6, measured and removed -- the first two were tests of "the kernel is bound by the staging of its K / V tiles":
 //   * ROW-MAJOR stage images (every LDS-DMA instruction copies one contiguous KB of the cache -- 4 K rows / 16 V^T rows -- into an XOR-swizzled
 //     [32][256 B] / [D][64 B] image, conflict-free fragment reads, same bits) instead of the fragment-order pieces below, whose DMA gathers 64
 //     separate 16-byte chunks: 8 x 386 rows 427.8 / 429.0 us vs 431.3 / 420.4, one-shot piece 690 / 692 vs 687 / 685, tower 20.80-20.88 ms vs
@@ -75,7 +75,13 @@ __device__ unsigned int lcc_attn32_zero_page[256];
 //     (see attn_gqa32_kernel) and issued 329 instructions per region against the 8-wave kernel's 185 (of which 32 v_pk_mul sit in the skipped
 //     rescale branch: 16 MFMAs, 16 fragment reads, 83 vector and ~38 scalar instructions per region and wave).  A 4-wave block with 1.8 x the
 //     instructions took 0.8 of the 8-wave block's time, so a wave alone on its SIMD runs its stream ~2.2 x faster than one that shares it:
-//     the two waves of a SIMD do not overlap their matrix and vector work, they mostly take turns.)
+//     the two waves of a SIMD do not overlap their matrix and vector work, they mostly take turns.
+//   * PING-PONG phases ("two waves of a SIMD in the same phase"): a region issued as a matrix phase (its 16 / 11 MFMAs with
+//     their fragment reads) and a vector phase (the softmax), in OPPOSITE order on the two waves that share a SIMD (w and w + 4; both phases
+//     of region t depend only on region t - 1; two copies of the key loop under a wave-uniform branch, 235 VGPRs, same bits) instead of the
+//     instruction-by-instruction interleave below: 8 x 386 rows 429-432 vs 382-387 us (+11 %), a 4,096-row piece 708 vs 655 (+8 %), one
+//     chunk 81.5 vs 74.0, tower 20.59 vs 20.38 ms; profiles/r06/attn_pingpong_phases_ab.jsonl.  The interleave already overlaps a wave's own
+//     MFMAs with its own vector instructions; separating them loses that and the other wave does not make up for it.  Removed.)
 template <int D, int PW, class Issue>
 LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf)[D / 16], int tb, int te, int mlim, int lim, float scale_log2e,
                                 bool active, int lane, int hh, f32x16 (&o)[(D + 31) / 32], float& m_run, float& l_run) {

@@ -70,6 +70,11 @@ tower4)        # tower attention after the AGPR-copy fixes: default routing vs t
 tower_prof)    # kernel stats of the one-chunk tower (2 frames 392x728 = 1,456 patches... x 2 temporal = one slice)
   cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python $R/tools/r5_tower.py prof 1 > $O/tower.log 2>&1
   cd $R; cp $O/prof/*kernel_stats.csv $O/tower_one_chunk_kernel_stats.csv; rm -rf $O/prof; head -30 $O/tower_one_chunk_kernel_stats.csv | cut -c1-200; cat $O/tower.log | tail -2 ;;
+pingpong)      # RECORD of a removed variant (LCC_ATTN32_PINGPONG no longer exists; attn32.hip keeps the result): 8-wave attention kernels: matrix phase / vector phase in opposite order on the two waves of a SIMD (LCC_ATTN32_PINGPONG bit 0 LLM, bit 1 tower)
+  for m in 0 3; do LCC_ATTN32_PINGPONG=$m timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_vit_fused.py tests/test_gpu_baseline_configs.py -q -x -k "attn or vit or attention" 2>&1 | tail -1 | sed "s/^/pingpong=$m: /" >> $O/tests.txt; done
+  for m in 0 1 0 1; do LCC_ATTN32_PINGPONG=$m python tools/bench_attn.py --only32 2>/dev/null | sed "s/^{/{\"pingpong\": $m, /" >> $O/attn_pingpong_ab.jsonl; done
+  for m in 0 2 0 2; do LCC_ATTN32_PINGPONG=$m python tools/r5_tower.py "pingpong=$m" 8 >> $O/tower_pingpong_ab.jsonl 2>/dev/null; done
+  cat $O/tests.txt; grep -v "nsplit\": 5" $O/attn_pingpong_ab.jsonl | cut -c1-200; cat $O/tower_pingpong_ab.jsonl ;;
 attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
   for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
   cat $O/attn_direct_ab.jsonl ;;
@@ -81,5 +86,5 @@ tall)          # one-chunk GEMMs: tall kernel schedule A/B
   for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
 rccl)          # can RCCL run two ranks on the box's one GPU?
   timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
-*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof attn_direct attn_tps tall rccl" ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof pingpong attn_direct attn_tps tall rccl" ;;
 esac
