@@ -43,6 +43,7 @@ LCC_DEVICE float xor32_sum(float x) {
 }
 
 __device__ unsigned int lcc_attn32_zero_page[256];
+__device__ unsigned int lcc_attn32_ones_page[256] = {[0 ... 255] = 0x3F803F80u};      // 1 KB of bf16 1.0: the V^T rows 80..95 of the tower kernel (LM)
 
 // (Round 6, measured null and removed: a static `s_setprio 1` for the younger or for the older half of the waves -- MI355X_MICROARCH "Two
 // waves per SIMD" item 4 -- 416-421 us either way at 8 x 386 rows x 6.2k keys, tower 20.8 ms either way: profiles/r06/attn_static_prio_ab.jsonl.)
@@ -82,7 +83,10 @@ __device__ unsigned int lcc_attn32_zero_page[256];
 //     instruction-by-instruction interleave below: 8 x 386 rows 429-432 vs 382-387 us (+11 %), a 4,096-row piece 708 vs 655 (+8 %), one
 //     chunk 81.5 vs 74.0, tower 20.59 vs 20.38 ms; profiles/r06/attn_pingpong_phases_ab.jsonl.  The interleave already overlaps a wave's own
 //     MFMAs with its own vector instructions; separating them loses that and the other wave does not make up for it.  Removed.)
-template <int D, int PW, class Issue>
+// LM (round 6, the tower kernel only): the softmax denominator comes out of the P . V MFMAs -- the V^T rows 80..95 of the third d-tile do not
+// exist at d = 80 and are fed with ONES, so O^T rows 80..95 accumulate sum_k bf16(P) under the same lazy rescale as O -- instead of 16 v_add +
+// the l_run update per region (VERDICT r5 next #2b).  l then sums the ROUNDED probabilities the numerator uses (fp32 accumulation either way).
+template <int D, int PW, bool LM, class Issue>
 LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf)[D / 16], int tb, int te, int mlim, int lim, float scale_log2e,
                                 bool active, int lane, int hh, f32x16 (&o)[(D + 31) / 32], float& m_run, float& l_run) {
   constexpr int KP = D / 16, DT = (D + 31) / 32, VP = 2 * DT, NP = KP + VP, NSTAGE = 10;
@@ -126,9 +130,9 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       p[r] = __builtin_amdgcn_exp2f(fmaf(sc_cur[r], scale_log2e, -m_use));   // masked scores are -inf -> 0
-      psum += p[r];
+      if (!LM) psum += p[r];
     }
-    l_run = l_run * alpha + psum;
+    if (!LM) l_run = l_run * alpha + psum;
     bf16x8 pn[2];
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss)
@@ -147,7 +151,7 @@ LCC_DEVICE void attn32_key_loop(const u32x4* alds, Issue issue, const u32x4 (&qf
     for (int i = 0; i < NP; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (i < NP - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, (MASKED ? 7 : 5) * 16 / NP, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, ((MASKED ? 7 : 5) - (LM ? 1 : 0)) * 16 / NP, 0);
     }
     // region boundary: the accumulators now hold tiles <= t-1 at the OLD maximum; bring them to the new one before tile t's P.V.
     // Lazy: once the running maximum has settled alpha is exactly 1.0 in every lane and the multiplies are skipped (x * 1.0f is
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_gqa32_kernel(
   int min_limit = key_limit;                             // wave-wide minimum of the key limits: tiles entirely below it need no mask
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) min_limit = min(min_limit, __shfl_xor(min_limit, off, 64));
-  attn32_key_loop<D, PW>(alds, issue, qf, tb, te, min(min_limit, te * 32), min(key_limit, te * 32), scale_log2e, active, lane, hh, o, m_run, l_run);
+  attn32_key_loop<D, PW, false>(alds, issue, qf, tb, te, min(min_limit, te * 32), min(key_limit, te * 32), scale_log2e, active, lane, hh, o, m_run, l_run);
   if (!active) return;
 
   float l = xor32_sum(l_run);
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_gqa32_kernel(
 // the last (partial) tile are clamped into the segment (the next segment's rows are NOT part of this attention).
 // (the 4-wave instantiation keeps one wave per SIMD and the AGPR form: capped at 256 registers it spills 52 bytes; it is an opt-in variant,
 // LCC_VIT32_MIN_BLOCKS4, and its 118 accumulator copies per region are what made it lose to the 8-wave form in rounds 3 and 6)
-template <int NWAVE>
+template <int NWAVE, bool LM>
 __global__ __launch_bounds__(NWAVE * 64, 2) void attn_vit32_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const int32_t* __restrict__ grp_seg,
     const int32_t* __restrict__ grp_q0, const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_len,
@@ -385,6 +389,8 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_vit32_kernel(
       const bf16_t* src = (isk ? kbase + (size_t)tc * (32 * ld) : vbase + (size_t)tc * (D * 32)) + poff[j];
       if (isk && tc == ntile - 1)                        // last tile: rows past the segment end are clamped (and masked)
         src = kbase + (size_t)min(tc * 32 + krow, nkeys - 1) * ld + p * 16 + hh * 8;
+      if (LM && p >= KP + 4 && col >= 16)                // V^T rows 80..95 (third d-tile, upper half): ones -> O^T rows 80..95 = sum of P
+        src = reinterpret_cast<const bf16_t*>(lcc_attn32_ones_page) + lane * 8;
       glds16(src, lds_addr(sbase + p * 64));
     }
   };
@@ -394,8 +400,8 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_vit32_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  attn32_key_loop<D, PW>(alds, issue, qf, 0, ntile, sl, sl, scale_log2e, active, lane, hh, o, m_run, l_run);
-  const float l = xor32_sum(l_run);
+  attn32_key_loop<D, PW, LM>(alds, issue, qf, 0, ntile, sl, sl, scale_log2e, active, lane, hh, o, m_run, l_run);
+  const float l = LM ? o[2][8] : xor32_sum(l_run);       // LM: row 80 + 4 hh of O^T, every one of rows 80..95 holds the sum over ALL keys
   if (active && col < nq) {
     const float inv = 1.f / l;
     bf16_t* op = out + (size_t)(s0 + q0 + col) * E + h * D;
@@ -412,17 +418,23 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_vit32_kernel(
   }
 }
 
-template <int NWAVE>
+// LCC_VIT32_LSUM_MFMA (A/B, read once): 1 = the tower kernel takes its softmax denominator from the P . V MFMAs (LM above), 0 = vector adds
+static int vit32_lsum_mfma() {
+  static const int v = [] { const char* e = getenv("LCC_VIT32_LSUM_MFMA"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+template <int NWAVE, bool LM>
 static void vit32_launch_t(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0, const int32_t* seg_start,
                            const int32_t* seg_len, const int32_t* seg_blk_start, int n_groups, int heads, int total_blocks, float scale_log2e, hipStream_t st) {
   constexpr size_t lds = (size_t)10 * 11 * 1024;
   static DeviceOnce once;   // per instantiation
-  if (once.first()) (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (once.first()) (void)hipFuncSetAttribute((const void*)attn_vit32_kernel<NWAVE, LM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const long nvb = (long)n_groups * heads;
   const int cap = get_grid_cap();
   static const int xcd = [] { const char* v = getenv("LCC_ATTN32_XCD"); return v ? atoi(v) : 1; }();      // A/B: 0 = virtual block = physical block
   const long nb = (cap > 0 && nvb > cap) ? cap : (xcd ? (nvb + 7) / 8 * 8 : nvb);      // (the cap is a multiple of 8: gemm.hip set_grid_cap)
-  attn_vit32_kernel<NWAVE><<<dim3((unsigned)nb), dim3(NWAVE * 64), lds, st>>>(
+  attn_vit32_kernel<NWAVE, LM><<<dim3((unsigned)nb), dim3(NWAVE * 64), lds, st>>>(
       qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, heads, total_blocks, scale_log2e, n_groups, xcd);
 }
 int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const int32_t* grp_seg, const int32_t* grp_q0,
@@ -431,8 +443,10 @@ int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const in
   if (n_groups <= 0) return 0;
   if (group_rows != 256 && group_rows != 128) return LCC_ERR_ARG;
   // group_rows 256: 8 waves x 32 rows per block; 128: 4 waves (one per SIMD) -- twice the blocks for a grid that does not fill the chip
-  if (group_rows == 256) vit32_launch_t<8>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st);
-  else vit32_launch_t<4>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st);
+#define LCC_VIT32_GO(NW, LMV) vit32_launch_t<NW, LMV>(qkv, vt, out, grp_seg, grp_q0, seg_start, seg_len, seg_blk_start, n_groups, heads, total_blocks, scale_log2e, st)
+  if (vit32_lsum_mfma()) { if (group_rows == 256) LCC_VIT32_GO(8, true); else LCC_VIT32_GO(4, true); }
+  else { if (group_rows == 256) LCC_VIT32_GO(8, false); else LCC_VIT32_GO(4, false); }
+#undef LCC_VIT32_GO
   g_launch_counts[LC_ATTN_VIT32] += 1;
   return 0;
 }

@@ -75,6 +75,10 @@ pingpong)      # RECORD of a removed variant (LCC_ATTN32_PINGPONG no longer exis
   for m in 0 1 0 1; do LCC_ATTN32_PINGPONG=$m python tools/bench_attn.py --only32 2>/dev/null | sed "s/^{/{\"pingpong\": $m, /" >> $O/attn_pingpong_ab.jsonl; done
   for m in 0 2 0 2; do LCC_ATTN32_PINGPONG=$m python tools/r5_tower.py "pingpong=$m" 8 >> $O/tower_pingpong_ab.jsonl 2>/dev/null; done
   cat $O/tests.txt; grep -v "nsplit\": 5" $O/attn_pingpong_ab.jsonl | cut -c1-200; cat $O/tower_pingpong_ab.jsonl ;;
+vit_lsum)      # tower attention: softmax denominator from the P.V MFMAs (ones rows 80..95 of V^T) vs vector adds
+  for m in 0 1; do LCC_VIT32_LSUM_MFMA=$m timeout 1200 python -m pytest tests/test_gpu_vit_fused.py tests/test_gpu_ops.py tests/test_gpu_e2e.py tests/test_gpu_golden.py tests/test_gpu_layer_parity.py -q -x -k "not 72b" 2>&1 | tail -1 | sed "s/^/lsum_mfma=$m: /" >> $O/tests.txt; done
+  for m in 0 1 0 1; do LCC_VIT32_LSUM_MFMA=$m python tools/r5_tower.py "lsum_mfma=$m" >> $O/tower_lsum_mfma_ab.jsonl 2>/dev/null; done
+  cat $O/tests.txt $O/tower_lsum_mfma_ab.jsonl ;;
 attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
   for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
   cat $O/attn_direct_ab.jsonl ;;
@@ -86,5 +90,5 @@ tall)          # one-chunk GEMMs: tall kernel schedule A/B
   for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
 rccl)          # can RCCL run two ranks on the box's one GPU?
   timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
-*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof pingpong attn_direct attn_tps tall rccl" ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof pingpong vit_lsum attn_direct attn_tps tall rccl" ;;
 esac
