@@ -94,6 +94,15 @@ int lcc_debug_set_attn_variant(int variant);
  * 8 x 32 columns (4 x 32 at <= 4 query heads per KV head), i.e. 256 / G rows -- 36 for Qwen2-VL-7B (28 / 4 heads), 32 for the 72B
  * (64 / 8); 32 otherwise.  Host logic only (no launch, no GPU); < 0 = LCC_ERR_ARG for head counts that do not divide. */
 int lcc_debug_attn_tile_rows(int n_q_heads, int n_kv_heads);
+/* Host-side plan of ONE LLM prefill attention launch under attention variant 3 (the 32x32x16 kernel), as lcc_llm_prefill makes it: query-tile
+ * height (32 or lcc_debug_attn_tile_rows) and key-split count for `n_streams` streams with n_new[b] new rows each against at most `max_kv` keys
+ * on a device of `cu_count` compute units.  One 8-wave block per CU and (tile, KV head, split): cost = rounds of blocks x keys per block
+ * + a per-split term (fp32 partials + merge); splits only for calls of <= 1,024 rows with >= 8 key tiles per split; the tall tile only where
+ * strictly cheaper.  At 28 / 4 heads, 256 CUs, 6.5k keys: one 386-row chunk -> (36, 5); two chunks -> (32, 2); five -> (36, 1); eight ->
+ * (32, 1); eight 1,131-row first turns -> (36, 1).  *tile_rows = *splits = 0 when another kernel family serves the call (variant != 3, or more than 8
+ * query heads per KV head).  Host logic only (no launch, no GPU). */
+int lcc_debug_attn_plan(const int32_t* n_new, int n_streams, int max_kv, int n_q_heads, int n_kv_heads, int cu_count, int32_t* tile_rows,
+                        int32_t* splits);
 /* 1: on the batch-1 decode path the consumers of a split-K GEMV (bias + M-RoPE + KV append; residual add + RMSNorm) run as the
  * TAIL of that GEMV in its last-arriving block (agent-scope release/acquire); 0 (default, measured faster): separate kernels */
 int lcc_debug_set_fused_tails(int on);

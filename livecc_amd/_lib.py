@@ -120,6 +120,7 @@ def load():
         "lcc_debug_launch_counts": (i32, [vp, i32, i32]),
         "lcc_debug_gemm_plan": (i32, [i32, i32, i32, i32, i32, i32, vp, vp]),
         "lcc_debug_attn_tile_rows": (i32, [i32, i32]),
+        "lcc_debug_attn_plan": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
         "lcc_debug_bench_grid_barrier": (i32, [i32, i32, i32, vp, C.c_size_t, vp, vp, vp]),
         "lcc_debug_bench_attn_decode": (i32, [i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, KvLayout, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp,
                                             C.POINTER(f32), vp]),

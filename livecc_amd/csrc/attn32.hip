@@ -468,6 +468,39 @@ int attn32_tile_rows(int G) {
   return forced >= 16 ? std::min(forced, mx) : mx;
 }
 
+// Tile height and key-split count of one prefill launch, planned TOGETHER (host logic only: lcc_debug_attn_plan pins it on the CPU).
+// One 8-wave block per CU and (tile, KV head, split); a block's time is proportional to its keys and does not depend on how many of its
+// waves work.  Cost of a candidate (tile rows, k splits) in units of one unsplit block's time:
+//     ceil(tiles x kv_heads x k / cus) / k          rounds of blocks on the chip x keys per block
+//   + k x (0.01 + 200 / max_kv)                     what a split costs: its fp32 partials written and merged (~4 us per split against ~0.02 us
+//                                                   per key of a block), and a small preference for fewer splits between near-ties
+// k <= 8 with >= 8 key tiles per split, and only for S <= 1024 rows (the partial buffers of carve_llm).  The model ranks every measured
+// configuration of profiles/r06/attn_tall_tiles_ab.jsonl / attn_tall_tiles_splits_probe.jsonl in the measured order:
+//   1 chunk  (386 rows, 6.2k keys): (36, 5) 65.4 us < (36, 4) 72.2 ~ (32, 4) 73.4 << (32, 1) 181
+//   2 chunks: (32, 2) 113.7 < (36, 2) 116 < (36, 8) 125.8 ~ (36, 4) 127.4 < (32, 7) 129 < (36, 3) 152.7 < (32, 1) 176
+//             (rounds 3-6 maximised "filled fraction of the last round" instead and ran 2-chunk batches at (32, 7): +13 %)
+//   3 chunks: (36, 3) 163 < (32, 1) 179 < (36, 4) 190 < (32, 2) 206 < (36, 2) 214  (the engine runs (32, 1) there: 1,158 rows > 1,024)
+//   4 / 8 chunks (no split above 1,024 rows): (32, 1) = (36, 1) within 1 %: ties keep 32 rows; 8 first turns: (36, 1) 132 < (32, 1) 140 (4 vs 5 rounds)
+void attn32_plan(const int* n_new, int n_streams, int max_kv, int G, int n_kv_heads, int cus, int* tile_rows, int* splits) {
+  long S = 0;
+  for (int b = 0; b < n_streams; ++b) S += n_new[b];
+  const int ks_cap = S <= 1024 ? std::max(1, std::min(8, (max_kv / 32) / 8)) : 1;
+  const float per_split = 0.01f + 200.f / (float)std::max(max_kv, 32);
+  const int tall = attn32_tile_rows(G);
+  float best = 1e30f;
+  *tile_rows = 32; *splits = 1;
+  for (int pass = 0; pass < (tall > 32 ? 2 : 1); ++pass) {           // 32-row tiles first: they win ties
+    const int rows = pass == 0 ? 32 : tall;
+    long tiles = 0;
+    for (int b = 0; b < n_streams; ++b) tiles += (n_new[b] + rows - 1) / rows;
+    const long base = tiles * n_kv_heads;
+    for (int k = 1; k <= ks_cap; ++k) {
+      const float cost = (float)((base * k + cus - 1) / cus) / (float)k + per_split * (float)k;
+      if (cost < best - 1e-6f) { best = cost; *tile_rows = rows; *splits = k; }
+    }
+  }
+}
+
 // launcher: tiles of <= attn32_max_tile_rows(G) rows; the caller (attention.hip: attn_prefill_bf16) runs the split merge
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,

@@ -324,43 +324,14 @@ extern "C" int lcc_llm_prefill(lcc_engine* e, int n_streams, const int32_t* slot
   // attention variant 3 (attn32.hip: 32x32x16 MFMAs, one wave = 32 rows of one head) always takes 32-row tiles.
   const bool mfma32 = get_attn_variant() == 3 && e->c.n_q_heads / e->c.n_kv_heads <= 8;
   // Round 6: a block of that kernel can hold 8 x 32 / G rows -- 36 at 7 heads per KV head, all eight waves busy instead of seven -- and a
-  // block's time does not depend on that (it is set by its busiest SIMD).  Tile height and key-split count are planned TOGETHER (plan32 below:
-  // rounds of blocks on the chip x keys per block); the taller tile is taken only where that plan is strictly cheaper.  Measured
-  // (profiles/r06/attn_tall_tiles_ab.jsonl, attn_tall_tiles_splits_probe.jsonl): one chunk 11 tiles x 4 x 5 splits = 220 blocks instead of
-  // 13 x 4 x 4 = 208 with 5/4 of the keys each, 73.4 -> 65 us; 8 first turns (1152 -> 1024 blocks: 5 -> 4 rounds) 142 -> 133 us; ties keep
-  // 32 rows: 2 chunks 113.7 vs 116 us, 4 chunks 183 = 184, 8 chunks (416 / 352 blocks: two rounds) 374-390 = 386-394, a 4,096-row piece 665 vs 672.
+  // block's time does not depend on that (it is set by its busiest SIMD).  Tile height and key-split count are planned TOGETHER
+  // (attn32.hip: attn32_plan, pinned on the CPU through lcc_debug_attn_plan).
   int tile_rows = mfma32 ? 32 : ((long)((S + 31) / 32) * e->c.n_q_heads >= 6144 ? 32 : 16);
   int max_kv = 0;
   for (int b = 0; b < n_streams; ++b) max_kv = std::max(max_kv, e->h_kv_len[slots[b]] + n_new[b]);
-  // key splits of the 32x32x16 kernel (one 8-wave block per CU and (tile, KV head, split)).  Measured (tools/bench_attn.py,
-  // profiles/r03/attn_prefill_microbench.jsonl): a split costs its fp32 partials twice (write + combine launch: 3,088 rows x 28 heads x 3
-  // splits = 137 MB, 415 vs 373 us at 8 streams), so keys are split only while the unsplit grid cannot fill ONE round of the chip (one
-  // stream's chunk: 52 blocks -> 4 splits, 68 vs 177 us); then the split count that fills whole rounds best, slightly preferring fewer splits.
-  const int cus = e->cu_count;     // of the engine's device, queried once at create time
   const int ks_cap = std::max(1, std::min(8, (max_kv / 32) / 8));      // >= 8 key tiles per split
-  auto plan32 = [&](long n_tiles_, int* ks_out) {      // -> relative time of the launch: rounds of blocks x keys per block
-    const long base = n_tiles_ * e->c.n_kv_heads;
-    const int ks_max = (S <= 1024 && base < cus) ? ks_cap : 1;
-    float best = -1.f; int best_ks = 1;
-    for (int k = 1; k <= ks_max; ++k) {
-      const long blocks = base * k, rounds = (blocks + cus - 1) / cus;
-      const float u = (float)blocks / (float)(rounds * cus) - 0.015f * (float)k;
-      if (u > best) { best = u; best_ks = k; }
-    }
-    *ks_out = best_ks;
-    return (float)((base * best_ks + cus - 1) / cus) / (float)best_ks;
-  };
   int ks32 = 1;
-  if (mfma32) {
-    const int tall = attn32_tile_rows(e->c.n_q_heads / e->c.n_kv_heads);
-    long t32 = 0, tt = 0;
-    for (int b = 0; b < n_streams; ++b) { t32 += (n_new[b] + 31) / 32; tt += (n_new[b] + tall - 1) / tall; }
-    const float c32 = plan32(t32, &ks32);
-    if (tall > 32) {      // the taller tile only where it saves rounds (ties keep 32 rows: 2 chunks 113.7 vs 116 us, 4 chunks 183 = 184 us)
-      int kst = 1;
-      if (plan32(tt, &kst) < c32 - 1e-6f) { tile_rows = tall; ks32 = kst; }
-    }
-  }
+  if (mfma32) attn32_plan(n_new, n_streams, max_kv, e->c.n_q_heads / e->c.n_kv_heads, e->c.n_kv_heads, e->cu_count, &tile_rows, &ks32);
   int row = 0;
   for (int b = 0; b < n_streams; ++b) {
     const int past = e->h_kv_len[slots[b]];

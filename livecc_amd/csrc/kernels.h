@@ -133,6 +133,8 @@ int attn_vit32_launch(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, const in
 // the engine builds (LCC_ATTN32_TILE_ROWS caps it)
 int attn32_max_tile_rows(int G);
 int attn32_tile_rows(int G);
+// tile height + key-split count of one 32x32x16 prefill launch (host logic only; attn32.hip)
+void attn32_plan(const int* n_new, int n_streams, int max_kv, int G, int n_kv_heads, int cus, int* tile_rows, int* splits);
 int attn_prefill32_launch(const bf16_t* q, bf16_t* out, const int32_t* tile_stream, const int32_t* tile_q0, const int32_t* tile_nq,
                           const int32_t* tile_pos0, bf16_t* const* kv_base, KvLayout lay, int layer, int n_tiles, int n_q_heads,
                           int nsplit, float* ws_o, float* ws_ml, float scale_log2e, hipStream_t st);

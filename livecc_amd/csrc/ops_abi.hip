@@ -29,6 +29,19 @@ extern "C" int lcc_debug_attn_tile_rows(int n_q_heads, int n_kv_heads) {   // ho
   const int G = n_q_heads / n_kv_heads;
   return (get_attn_variant() == 3 && G <= 8) ? attn32_tile_rows(G) : 32;
 }
+extern "C" int lcc_debug_attn_plan(const int32_t* n_new, int n_streams, int max_kv, int n_q_heads, int n_kv_heads, int cu_count, int32_t* tile_rows,
+                                   int32_t* splits) {   // host logic only: no launch
+  if (!n_new || n_streams < 1 || max_kv < 1 || n_kv_heads < 1 || n_q_heads < n_kv_heads || n_q_heads % n_kv_heads || cu_count < 1 || !tile_rows || !splits)
+    return fail(LCC_ERR_ARG, "lcc_debug_attn_plan: invalid arguments");
+  for (int b = 0; b < n_streams; ++b)
+    if (n_new[b] < 1) return fail(LCC_ERR_ARG, "lcc_debug_attn_plan: stream %d has no new rows", b);
+  const int G = n_q_heads / n_kv_heads;
+  if (get_attn_variant() != 3 || G > 8) { *tile_rows = 0; *splits = 0; return 0; }      // another kernel family plans this call
+  int tr = 32, ks = 1;
+  attn32_plan(n_new, n_streams, max_kv, G, n_kv_heads, cu_count, &tr, &ks);
+  *tile_rows = tr; *splits = ks;
+  return 0;
+}
 extern "C" int lcc_debug_gemm_plan(int M, int N, int K, int epilogue, int nsplit, int w_fp8, int32_t* tile_rows, int32_t* engine_splits) {
   if (M <= 0 || N <= 0 || K <= 0 || !tile_rows || !engine_splits) return fail(LCC_ERR_ARG, "lcc_debug_gemm_plan: invalid arguments");
   *engine_splits = gemm_tiled_num_splits(M, N, K, w_fp8 == 0);

@@ -126,6 +126,17 @@ def attn_tile_rows(n_q_heads: int, n_kv_heads: int) -> int:
     return int(rc)
 
 
+def attn_plan(n_new: Sequence[int], max_kv: int, n_q_heads: int, n_kv_heads: int, cu_count: int = 256) -> Tuple[int, int]:
+    """(tile_rows, key_splits) of one LLM prefill attention launch as the engine plans it (lcc_debug_attn_plan: host logic, no GPU);
+    (0, 0) when another kernel family serves the call."""
+    import numpy as np
+    nn = np.ascontiguousarray(np.asarray(list(n_new), dtype=np.int32))
+    out = np.zeros(2, dtype=np.int32)
+    _lib.check(_lib.load().lcc_debug_attn_plan(nn.ctypes.data, int(nn.size), int(max_kv), int(n_q_heads), int(n_kv_heads), int(cu_count),
+                                               out[0:].ctypes.data, out[1:].ctypes.data), "lcc_debug_attn_plan")
+    return int(out[0]), int(out[1])
+
+
 def gemm_plan(M: int, N: int, K: int, epilogue: int = EPI_NONE, nsplit: int = 0, w_fp8: bool = False) -> Tuple[int, int]:
     """(tile_rows, engine_splits) of lcc_debug_gemm_plan: the kernel family that serves this packed-weight GEMM and the split count the
     engine's prefill asks for at this shape.  Host logic only: needs the library, not a GPU."""

@@ -56,3 +56,29 @@ def test_the_switch_restores_the_128_row_slabs(built_lib):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LCC_GEMM_VH_SMALL="0"), timeout=120)
     assert r.returncode == 0, r.stderr[-400:]
     assert r.stdout.strip() == "4 128", r.stdout      # four slabs on the 128-row tiles: the round-4 form
+
+
+def test_prefill_attention_plan_at_the_engines_shapes(built_lib):
+    """Tile height x key-split count of the LLM prefill attention (lcc_debug_attn_plan: the function lcc_llm_prefill itself calls, no launch):
+    one block per CU and (tile, KV head, split), relative time = rounds of blocks x keys per block; measured in
+    profiles/r06/attn_tall_tiles_ab.jsonl and attn_tall_tiles_splits_probe.jsonl."""
+    from livecc_amd import _lib, ops
+    assert ops.attn_tile_rows(28, 4) == 36 and ops.attn_tile_rows(64, 8) == 32 and ops.attn_tile_rows(12, 2) == 42 and ops.attn_tile_rows(16, 1) == 32
+    plan = lambda n_new, kv, hq=28, hkv=4, cus=256: ops.attn_plan(n_new, kv, hq, hkv, cus)      # noqa: E731
+    assert plan([386], 6586) == (36, 5)              # one streaming chunk: 11 tiles x 4 KV heads x 5 splits = 220 blocks, one round (65 us; (32, 4): 73)
+    assert plan([386] * 2, 6586) == (32, 2)          # 208 blocks, one round: 113.7 us ((36, 8) 126, (32, 7) 129: what "fill the last round" chose)
+    assert plan([386] * 3, 6586) == (32, 1)          # 1,158 rows: no split above 1,024 rows (the partial buffers); 156 / 132 blocks: one round, a tie
+    assert plan([386] * 4, 6586) == (32, 1)          # 208 blocks unsplit, a tie with the tall tile
+    assert plan([386] * 5, 6586) == (36, 1)          # 260 blocks = two rounds, 220 tall ones = one
+    assert plan([300] * 3, 6586) == (32, 2)          # 900 rows may split: 30 tiles x 4 x 2 = 240 blocks of half the keys, one round
+    assert plan([386] * 8, 6586) == (32, 1)          # 416 / 352 blocks: two rounds either way
+    assert plan([1131] * 8, 1131) == (36, 1)         # 1152 -> 1024 blocks: five rounds -> four
+    assert plan([4096], 12288) == (32, 1)            # a one-shot piece: 512 / 456 blocks, two rounds either way
+    assert plan([386], 200) == (32, 1)               # too few keys to split (>= 8 key tiles per split): 52 / 44 blocks, one round: a tie
+    assert plan([386], 26000) == (36, 5)             # a long history changes nothing for one chunk
+    assert plan([386], 6586, 64, 8) == (32, 2)       # 72B heads (G = 8): the tall tile does not exist; 13 x 8 x 2 = 208 blocks
+    assert plan([386], 6586, 32, 2) == (0, 0)        # 16 query heads per KV head: another kernel family
+    with pytest.raises(_lib.LccError):
+        plan([386, 0], 6586)
+    with pytest.raises(_lib.LccError):
+        plan([386], 6586, 28, 5)

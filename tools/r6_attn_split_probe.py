@@ -51,8 +51,9 @@ kv = ops.KvArena(8, 1, Hkv, 24576 + 8192, dev)
 kv.buf.copy_((torch.randn(kv.buf.shape, device=dev) * 0.7).to(torch.bfloat16))
 tall = ops.attn_tile_rows(Hq, Hkv)
 for name, segs in (("chunk_8streams", [(s, 386, 6200) for s in range(8)]), ("chunk_4streams", [(s, 386, 6200) for s in range(4)]),
-                   ("chunk_8streams_12k", [(s, 386, 12000) for s in range(8)]), ("chunk_2streams", [(s, 386, 6200) for s in range(2)])):
+                   ("chunk_8streams_12k", [(s, 386, 12000) for s in range(8)]), ("chunk_2streams", [(s, 386, 6200) for s in range(2)]),
+                   ("chunk_3streams", [(s, 386, 6200) for s in range(3)])):
     for rep in range(2):
-        for tr, nsplit in ((32, 1), (tall, 1), (tall, 2), (32, 2), (tall, 3), (tall, 4)):
+        for tr, nsplit in ((32, 1), (tall, 1), (tall, 2), (32, 2), (tall, 3), (tall, 4)) + (((32, 7), (tall, 8)) if len(segs) == 2 else ()):
             us, pf = run(kv, segs, tr, nsplit)
             print(json.dumps(dict(case=name, repetition=rep, tile_rows=tr, nsplit=nsplit, us=round(us, 1), pflops=round(pf, 3))), flush=True)
