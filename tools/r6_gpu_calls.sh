@@ -79,6 +79,11 @@ vit_lsum)      # tower attention: softmax denominator from the P.V MFMAs (ones r
   for m in 0 1; do LCC_VIT32_LSUM_MFMA=$m timeout 1200 python -m pytest tests/test_gpu_vit_fused.py tests/test_gpu_ops.py tests/test_gpu_e2e.py tests/test_gpu_golden.py tests/test_gpu_layer_parity.py -q -x -k "not 72b" 2>&1 | tail -1 | sed "s/^/lsum_mfma=$m: /" >> $O/tests.txt; done
   for m in 0 1 0 1; do LCC_VIT32_LSUM_MFMA=$m python tools/r5_tower.py "lsum_mfma=$m" >> $O/tower_lsum_mfma_ab.jsonl 2>/dev/null; done
   cat $O/tests.txt $O/tower_lsum_mfma_ab.jsonl ;;
+pmc_attn)      # MfmaUtil of the 32x32x16 attention kernels (LLM prefill shapes of tools/bench_attn.py --only32, then the tower at 8 / 1 chunks)
+  cd /tmp; timeout 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/p1 -o a -- python $R/tools/bench_attn.py --only32 > $O/bench_attn_under_pmc.jsonl 2>$O/p1.err
+  timeout 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/p2 -o t -- python $R/tools/r5_tower.py pmc > $O/tower_under_pmc.jsonl 2>$O/p2.err
+  cd $R; python tools/r6_summarize_attn_pmc.py $O/p1 > $O/attn_mfma_util.jsonl; python tools/r6_summarize_attn_pmc.py $O/p2 >> $O/attn_mfma_util.jsonl
+  rm -rf $O/p1 $O/p2; cat $O/attn_mfma_util.jsonl ;;
 attn_direct)   # decode attention with the stream state by value (LCC_ATTN_DIRECT), whole replay without the tower prefetch, A/B/A/B
   for d in 0 1 0 1; do LCC_ATTN_DIRECT=$d python bench.py --steps 3 --warmup 1 --no-prefetch $QUIET 2>/dev/null | step "attn_direct=$d" >> $O/attn_direct_ab.jsonl; done
   cat $O/attn_direct_ab.jsonl ;;
@@ -90,5 +95,5 @@ tall)          # one-chunk GEMMs: tall kernel schedule A/B
   for s in 0 1 2 0 1 2; do LCC_TALL_SCHED=$s python tools/r6_tall_sched.py "tall_sched$s" 2>/dev/null >> $O/m386_gemms_ab.jsonl; done; cat $O/m386_gemms_ab.jsonl ;;
 rccl)          # can RCCL run two ranks on the box's one GPU?
   timeout 150 python tools/r6_rccl_same_device_probe.py | tee $O/rccl_probe.json ;;
-*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof pingpong vit_lsum attn_direct attn_tps tall rccl" ;;
+*) echo "recipes: tier bench pmc pmc_gemv attn_map attn_rowmajor attn_vgprform attn_tall tower4 tower_prof pingpong vit_lsum pmc_attn attn_direct attn_tps tall rccl" ;;
 esac
